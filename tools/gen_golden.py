@@ -1,0 +1,277 @@
+"""Generate golden vectors by RUNNING the reference's Python in the build container.
+
+    python tools/gen_golden.py            # writes tests/golden/*.npz
+
+Every fixture holds seeded inputs + the reference's outputs (data only).  The
+script needs /root/reference and is never run on the GPU box.  Fixtures whose
+outputs went through the reference's native extensions carry
+`native = "oracle"`: those extensions are unbuildable here, so this repo's C
+oracle stood in for them (tools/ref_harness.py) and the fixture pins only the
+Python graph logic around them.
+"""
+import os
+import sys
+import tempfile
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from tools import ref_harness  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def save(name, **arrs):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
+def small_config(ref_config, dim, num_classes=2):
+    class Cfg(ref_config.Config):
+        NAME = "golden"
+        GPU_COUNT = 0
+        IMAGE_MAX_DIM = dim
+        IMAGE_MIN_DIM = dim
+        NUM_CLASSES = num_classes
+        EXPERIMENT_DIR = tempfile.mkdtemp()
+    return Cfg()
+
+
+def synth_label(rng, H, W, n_obj, hole=None):
+    """Painter's-order ellipses -> uint64 label."""
+    yy, xx = np.mgrid[0:H, 0:W]
+    masks = []
+    for i in range(n_obj):
+        cy, cx = rng.uniform(0.2, 0.8) * H, rng.uniform(0.2, 0.8) * W
+        ry, rx = rng.uniform(0.1, 0.35) * H, rng.uniform(0.1, 0.35) * W
+        masks.append(((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 <= 1.0)
+    from oracle.oracle import encode_labels
+    return encode_labels(np.stack(masks)), np.stack(masks)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    ref_modals, ref_F = ref_harness.install()
+    import utils as ref_utils
+    import config as ref_config
+    import modal.loss as ref_loss
+    import amodal_train as ref_train
+
+    # ---------------------------------------------------------------- anchors
+    for dim in (128, 256):
+        cfg = small_config(ref_config, dim)
+        a = ref_utils.generate_pyramid_anchors(cfg.RPN_ANCHOR_SCALES, cfg.RPN_ANCHOR_RATIOS,
+                                               cfg.BACKBONE_SHAPES, cfg.BACKBONE_STRIDES,
+                                               cfg.RPN_ANCHOR_STRIDE)
+        save("anchors_%d" % dim, anchors=a, shapes=cfg.BACKBONE_SHAPES)
+    cfg = small_config(ref_config, 1024)
+    a = ref_utils.generate_pyramid_anchors(cfg.RPN_ANCHOR_SCALES, cfg.RPN_ANCHOR_RATIOS,
+                                           cfg.BACKBONE_SHAPES, cfg.BACKBONE_STRIDES, 1)
+    save("anchors_1024_digest", count=np.array(a.shape[0]), colsum=a.sum(axis=0),
+         first=a[:7], last=a[-7:], stride_sample=a[::9973])
+
+    # ----------------------------------------------------------- label decode
+    rng = np.random.RandomState(7)
+    cases = {}
+    specs = [(48, 64, 5, 1), (48, 64, 5, 2), (48, 64, 6, 4), (40, 40, 8, 4), (33, 47, 3, 3),
+             (32, 32, 1, 1)]
+    for ci, (H, W, n, L) in enumerate(specs):
+        label, _ = synth_label(rng, H, W, n)
+        if ci == 3:  # stress: hand-made deep occlusion stack + stray bits
+            label[5:20, 5:20] |= np.uint64(0b1011) << np.uint64(32)
+            label[25:30, 25:30] = (np.uint64(1) << np.uint64(2)) | (np.uint64(0b11110011) << np.uint64(32))
+        tmp = tempfile.mkdtemp()
+        np.savez(os.path.join(tmp, "img.npz"), layer=label)
+
+        class FakeSelf:
+            image_info = [{"path": os.path.join(tmp, "img.jpg"), "height": H, "width": W}]
+
+        cfgL = small_config(ref_config, 128, num_classes=L + 1)
+        out = ref_train.AmodalDataset.load_layer2(FakeSelf(), 0, cfgL)
+        if not isinstance(out, tuple) or out[0].ndim != 4:
+            raise RuntimeError("unexpected load_layer2 output")
+        mask_layers, class_ids = out  # [H,W,L,N] bool
+        # load_image_gt tail (Functions.py:735) + Dataset.__getitem__ (model.py:114)
+        ml = (np.swapaxes(mask_layers, 2, 3) > 0).astype("uint8")
+        planes = ml.transpose(3, 2, 0, 1)  # [L,N,H,W]
+        cases["label_%d" % ci] = label
+        cases["planes_%d" % ci] = planes
+        cases["L_%d" % ci] = np.array(L)
+        cases["class_ids_%d" % ci] = class_ids
+    save("label_decode", n_cases=np.array(len(specs)), **cases)
+
+    # ------------------------------------------------------------- box ops
+    g = torch.Generator().manual_seed(11)
+    n = 257
+    anc = torch.rand(n, 2, generator=g) * 200
+    anc = torch.cat([anc, anc + torch.rand(n, 2, generator=g) * 150 + 1], 1)
+    dl = torch.randn(n, 4, generator=g) * 0.7
+    dec = ref_F.apply_box_deltas(anc.clone(), dl * torch.tensor([[0.1, 0.1, 0.2, 0.2]]))
+    clip = ref_F.clip_boxes(dec, np.array([0, 0, 256, 256]).astype(np.float32))
+    b1 = torch.rand(40, 2, generator=g) * 0.6
+    b1 = torch.cat([b1, b1 + torch.rand(40, 2, generator=g) * 0.4], 1)
+    b2 = torch.rand(9, 2, generator=g) * 0.6
+    b2 = torch.cat([b2, b2 + torch.rand(9, 2, generator=g) * 0.4], 1)
+    ov = ref_F.bbox_overlaps(b1, b2)
+    refine = ref_utils.box_refinement(b1[:9], b2)
+    save("box_ops", anchors=anc.numpy(), deltas=dl.numpy(), decoded=dec.numpy(),
+         clipped=clip.numpy(), b1=b1.numpy(), b2=b2.numpy(), overlaps=ov.numpy(),
+         refine=refine.numpy())
+
+    # ------------------------------------------------------- proposal_layer
+    for dim in (128, 256):
+        cfg = small_config(ref_config, dim)
+        anchors = torch.from_numpy(ref_utils.generate_pyramid_anchors(
+            cfg.RPN_ANCHOR_SCALES, cfg.RPN_ANCHOR_RATIOS, cfg.BACKBONE_SHAPES,
+            cfg.BACKBONE_STRIDES, 1)).float()
+        A = anchors.shape[0]
+        # torch's sort is not stable: keep the fixture free of fg-score ties so the
+        # visiting order is well defined ("Sort ties").
+        g = torch.Generator().manual_seed(100 + dim)
+        fg = (torch.randperm(A, generator=g).float() + 0.5) / A
+        assert np.unique(fg.numpy()).size == A
+        probs = torch.stack([1 - fg, fg], dim=1).unsqueeze(0)
+        deltas = torch.randn(1, A, 4, generator=g) * 0.8
+        rois = ref_F.proposal_layer([probs.clone(), deltas.clone()], proposal_count=1000,
+                                    nms_threshold=0.7, anchors=anchors, config=cfg)
+        save("proposal_layer_%d" % dim, native=np.array("oracle"), probs=probs.numpy(),
+             deltas=deltas.numpy(), anchors=anchors.numpy(), rois=rois.numpy())
+
+    # --------------------------------------------------- pyramid_roi_align
+    g = torch.Generator().manual_seed(5)
+    C = 8
+    maps = [torch.randn(1, C, s, s, generator=g, requires_grad=True) for s in (64, 32, 16, 8)]
+    R = 60
+    ctr = torch.rand(R, 2, generator=g)
+    size = torch.exp(torch.rand(R, 2, generator=g) * 4.5 - 4.6)
+    boxes_big = None  # spans levels 2..5 + clamps
+    boxes = torch.cat([ctr - size / 2, ctr + size / 2], 1).clamp(0, 1)
+    boxes[0] = torch.tensor([0.1, 0.1, 0.1 + 112 / 1024, 0.1 + 112 / 1024])  # exact level edges
+    boxes[1] = torch.tensor([0.2, 0.2, 0.2 + 224 / 1024, 0.2 + 224 / 1024]).clamp(0, 1)
+    boxes[2] = torch.tensor([0.3, 0.3, 0.3 + 56 / 1024, 0.3 + 56 / 1024])
+    pooled = ref_modals.pyramid_roi_align([boxes.unsqueeze(0)] + list(maps), 7, (1024, 1024, 3))
+    up = torch.randn(pooled.shape, generator=g)
+    pooled.backward(up)
+    h, w = boxes[:, 2] - boxes[:, 0], boxes[:, 3] - boxes[:, 1]
+    lvl = 4 + ref_modals.log2(torch.sqrt(h * w) / (224.0 / torch.sqrt(torch.tensor([1024.0 * 1024]))))
+    lvl = lvl.round().int().clamp(2, 5)
+    save("pyramid_roi_align", native=np.array("oracle"), boxes=boxes.numpy(),
+         levels=lvl.numpy(), pooled=pooled.detach().numpy(), upstream=up.numpy(),
+         **{"map%d" % i: m.detach().numpy() for i, m in enumerate(maps)},
+         **{"grad%d" % i: (m.grad.numpy() if m.grad is not None else np.zeros(m.shape, np.float32))
+            for i, m in enumerate(maps)})
+
+    # ----------------------------------------------- detection_target_layer
+    cfg = small_config(ref_config, 128)
+    rng = np.random.RandomState(21)
+    H = W = 128
+    label, amodal = synth_label(rng, H, W, 5)
+    from oracle import oracle as orc
+    for case, L in (("a", 1), ("b", 3)):
+        planes = orc.label_decode(label, L)  # [L,N,H,W]; decode itself pinned above
+        N = planes.shape[1]
+        gt_boxes = []
+        am = planes.sum(axis=0) > 0
+        for i in range(N):
+            ys, xs = np.where(am[i])
+            gt_boxes.append([ys.min(), xs.min(), ys.max() + 1, xs.max() + 1])
+        gt_boxes = torch.tensor(gt_boxes, dtype=torch.float32) / 128.0
+        g = torch.Generator().manual_seed(31)
+        P = 300
+        jit = torch.randn(P, 4, generator=g) * 0.04
+        props = gt_boxes[torch.randint(0, N, (P,), generator=g)] + jit
+        props[200:] = torch.rand(100, 4, generator=g).sort(dim=1)[0][:, [0, 1, 2, 3]]
+        props = torch.stack([torch.minimum(props[:, 0], props[:, 2]), torch.minimum(props[:, 1], props[:, 3]),
+                             torch.maximum(props[:, 0], props[:, 2]) + 0.02,
+                             torch.maximum(props[:, 1], props[:, 3]) + 0.02], 1).clamp(0, 1)
+        draws = []
+        real = torch.randperm
+
+        def rec(n, *a, **k):
+            p = real(n, *a, **k)
+            draws.append(p.numpy().copy())
+            return p
+
+        torch.randperm = rec
+        try:
+            rois, cls, dl, masks = ref_F.detection_target_layer(
+                props.unsqueeze(0), torch.ones(1, N, dtype=torch.int32), gt_boxes.unsqueeze(0),
+                torch.from_numpy(planes).unsqueeze(0), cfg)
+        finally:
+            torch.randperm = real
+        save("detection_target_%s" % case, native=np.array("oracle"), proposals=props.numpy(),
+             gt_boxes=gt_boxes.numpy(), label=label, L=np.array(L), perm_pos=draws[0],
+             perm_neg=draws[1], rois=rois.numpy(), class_ids=cls.numpy(),
+             deltas=dl.numpy(), masks=masks.numpy())
+
+    # ---------------------------------------------------- build_rpn_targets
+    for dim in (128, 256):
+        cfg = small_config(ref_config, dim)
+        anchors = ref_utils.generate_pyramid_anchors(cfg.RPN_ANCHOR_SCALES, cfg.RPN_ANCHOR_RATIOS,
+                                                     cfg.BACKBONE_SHAPES, cfg.BACKBONE_STRIDES, 1)
+        rng = np.random.RandomState(dim)
+        N = 6
+        tl = rng.randint(0, dim // 2, size=(N, 2))
+        wh = rng.randint(dim // 10, dim // 2, size=(N, 2))
+        gt = np.concatenate([tl, np.minimum(tl + wh, dim)], 1).astype(np.int32)
+        draws = []
+        real_choice = np.random.choice
+
+        def rec_choice(ids, extra, replace=False):
+            r = real_choice(ids, extra, replace=replace)
+            draws.append(np.asarray(r).copy())
+            return r
+
+        np.random.seed(dim)
+        np.random.choice = rec_choice
+        try:
+            match, bbox = ref_F.build_rpn_targets((dim, dim, 3), anchors,
+                                                  np.ones(N, np.int32), gt, cfg)
+        finally:
+            np.random.choice = real_choice
+        save("rpn_targets_%d" % dim, gt_boxes=gt, rpn_match=match, rpn_bbox=bbox,
+             n_draws=np.array(len(draws)),
+             **{"draw%d" % i: d for i, d in enumerate(draws)})
+
+    # ----------------------------------------------------------------- losses
+    g = torch.Generator().manual_seed(77)
+    A, R, P, L = 500, 40, 25, 1
+    rpn_match = torch.zeros(1, A, 1, dtype=torch.int32)
+    idx = torch.randperm(A, generator=g)
+    rpn_match[0, idx[:30], 0] = 1
+    rpn_match[0, idx[30:130], 0] = -1
+    rpn_logits = torch.randn(1, A, 2, generator=g, requires_grad=True)
+    rpn_bbox_t = torch.zeros(1, 256, 4)
+    rpn_bbox_t[0, :30] = torch.randn(30, 4, generator=g)
+    rpn_bbox_p = torch.randn(1, A, 4, generator=g, requires_grad=True)
+    tcls = torch.cat([torch.ones(P), torch.zeros(R - P)]).int()
+    cls_logits = torch.randn(R, 2, generator=g, requires_grad=True)
+    tdl = torch.cat([torch.randn(P, 4, generator=g), torch.zeros(R - P, 4)])
+    pdl = torch.randn(R, 2, 4, generator=g, requires_grad=True)
+    tmask = torch.cat([(torch.rand(P, L, 32, 32, generator=g) > 0.5).float(),
+                       torch.zeros(R - P, L, 32, 32)])
+    pmask = torch.randn(R, 1 + L, 32, 32, generator=g, requires_grad=True)
+    l_rc = ref_loss.compute_rpn_class_loss(rpn_match, rpn_logits)
+    l_rb = ref_loss.compute_rpn_bbox_loss(rpn_bbox_t, rpn_match, rpn_bbox_p)
+    l_mc = ref_loss.compute_mrcnn_class_loss(tcls, cls_logits)
+    l_mb = ref_loss.compute_mrcnn_bbox_loss(tdl, tcls, pdl)
+    l_ly, _, _ = ref_loss.compute_layer_loss(tmask, tcls, pmask)
+    l_am, _ = ref_loss.compute_amodal_loss(tmask, tcls, pmask)
+    total = l_ly + l_rb + l_mb + l_mc + l_am + l_rc
+    total.backward()
+    save("losses", rpn_match=rpn_match.numpy(), rpn_logits=rpn_logits.detach().numpy(),
+         rpn_bbox_t=rpn_bbox_t.numpy(), rpn_bbox_p=rpn_bbox_p.detach().numpy(),
+         tcls=tcls.numpy(), cls_logits=cls_logits.detach().numpy(), tdl=tdl.numpy(),
+         pdl=pdl.detach().numpy(), tmask=tmask.numpy(), pmask=pmask.detach().numpy(),
+         losses=np.array([l_rc.item(), l_rb.item(), l_mc.item(), l_mb.item(), l_ly.item(),
+                          l_am.item()], dtype=np.float64),
+         g_rpn_logits=rpn_logits.grad.numpy(), g_rpn_bbox=rpn_bbox_p.grad.numpy(),
+         g_cls_logits=cls_logits.grad.numpy(), g_pdl=pdl.grad.numpy(),
+         g_pmask=pmask.grad.numpy())
+
+
+if __name__ == "__main__":
+    main()
