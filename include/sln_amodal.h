@@ -1,0 +1,142 @@
+/*
+ * sln_amodal.h -- C ABI of libsln_amodal_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the native ops of SLN-Amodal's detection hot path.  Each
+ * entry point replaces one symbol (or one tight group) of the reference's
+ * torch.utils.ffi extensions; the replaced interface is cited per function
+ * (paths relative to the reference repository root).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch / TH types.
+ *   - every data pointer is a DEVICE pointer unless marked host.
+ *   - every entry point takes the HIP stream to launch on (`void*` = hipStream_t,
+ *     NULL = the default stream), enqueues asynchronously and never synchronises
+ *     the device or copies to the host (the reference's gpu_nms copies the whole
+ *     mask to the host and reduces it there, nms/src/nms_cuda.c:31-58).
+ *   - the caller owns and sizes every buffer; nothing is retained after return.
+ *   - return value: 0 = SLN_OK, otherwise an SLN_ERR_* code; never exit()s
+ *     (the reference CPU crop exit(-1)s on a bad box index,
+ *     roialign/roi_align/src/crop_and_resize.c:39-42).
+ *   - thread-safe: no global mutable state.
+ */
+#ifndef SLN_AMODAL_H
+#define SLN_AMODAL_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SLN_OK 0
+#define SLN_ERR_INVALID_ARG 1
+#define SLN_ERR_WORKSPACE 2
+#define SLN_ERR_LAUNCH 3
+#define SLN_ERR_UNSUPPORTED 4
+
+/* memory layout of [B,C,H,W]-shaped tensors */
+#define SLN_LAYOUT_NCHW 0 /* reference layout                                   */
+#define SLN_LAYOUT_NHWC 1 /* channels-last: what the HIP conv stack produces    */
+
+typedef void *sln_stream_t; /* hipStream_t */
+
+int sln_abi_version(void);
+const char *sln_error_string(int code);
+
+/* ---------------------------------------------------------------------------
+ * Greedy NMS, batched over images, reduce kept on the device.
+ * Replaces: int gpu_nms(THLongTensor* keep, THLongTensor* num_out,
+ *                       THCudaTensor* boxes, float thresh)
+ *           (nms/src/nms_cuda.h, nms/src/nms_cuda.c:17-67,
+ *            nms/src/cuda/nms_kernel.cu:26-83)
+ * with the *CPU* semantics the north star pins (nms/src/nms.c:55-61):
+ * suppress when inter/(area_i+area_j-inter) >= thresh, widths/heights with the
+ * legacy +1, fp32 IEEE, areas = (x2-x1+1)*(y2-y1+1) (nms/pth_nms.py:16).
+ *
+ * dets      [B,N,5] f32 rows (y1,x1,y2,x2,score), ALREADY sorted by score,
+ *           descending, per image (like gpu_nms's `boxes`).
+ * n_valid   [B] int32 number of leading valid rows per image, or NULL (= N).
+ * keep      [B,max_out] int64: indices into the sorted rows, visiting order;
+ *           entries past num_keep[b] are set to -1.
+ * num_keep  [B] int32: min(#kept, max_out).
+ * workspace device scratch of sln_nms_workspace_bytes(B,N) bytes.
+ * ------------------------------------------------------------------------- */
+size_t sln_nms_workspace_bytes(int B, int N);
+int sln_nms_f32(const float *dets, int B, int N, const int32_t *n_valid, float thresh,
+                int max_out, int64_t *keep, int32_t *num_keep, void *workspace,
+                size_t workspace_bytes, sln_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * crop_and_resize (TensorFlow-style RoIAlign, one bilinear sample per bin).
+ * Replaces: crop_and_resize_gpu_forward / crop_and_resize_gpu_backward
+ *           (roialign/roi_align/src/crop_and_resize_gpu.h:1-16,
+ *            roialign/roi_align/src/cuda/crop_and_resize_kernel.cu:10-221)
+ * with the arithmetic of the CPU path
+ *           (roialign/roi_align/src/crop_and_resize.c:6-252).
+ *
+ * image     [B,C,H,W] f32 in `layout`;  boxes [K,4] f32 normalised
+ *           (y1,x1,y2,x2);  box_ind [K] int32 in [0,B).
+ * crops     [K,C,ch,cw] f32 in the same `layout` (NHWC: [K,ch,cw,C]); every
+ *           element is written (no pre-zeroing needed).
+ * err_flag  optional device int32; bit 0 is OR-ed in when a box index is out of
+ *           range (that box's crop is filled with zeros, its gradient skipped).
+ * backward: grad_image [B,C,H,W] is zeroed by the callee, then accumulated with
+ *           fp32 atomics (summation order is not deterministic).
+ * ------------------------------------------------------------------------- */
+int sln_crop_and_resize_fwd_f32(const float *image, int B, int C, int H, int W, int layout,
+                                const float *boxes, const int32_t *box_ind, int K, int ch,
+                                int cw, float extrapolation_value, float *crops,
+                                int32_t *err_flag, sln_stream_t stream);
+int sln_crop_and_resize_bwd_f32(const float *grads, const float *boxes,
+                                const int32_t *box_ind, int K, int ch, int cw, int B, int C,
+                                int H, int W, int layout, float *grad_image,
+                                int32_t *err_flag, sln_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * Sem-dist ("layer") target decode: per-pixel uint64 occlusion label ->
+ * per-instance bit planes.
+ * Replaces (Python/numpy in the reference): AmodalDataset.load_layer2
+ *           (amodal_train.py:236-271) + get_image_labals, max_objectID,
+ *           objectID_to_masks, maskID_to_objectIDs, number_to_index,
+ *           objIDs_to_sindistanceLayer (modal/Functions.py:1012-1095) + the axis
+ *           shuffle of modal/Functions.py:735 and model.py:114.
+ *
+ * label     [B,H,W] uint64 (low word: visible object bits, high word: occluded)
+ * n_obj     [B] int32 out: object count per image (max_objectID semantics).
+ * planes    [B,L,N,H,W] uint8 out, fully written; objects >= n_obj[b] are zero.
+ * ------------------------------------------------------------------------- */
+int sln_label_num_objects_u64(const uint64_t *label, int B, int64_t npix, int32_t *n_obj,
+                              sln_stream_t stream);
+int sln_label_decode_u64(const uint64_t *label, int B, int H, int W, int L, int N,
+                         uint8_t *planes, sln_stream_t stream);
+
+/* Fused mask-target generation: decode + crop_and_resize + round-half-even in
+ * one pass over the label (never materialises the [L,P,H,W] float planes of
+ * modal/Functions.py:329-346).
+ * rois [K,4] normalised; roi_img [K] image index; roi_obj [K] object index
+ * (the roi's assigned GT instance); masks [K,L,mh,mw] f32 in {0,1}. */
+int sln_mask_targets_u64(const uint64_t *label, int B, int H, int W, int L, const float *rois,
+                         const int32_t *roi_img, const int32_t *roi_obj, int K, int mh,
+                         int mw, float *masks, sln_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * Proposal front end (modal/Functions.py:114-178, :77-111): gather the top-n
+ * anchors by foreground score, scale deltas by std_dev, decode against the
+ * pixel-space anchors, clip to [0,win], emit NMS-ready rows.
+ * probs [B,A,2], deltas [B,A,4], anchors [A,4], order [B,n] int64 anchor indices
+ * (score-descending); std_dev: 4 host floats.  dets [B,n,5] out.
+ * sln_gather_rois: rois[b,r,:] = dets[b,keep[b,r],:4] / (h,w,h,w) for
+ * r < num_keep[b], zero padding after (Functions.py:166-176).
+ * ------------------------------------------------------------------------- */
+int sln_proposal_decode_f32(const float *probs, const float *deltas, const float *anchors,
+                            const int64_t *order, int B, int A, int n, const float *std_dev,
+                            float win_h, float win_w, float *dets, sln_stream_t stream);
+int sln_gather_rois_f32(const float *dets, const int64_t *keep, const int32_t *num_keep, int B,
+                        int N, int max_out, float norm_h, float norm_w, float *rois,
+                        sln_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SLN_AMODAL_H */

@@ -1,0 +1,60 @@
+"""ctypes loader for libsln_amodal_hip.so (the C-ABI drop-in boundary).
+
+The product path fails loudly when the HIP library is missing: there is no CPU
+or eager-PyTorch fallback for the native ops.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libsln_amodal_hip.so")
+_lib = None
+
+_p = C.c_void_p
+_i = C.c_int
+_f = C.c_float
+
+# name -> (restype, argtypes); mirrors include/sln_amodal.h one to one.
+SIGNATURES = {
+    "sln_abi_version": (_i, []),
+    "sln_error_string": (C.c_char_p, [_i]),
+    "sln_nms_workspace_bytes": (C.c_size_t, [_i, _i]),
+    "sln_nms_f32": (_i, [_p, _i, _i, _p, _f, _i, _p, _p, _p, C.c_size_t, _p]),
+    "sln_crop_and_resize_fwd_f32": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _i, _i, _i, _f, _p, _p, _p]),
+    "sln_crop_and_resize_bwd_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
+    "sln_label_num_objects_u64": (_i, [_p, _i, C.c_int64, _p, _p]),
+    "sln_label_decode_u64": (_i, [_p, _i, _i, _i, _i, _i, _p, _p]),
+    "sln_mask_targets_u64": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _i, _i, _i, _p, _p]),
+    "sln_proposal_decode_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, C.POINTER(_f), _f, _f, _p, _p]),
+    "sln_gather_rois_f32": (_i, [_p, _p, _p, _i, _i, _i, _f, _f, _p, _p]),
+}
+
+
+class HipExtensionMissing(RuntimeError):
+    pass
+
+
+def register(name, restype, argtypes):
+    SIGNATURES[name] = (restype, argtypes)
+    if _lib is not None:
+        fn = getattr(_lib, name)
+        fn.restype, fn.argtypes = restype, argtypes
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipExtensionMissing(
+                "%s not found: build it with `python -m sln_amodal_amd.csrc.build` "
+                "(hipcc --offload-arch=gfx950). No CPU fallback exists." % LIB_PATH)
+        _lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(_lib, name)  # AttributeError if the .so lacks a declared symbol
+            fn.restype, fn.argtypes = res, args
+    return _lib
+
+
+def check(code, what):
+    if code != 0:
+        raise RuntimeError("%s failed: %s" % (what, lib().sln_error_string(code).decode()))

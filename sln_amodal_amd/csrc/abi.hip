@@ -1,0 +1,14 @@
+#include "common.h"
+
+extern "C" int sln_abi_version(void) { return 1; }
+
+extern "C" const char *sln_error_string(int code) {
+    switch (code) {
+        case SLN_OK: return "ok";
+        case SLN_ERR_INVALID_ARG: return "invalid argument";
+        case SLN_ERR_WORKSPACE: return "workspace too small";
+        case SLN_ERR_LAUNCH: return "kernel launch failed";
+        case SLN_ERR_UNSUPPORTED: return "unsupported configuration";
+        default: return "unknown error";
+    }
+}

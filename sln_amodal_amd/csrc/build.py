@@ -1,0 +1,48 @@
+"""Builds libsln_amodal_hip.so in-tree with hipcc for gfx950 (cross-compiles
+without a GPU).  Exact-arithmetic kernels (NMS, crop_and_resize, label decode,
+proposal decode) are compiled with -ffp-contract=off and correctly rounded
+division so index-producing float math rounds like the reference CPU path."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "libsln_amodal_hip.so")
+
+EXACT = ["abi.hip", "nms.hip", "crop_and_resize.hip", "label_decode.hip", "proposal.hip"]
+FAST = [f for f in sorted(os.listdir(HERE)) if f.endswith(".hip") and f not in EXACT]
+
+COMMON = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall",
+          "-Wno-unused-function", "-fgpu-rdc" if False else "-fno-gpu-rdc"]
+EXACT_FLAGS = ["-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math"]
+
+
+def _stale(out, deps):
+    return (not os.path.exists(out)) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps)
+
+
+def build(force=False, verbose=False):
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    hdrs = [os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith(".h")]
+    hdrs.append(os.path.join(HERE, "..", "..", "include", "sln_amodal.h"))
+    objs = []
+    for name in EXACT + FAST:
+        src = os.path.join(HERE, name)
+        obj = os.path.join(HERE, name.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or _stale(obj, [src] + hdrs):
+            flags = COMMON + (EXACT_FLAGS if name in EXACT else [])
+            cmd = [hipcc, "-c", "-x", "hip", src, "-o", obj] + flags
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+    if force or _stale(LIB, objs):
+        cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

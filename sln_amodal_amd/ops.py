@@ -1,0 +1,190 @@
+"""Tensor-level bindings of the C ABI (include/sln_amodal.h).
+
+PyTorch is plumbing here: it owns device memory and the current HIP stream; all
+arithmetic happens in libsln_amodal_hip.so.  Every function enqueues on
+torch's current stream and returns without synchronising.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+LAYOUT_NCHW, LAYOUT_NHWC = 0, 1
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _need(t, dtype, name):
+    if not t.is_cuda:
+        raise RuntimeError("%s must live on the GPU (no CPU fallback in sln_amodal_amd)" % name)
+    if t.dtype != dtype:
+        raise TypeError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    return t
+
+
+def layout_of(t):
+    """NHWC if the 4-d tensor is channels-last in memory (and not also plain
+    contiguous), else NCHW."""
+    if t.is_contiguous():
+        return LAYOUT_NCHW
+    if t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last):
+        return LAYOUT_NHWC
+    return None
+
+
+# ---------------------------------------------------------------------------- NMS
+_ws_cache = {}
+
+
+def _workspace(nbytes, device):
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def nms_sorted(dets, thresh, max_out, n_valid=None):
+    """dets [B,N,5] f32 (y1,x1,y2,x2,score), score-descending per image.
+    Returns keep [B,max_out] int64 (-1 padded) and num_keep [B] int32."""
+    _need(dets, torch.float32, "dets")
+    if dets.dim() != 3 or dets.shape[2] != 5:
+        raise ValueError("dets must be [B,N,5]")
+    dets = dets.contiguous()
+    B, N = dets.shape[0], dets.shape[1]
+    keep = torch.empty((B, max_out), dtype=torch.int64, device=dets.device)
+    num = torch.empty((B,), dtype=torch.int32, device=dets.device)
+    L = _lib.lib()
+    nbytes = L.sln_nms_workspace_bytes(B, N)
+    ws = _workspace(nbytes, dets.device)
+    if n_valid is not None:
+        n_valid = _need(n_valid, torch.int32, "n_valid").contiguous()
+    _lib.check(L.sln_nms_f32(_ptr(dets), B, N, _ptr(n_valid), float(thresh), int(max_out),
+                             _ptr(keep), _ptr(num), _ptr(ws), nbytes, _stream()), "sln_nms_f32")
+    return keep, num
+
+
+# ---------------------------------------------------------------- crop_and_resize
+def crop_and_resize_fwd(image, boxes, box_ind, ch, cw, extrap=0.0, err_flag=None):
+    _need(image, torch.float32, "image")
+    _need(boxes, torch.float32, "boxes")
+    _need(box_ind, torch.int32, "box_ind")
+    if image.dim() != 4:
+        raise ValueError("image must be [B,C,H,W]")
+    lay = layout_of(image)
+    if lay is None:
+        image = image.contiguous()
+        lay = LAYOUT_NCHW
+    boxes = boxes.contiguous().view(-1, 4)
+    box_ind = box_ind.contiguous()
+    B, Cc, H, W = image.shape
+    K = boxes.shape[0]
+    if box_ind.numel() != K:
+        raise ValueError("box_ind must have one entry per box")
+    fmt = torch.channels_last if lay == LAYOUT_NHWC else torch.contiguous_format
+    crops = torch.empty((K, Cc, ch, cw), dtype=torch.float32, device=image.device,
+                        memory_format=fmt)
+    _lib.check(_lib.lib().sln_crop_and_resize_fwd_f32(
+        _ptr(image), B, Cc, H, W, lay, _ptr(boxes), _ptr(box_ind), K, int(ch), int(cw),
+        float(extrap), _ptr(crops), _ptr(err_flag), _stream()), "sln_crop_and_resize_fwd_f32")
+    return crops
+
+
+def crop_and_resize_bwd(grads, boxes, box_ind, image_shape, layout, err_flag=None):
+    _need(grads, torch.float32, "grads")
+    B, Cc, H, W = image_shape
+    K, _, ch, cw = grads.shape
+    if layout == LAYOUT_NHWC:
+        grads = grads.contiguous(memory_format=torch.channels_last)
+        fmt = torch.channels_last
+    else:
+        grads = grads.contiguous()
+        fmt = torch.contiguous_format
+    gimg = torch.empty((B, Cc, H, W), dtype=torch.float32, device=grads.device, memory_format=fmt)
+    _lib.check(_lib.lib().sln_crop_and_resize_bwd_f32(
+        _ptr(grads), _ptr(boxes), _ptr(box_ind), K, ch, cw, B, Cc, H, W, layout, _ptr(gimg),
+        _ptr(err_flag), _stream()), "sln_crop_and_resize_bwd_f32")
+    return gimg
+
+
+# ------------------------------------------------------------------- label decode
+def label_num_objects(label):
+    """label [B,H,W] int64/uint64 bit pattern -> n_obj [B] int32 (device)."""
+    label = _as_u64(label)
+    B = label.shape[0]
+    n = torch.empty((B,), dtype=torch.int32, device=label.device)
+    _lib.check(_lib.lib().sln_label_num_objects_u64(_ptr(label), B, label[0].numel(), _ptr(n),
+                                                    _stream()), "sln_label_num_objects_u64")
+    return n
+
+
+def _as_u64(label):
+    if not label.is_cuda:
+        raise RuntimeError("label must live on the GPU")
+    if label.dtype not in (torch.int64, torch.uint64):
+        raise TypeError("label must hold 64-bit patterns (int64 or uint64)")
+    if label.dim() == 2:
+        label = label.unsqueeze(0)
+    return label.contiguous()
+
+
+def label_decode(label, L, N):
+    """label [B,H,W] -> planes [B,L,N,H,W] uint8."""
+    label = _as_u64(label)
+    B, H, W = label.shape
+    planes = torch.empty((B, L, N, H, W), dtype=torch.uint8, device=label.device)
+    _lib.check(_lib.lib().sln_label_decode_u64(_ptr(label), B, H, W, int(L), int(N), _ptr(planes),
+                                               _stream()), "sln_label_decode_u64")
+    return planes
+
+
+def mask_targets(label, L, rois, roi_img, roi_obj, mh, mw):
+    """Fused decode+crop+round: -> masks [K,L,mh,mw] f32 in {0,1}."""
+    label = _as_u64(label)
+    B, H, W = label.shape
+    rois = _need(rois, torch.float32, "rois").contiguous().view(-1, 4)
+    roi_img = _need(roi_img, torch.int32, "roi_img").contiguous()
+    roi_obj = _need(roi_obj, torch.int32, "roi_obj").contiguous()
+    K = rois.shape[0]
+    masks = torch.empty((K, L, mh, mw), dtype=torch.float32, device=label.device)
+    _lib.check(_lib.lib().sln_mask_targets_u64(_ptr(label), B, H, W, int(L), _ptr(rois),
+                                               _ptr(roi_img), _ptr(roi_obj), K, int(mh), int(mw),
+                                               _ptr(masks), _stream()), "sln_mask_targets_u64")
+    return masks
+
+
+# --------------------------------------------------------------------- proposals
+def proposal_decode(probs, deltas, anchors, order, std_dev, win_h, win_w):
+    """probs [B,A,2], deltas [B,A,4], anchors [A,4], order [B,n] int64 ->
+    dets [B,n,5] (y1,x1,y2,x2,score) decoded + clipped."""
+    probs = _need(probs, torch.float32, "probs").contiguous()
+    deltas = _need(deltas, torch.float32, "deltas").contiguous()
+    anchors = _need(anchors, torch.float32, "anchors").contiguous()
+    order = _need(order, torch.int64, "order").contiguous()
+    B, A = probs.shape[0], probs.shape[1]
+    n = order.shape[1]
+    dets = torch.empty((B, n, 5), dtype=torch.float32, device=probs.device)
+    std = (C.c_float * 4)(*[float(s) for s in std_dev])
+    _lib.check(_lib.lib().sln_proposal_decode_f32(_ptr(probs), _ptr(deltas), _ptr(anchors),
+                                                  _ptr(order), B, A, n, std, float(win_h),
+                                                  float(win_w), _ptr(dets), _stream()),
+               "sln_proposal_decode_f32")
+    return dets
+
+
+def gather_rois(dets, keep, num_keep, norm_h, norm_w):
+    B, N = dets.shape[0], dets.shape[1]
+    max_out = keep.shape[1]
+    rois = torch.empty((B, max_out, 4), dtype=torch.float32, device=dets.device)
+    _lib.check(_lib.lib().sln_gather_rois_f32(_ptr(dets), _ptr(keep), _ptr(num_keep), B, N,
+                                              max_out, float(norm_h), float(norm_w), _ptr(rois),
+                                              _stream()), "sln_gather_rois_f32")
+    return rois

@@ -1,0 +1,76 @@
+"""CPU suite: the C-ABI library loads and exports every symbol include/sln_amodal.h
+declares (no compute calls without a GPU), and the product path refuses to run
+without it."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    names = []
+    for fn in sorted(os.listdir(os.path.join(ROOT, "include"))):
+        if fn.endswith(".h"):
+            text = open(os.path.join(ROOT, "include", fn)).read()
+            text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+            names += re.findall(r"\b(sln_[a-z0-9_]+)\s*\(", text)
+    return sorted(set(names))
+
+
+def test_library_builds_and_exports_header_symbols():
+    from sln_amodal_amd.csrc import build
+    so = build.build()
+    lib = ctypes.CDLL(so)
+    syms = _declared_symbols()
+    assert len(syms) >= 10
+    for name in syms:
+        assert hasattr(lib, name), "missing export: " + name
+
+
+def test_ctypes_signatures_cover_header():
+    from sln_amodal_amd import _lib
+    assert sorted(_lib.SIGNATURES) == _declared_symbols()
+    L = _lib.lib()
+    assert L.sln_abi_version() >= 1
+    assert L.sln_error_string(0) == b"ok"
+    assert L.sln_nms_workspace_bytes(2, 6000) == 2 * 6000 * 94 * 8
+
+
+def test_argument_validation_needs_no_gpu():
+    from sln_amodal_amd import _lib
+    L = _lib.lib()
+    assert L.sln_nms_f32(None, -1, 0, None, 0.5, 0, None, None, None, 0, None) == 1
+    assert L.sln_crop_and_resize_fwd_f32(None, 1, 1, 0, 1, 0, None, None, 1, 1, 1, 0.0, None,
+                                         None, None) == 1
+    assert L.sln_label_decode_u64(None, 1, 4, 4, 0, 1, None, None) == 1
+
+
+def test_product_path_fails_loudly_without_gpu_tensors():
+    import torch
+    from sln_amodal_amd import ops
+    from sln_amodal_amd.nms.nms_wrapper import nms
+    with pytest.raises(RuntimeError):
+        ops.nms_sorted(torch.zeros(1, 4, 5), 0.5, 4)
+    with pytest.raises(RuntimeError):
+        nms(torch.rand(8, 5), 0.5)
+
+
+def test_missing_library_is_an_error(monkeypatch):
+    from sln_amodal_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libsln.so")
+    with pytest.raises(_lib.HipExtensionMissing):
+        _lib.lib()
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "sln_amodal_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".h")):
+                text = open(os.path.join(dirpath, fn)).read()
+                assert "import oracle" not in text and "from oracle" not in text, fn
+                assert "libsln_oracle" not in text, fn
