@@ -136,6 +136,29 @@ int sln_gather_rois_f32(const float *dets, const int64_t *keep, const int32_t *n
                         int N, int max_out, float norm_h, float norm_w, float *rois,
                         sln_stream_t stream);
 
+/* ---------------------------------------------------------------------------
+ * pyramid_roi_align as one launch (modal/modals.py:20-110): every roi carries
+ * its FPN level (2..5, computed by the caller with modals.py:51-64's formula);
+ * the roi is sampled from that level's map with crop_and_resize's arithmetic and
+ * written to its own slot, so no per-level gather / cat / re-ordering is needed.
+ * maps      host array of 4 device pointers, P2..P5, each [B,H_l,W_l,C] NHWC.
+ * map_hw    host array of 8 ints (H2,W2,...,H5,W5).
+ * box_ind   [K] image index; level [K] int32; rois with box_ind outside [0,B) or
+ *           level outside [2,5] are padding: their output is zero / no gradient.
+ * out       [K,ch,cw,out_cstride] NHWC rows; this op writes channels
+ *           [out_coffset, out_coffset+C) of each row (fused concat,
+ *           modal/modals.py:481).
+ * backward  grad_maps: 4 device pointers [B,H_l,W_l,C], zeroed by the callee.
+ * ------------------------------------------------------------------------- */
+int sln_pyramid_crop_fwd_f32(const float *const *maps, const int32_t *map_hw, int B, int C,
+                             const float *boxes, const int32_t *box_ind, const int32_t *level,
+                             int K, int ch, int cw, float extrapolation_value, float *out,
+                             int out_cstride, int out_coffset, sln_stream_t stream);
+int sln_pyramid_crop_bwd_f32(const float *grads, int g_cstride, int g_coffset, const float *boxes,
+                             const int32_t *box_ind, const int32_t *level, int K, int ch, int cw,
+                             int B, int C, float *const *grad_maps, const int32_t *map_hw,
+                             sln_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -27,6 +27,10 @@ SIGNATURES = {
     "sln_mask_targets_u64": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _i, _i, _i, _p, _p]),
     "sln_proposal_decode_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, C.POINTER(_f), _f, _f, _p, _p]),
     "sln_gather_rois_f32": (_i, [_p, _p, _p, _i, _i, _i, _f, _f, _p, _p]),
+    "sln_pyramid_crop_fwd_f32": (_i, [C.POINTER(_p), C.POINTER(_i), _i, _i, _p, _p, _p, _i, _i, _i,
+                                      _f, _p, _i, _i, _p]),
+    "sln_pyramid_crop_bwd_f32": (_i, [_p, _i, _i, _p, _p, _p, _i, _i, _i, _i, _i, C.POINTER(_p),
+                                      C.POINTER(_i), _p]),
 }
 
 
@@ -48,6 +52,11 @@ def lib():
             raise HipExtensionMissing(
                 "%s not found: build it with `python -m sln_amodal_amd.csrc.build` "
                 "(hipcc --offload-arch=gfx950). No CPU fallback exists." % LIB_PATH)
+        # Load PyTorch's HIP runtime FIRST: the library's DT_NEEDED libamdhip64.so.7
+        # then binds to the copy already in the process (same SONAME).  Loading ours
+        # first would pull /opt/rocm's runtime in and hand torch a second, different
+        # HIP runtime ("no ROCm-capable device", mismatched stream handles).
+        import torch  # noqa: F401
         _lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(_lib, name)  # AttributeError if the .so lacks a declared symbol

@@ -245,6 +245,7 @@ extern "C" int sln_crop_and_resize_fwd_f32(const float *image, int B, int C, int
                                            int layout, const float *boxes, const int32_t *box_ind,
                                            int K, int ch, int cw, float extrap, float *crops,
                                            int32_t *err_flag, sln_stream_t stream) {
+    sln_enter();
     if (B < 0 || C < 0 || H < 1 || W < 1 || K < 0 || ch < 1 || cw < 1) return SLN_ERR_INVALID_ARG;
     if (K == 0 || C == 0) return SLN_OK;
     if (!image || !boxes || !box_ind || !crops) return SLN_ERR_INVALID_ARG;
@@ -271,6 +272,7 @@ extern "C" int sln_crop_and_resize_bwd_f32(const float *grads, const float *boxe
                                            const int32_t *box_ind, int K, int ch, int cw, int B,
                                            int C, int H, int W, int layout, float *grad_image,
                                            int32_t *err_flag, sln_stream_t stream) {
+    sln_enter();
     if (B < 0 || C < 0 || H < 1 || W < 1 || K < 0 || ch < 1 || cw < 1) return SLN_ERR_INVALID_ARG;
     if (layout != SLN_LAYOUT_NHWC && layout != SLN_LAYOUT_NCHW) return SLN_ERR_INVALID_ARG;
     if (B == 0 || C == 0) return SLN_OK;

@@ -136,6 +136,7 @@ __global__ __launch_bounds__(256) void mask_targets_kernel(const u64 *__restrict
 
 extern "C" int sln_label_num_objects_u64(const uint64_t *label, int B, int64_t npix, int32_t *n_obj,
                                          sln_stream_t stream) {
+    sln_enter();
     if (B < 0 || npix < 0) return SLN_ERR_INVALID_ARG;
     if (B == 0) return SLN_OK;
     if (!n_obj || (!label && npix > 0)) return SLN_ERR_INVALID_ARG;
@@ -155,6 +156,7 @@ extern "C" int sln_label_num_objects_u64(const uint64_t *label, int B, int64_t n
 
 extern "C" int sln_label_decode_u64(const uint64_t *label, int B, int H, int W, int L, int N,
                                     uint8_t *planes, sln_stream_t stream) {
+    sln_enter();
     if (B < 0 || H < 0 || W < 0 || L < 1 || N < 0 || N > 32) return SLN_ERR_INVALID_ARG;
     const long npix = (long)H * W;
     if (B == 0 || N == 0 || npix == 0) return SLN_OK;
@@ -170,6 +172,7 @@ extern "C" int sln_mask_targets_u64(const uint64_t *label, int B, int H, int W, 
                                     const float *rois, const int32_t *roi_img,
                                     const int32_t *roi_obj, int K, int mh, int mw, float *masks,
                                     sln_stream_t stream) {
+    sln_enter();
     if (B < 0 || H < 1 || W < 1 || L < 1 || K < 0 || mh < 1 || mw < 1) return SLN_ERR_INVALID_ARG;
     if (K == 0) return SLN_OK;
     if (!label || !rois || !roi_img || !roi_obj || !masks) return SLN_ERR_INVALID_ARG;

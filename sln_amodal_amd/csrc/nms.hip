@@ -156,6 +156,7 @@ extern "C" size_t sln_nms_workspace_bytes(int B, int N) {
 extern "C" int sln_nms_f32(const float *dets, int B, int N, const int32_t *n_valid, float thresh,
                            int max_out, int64_t *keep, int32_t *num_keep, void *workspace,
                            size_t workspace_bytes, sln_stream_t stream) {
+    sln_enter();
     if (B < 0 || N < 0 || max_out < 0) return SLN_ERR_INVALID_ARG;
     if (B == 0) return SLN_OK;
     if (!keep && max_out > 0) return SLN_ERR_INVALID_ARG;

@@ -59,6 +59,7 @@ extern "C" int sln_proposal_decode_f32(const float *probs, const float *deltas, 
                                        const int64_t *order, int B, int A, int n,
                                        const float *std_dev, float win_h, float win_w, float *dets,
                                        sln_stream_t stream) {
+    sln_enter();
     if (B < 0 || A < 0 || n < 0 || !std_dev) return SLN_ERR_INVALID_ARG;
     if (B == 0 || n == 0) return SLN_OK;
     if (!probs || !deltas || !anchors || !order || !dets) return SLN_ERR_INVALID_ARG;
@@ -71,6 +72,7 @@ extern "C" int sln_proposal_decode_f32(const float *probs, const float *deltas, 
 extern "C" int sln_gather_rois_f32(const float *dets, const int64_t *keep, const int32_t *num_keep,
                                    int B, int N, int max_out, float norm_h, float norm_w, float *rois,
                                    sln_stream_t stream) {
+    sln_enter();
     if (B < 0 || N < 0 || max_out < 0) return SLN_ERR_INVALID_ARG;
     if (B == 0 || max_out == 0) return SLN_OK;
     if (!keep || !num_keep || !rois || (!dets && N > 0)) return SLN_ERR_INVALID_ARG;

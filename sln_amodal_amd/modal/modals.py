@@ -1,0 +1,373 @@
+"""Detector modules with the reference's names and state-dict keys
+(modal/modals.py): SamePad2d, Bottleneck, ResNet, FPN, RPN, Classifier, Mask,
+pyramid_roi_align, pyramid_roi_align_image.
+
+Differences in construction, not in arithmetic:
+  * batched (B images) instead of batch 1; rois carry their image index;
+  * activations are channels-last; every conv goes through nn_ops.conv_bn_act
+    (conv + frozen-BN affine + residual + ReLU fused); SamePad2d is folded into
+    the convolution's padding; nn.Conv2d / nn.BatchNorm2d objects are kept as
+    parameter holders so reference checkpoints load by key
+    (fpn.C1.0.weight, fpn.C2.0.conv1.weight, rpn.conv_shared.weight, ...);
+  * pyramid_roi_align is one kernel launch over all levels (csrc/pyramid_crop.hip).
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import nn_ops, ops
+from ..roialign.roi_align.crop_and_resize import CropAndResizeFunction
+
+
+def log2(x):
+    """log(x)/log(2) in fp32, like the reference helper (modals.py:8-13)."""
+    ln2 = torch.log(torch.tensor([2.0], dtype=torch.float32, device=x.device))
+    return torch.log(x) / ln2
+
+
+############################################################
+#  ROIAlign Layer
+############################################################
+
+def roi_levels(boxes, image_shape):
+    """FPN level of each roi, boxes [K,4] normalised (modals.py:51-64):
+    4 + log2(sqrt(h*w) / (224/sqrt(image_area))), round (half-to-even), clamp 2..5."""
+    y1, x1, y2, x2 = boxes.chunk(4, dim=1)
+    h = y2 - y1
+    w = x2 - x1
+    image_area = torch.tensor([float(image_shape[0] * image_shape[1])], dtype=torch.float32,
+                              device=boxes.device)
+    lvl = 4 + log2(torch.sqrt(h * w) / (224.0 / torch.sqrt(image_area)))
+    lvl = torch.nan_to_num(lvl, nan=2.0, posinf=5.0, neginf=2.0)
+    return lvl.round().int().clamp(2, 5).view(-1)
+
+
+class _PyramidCrop(torch.autograd.Function):
+    """All-level crop in one launch; gradient flows to the four maps only."""
+
+    @staticmethod
+    def forward(ctx, boxes, box_ind, level, pool, *maps):
+        import ctypes as C
+        from .. import _lib
+        maps = [m if m.is_contiguous(memory_format=torch.channels_last) else
+                m.contiguous(memory_format=torch.channels_last) for m in maps]
+        B, Cc = maps[0].shape[0], maps[0].shape[1]
+        K = boxes.shape[0]
+        out = torch.empty((K, Cc, pool, pool), dtype=torch.float32, device=boxes.device,
+                          memory_format=torch.channels_last)
+        ptrs = (C.c_void_p * 4)(*[m.data_ptr() for m in maps])
+        hw = (C.c_int * 8)(*[d for m in maps for d in (m.shape[2], m.shape[3])])
+        _lib.check(_lib.lib().sln_pyramid_crop_fwd_f32(
+            ptrs, hw, B, Cc, ops._ptr(boxes), ops._ptr(box_ind), ops._ptr(level), K, pool, pool,
+            0.0, ops._ptr(out), Cc, 0, ops._stream()), "sln_pyramid_crop_fwd_f32")
+        ctx.save_for_backward(boxes, box_ind, level)
+        ctx.shapes = [tuple(m.shape) for m in maps]
+        ctx.pool = pool
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        import ctypes as C
+        from .. import _lib
+        boxes, box_ind, level = ctx.saved_tensors
+        g = g.contiguous(memory_format=torch.channels_last)
+        B, Cc = ctx.shapes[0][0], ctx.shapes[0][1]
+        grads = [torch.empty(s, dtype=torch.float32, device=g.device,
+                             memory_format=torch.channels_last) for s in ctx.shapes]
+        ptrs = (C.c_void_p * 4)(*[t.data_ptr() for t in grads])
+        hw = (C.c_int * 8)(*[d for s in ctx.shapes for d in (s[2], s[3])])
+        _lib.check(_lib.lib().sln_pyramid_crop_bwd_f32(
+            ops._ptr(g), Cc, 0, ops._ptr(boxes), ops._ptr(box_ind), ops._ptr(level),
+            boxes.shape[0], ctx.pool, ctx.pool, B, Cc, ptrs, hw, ops._stream()),
+            "sln_pyramid_crop_bwd_f32")
+        return (None, None, None, None) + tuple(grads)
+
+
+def pyramid_roi_align(inputs, pool_size, image_shape, box_ind=None):
+    """inputs = [boxes] + [P2, P3, P4, P5].
+    boxes: [B,R,4] (or the reference's [1,R,4]) normalised (y1,x1,y2,x2); image b's
+    rois index feature-map batch entry b.  Padded roi slots may be marked by
+    box_ind = -1 ([B*R] int32); their output is zero.
+    Returns pooled [B*R, C, pool, pool] in roi order (reference: modals.py:20-110)."""
+    boxes = inputs[0]
+    feature_maps = list(inputs[1:])
+    B = feature_maps[0].shape[0]
+    if boxes.dim() == 3:
+        R = boxes.shape[1]
+        flat = boxes.reshape(-1, 4)
+        if box_ind is None:
+            box_ind = torch.arange(boxes.shape[0], dtype=torch.int32,
+                                   device=boxes.device).repeat_interleave(R)
+    else:
+        flat = boxes.view(-1, 4)
+        if box_ind is None:
+            box_ind = torch.zeros(flat.shape[0], dtype=torch.int32, device=boxes.device)
+    flat = flat.detach().contiguous()  # stop gradient into the proposals (modals.py:81)
+    level = roi_levels(flat, image_shape)
+    chlast = all(m.is_contiguous(memory_format=torch.channels_last) and not m.is_contiguous()
+                 for m in feature_maps)
+    if chlast and len(feature_maps) == 4:
+        return _PyramidCrop.apply(flat, box_ind.contiguous(), level.contiguous(), int(pool_size),
+                                  *feature_maps)
+    # Reference-layout (NCHW) maps: per-level crops, like the reference's loop.
+    pooled = torch.zeros((flat.shape[0], feature_maps[0].shape[1], pool_size, pool_size),
+                         dtype=torch.float32, device=flat.device)
+    for i, lv in enumerate(range(2, 6)):
+        ix = torch.nonzero((level == lv) & (box_ind >= 0))[:, 0]
+        if ix.numel() == 0:
+            continue
+        crops = CropAndResizeFunction(pool_size, pool_size, 0)(feature_maps[i], flat[ix],
+                                                               box_ind[ix].contiguous())
+        pooled = pooled.index_add(0, ix, crops.contiguous())
+    return pooled
+
+
+def pyramid_roi_align_image(inputs, pool_size, image_shape, istrain=False, box_ind=None):
+    """Single-map crop used for the GLM probabilities and the raw image
+    (modals.py:112-157): ignores pyramid levels and `image_shape`.
+    inputs = [boxes [B,R,4] | [R,4], image [B,C,H,W]]."""
+    boxes, image = inputs[0], inputs[1]
+    if boxes.dim() == 3:
+        R = boxes.shape[1]
+        if box_ind is None:
+            box_ind = torch.arange(boxes.shape[0], dtype=torch.int32,
+                                   device=boxes.device).repeat_interleave(R)
+        boxes = boxes.reshape(-1, 4)
+    elif box_ind is None:
+        box_ind = torch.zeros(boxes.shape[0], dtype=torch.int32, device=boxes.device)
+    return CropAndResizeFunction(pool_size, pool_size, 0)(image, boxes.contiguous(),
+                                                          box_ind.contiguous())
+
+
+class SamePad2d(nn.Module):
+    """TensorFlow 'SAME' padding (modals.py:159-184).  Kept as a module for
+    Sequential index compatibility; the conv dispatch folds it into the conv."""
+
+    def __init__(self, kernel_size, stride):
+        super(SamePad2d, self).__init__()
+        self.kernel_size = torch.nn.modules.utils._pair(kernel_size)
+        self.stride = torch.nn.modules.utils._pair(stride)
+
+    def forward(self, input):
+        pt, pb = nn_ops.same_pad(input.shape[2], self.kernel_size[0], self.stride[0])
+        pl, pr = nn_ops.same_pad(input.shape[3], self.kernel_size[1], self.stride[1])
+        return F.pad(input, (pl, pr, pt, pb), "constant", 0)
+
+    def __repr__(self):
+        return self.__class__.__name__
+
+
+############################################################
+#  FPN Graph
+############################################################
+
+class FPN(nn.Module):
+    def __init__(self, C1, C2, C3, C4, C5, out_channels):
+        super(FPN, self).__init__()
+        self.out_channels = out_channels
+        self.C1, self.C2, self.C3, self.C4, self.C5 = C1, C2, C3, C4, C5
+        self.P6 = nn.MaxPool2d(kernel_size=1, stride=2)
+        for name, cin in (("P5", 2048), ("P4", 1024), ("P3", 512), ("P2", 256)):
+            setattr(self, name + "_conv1", nn.Conv2d(cin, out_channels, kernel_size=1, stride=1))
+            setattr(self, name + "_conv2", nn.Sequential(
+                SamePad2d(kernel_size=3, stride=1),
+                nn.Conv2d(out_channels, out_channels, kernel_size=3, stride=1)))
+
+    def forward(self, x):
+        x = x.contiguous(memory_format=torch.channels_last)
+        x = self.C1(x)
+        c2 = self.C2(x)
+        c3 = self.C3(c2)
+        c4 = self.C4(c3)
+        c5 = self.C5(c4)
+        conv = nn_ops.conv_bn_act
+        p5 = conv(c5, self.P5_conv1)
+        p4 = nn_ops.upsample2x_add(conv(c4, self.P4_conv1), p5)
+        p3 = nn_ops.upsample2x_add(conv(c3, self.P3_conv1), p4)
+        p2 = nn_ops.upsample2x_add(conv(c2, self.P2_conv1), p3)
+        p5 = conv(p5, self.P5_conv2[1], same=True)
+        p4 = conv(p4, self.P4_conv2[1], same=True)
+        p3 = conv(p3, self.P3_conv2[1], same=True)
+        p2 = conv(p2, self.P2_conv2[1], same=True)
+        p6 = p5[:, :, ::2, ::2]  # MaxPool2d(kernel 1, stride 2) == strided subsample
+        p6 = p6.contiguous(memory_format=torch.channels_last)
+        return [p2, p3, p4, p5, p6]
+
+
+############################################################
+#  Resnet Graph
+############################################################
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super(Bottleneck, self).__init__()
+        # the stride sits on the first 1x1 (modals.py:269)
+        self.conv1 = nn.Conv2d(inplanes, planes, kernel_size=1, stride=stride)
+        self.bn1 = nn.BatchNorm2d(planes, eps=0.001, momentum=0.01)
+        self.padding2 = SamePad2d(kernel_size=3, stride=1)
+        self.conv2 = nn.Conv2d(planes, planes, kernel_size=3)
+        self.bn2 = nn.BatchNorm2d(planes, eps=0.001, momentum=0.01)
+        self.conv3 = nn.Conv2d(planes, planes * 4, kernel_size=1)
+        self.bn3 = nn.BatchNorm2d(planes * 4, eps=0.001, momentum=0.01)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        conv = nn_ops.conv_bn_act
+        residual = x
+        if self.downsample is not None:
+            residual = conv(x, self.downsample[0], self.downsample[1])
+        out = conv(x, self.conv1, self.bn1, relu=True)
+        out = conv(out, self.conv2, self.bn2, relu=True, same=True)
+        return conv(out, self.conv3, self.bn3, relu=True, residual=residual)
+
+
+class _Stem(nn.Sequential):
+    """C1: 7x7/2 conv + BN + ReLU + SamePad + 3x3/2 max-pool (modals.py:311-317)."""
+
+    def forward(self, x):
+        x = nn_ops.conv_bn_act(x, self[0], self[1], relu=True)
+        return nn_ops.max_pool_same(x, 3, 2)
+
+
+class ResNet(nn.Module):
+    def __init__(self, architecture, stage5=False):
+        super(ResNet, self).__init__()
+        assert architecture in ["resnet50", "resnet101"]
+        self.inplanes = 64
+        self.layers = [3, 4, {"resnet50": 6, "resnet101": 23}[architecture], 3]
+        self.block = Bottleneck
+        self.stage5 = stage5
+        self.C1 = _Stem(
+            nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3),
+            nn.BatchNorm2d(64, eps=0.001, momentum=0.01),
+            nn.ReLU(inplace=True),
+            SamePad2d(kernel_size=3, stride=2),
+            nn.MaxPool2d(kernel_size=3, stride=2),
+        )
+        self.C2 = self.make_layer(self.block, 64, self.layers[0])
+        self.C3 = self.make_layer(self.block, 128, self.layers[1], stride=2)
+        self.C4 = self.make_layer(self.block, 256, self.layers[2], stride=2)
+        self.C5 = self.make_layer(self.block, 512, self.layers[3], stride=2) if stage5 else None
+
+    def forward(self, x):
+        for stage in self.stages():
+            x = stage(x)
+        return x
+
+    def stages(self):
+        return [self.C1, self.C2, self.C3, self.C4, self.C5]
+
+    def make_layer(self, block, planes, blocks, stride=1):
+        downsample = None
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            downsample = nn.Sequential(
+                nn.Conv2d(self.inplanes, planes * block.expansion, kernel_size=1, stride=stride),
+                nn.BatchNorm2d(planes * block.expansion, eps=0.001, momentum=0.01))
+        layers = [block(self.inplanes, planes, stride, downsample)]
+        self.inplanes = planes * block.expansion
+        for _ in range(1, blocks):
+            layers.append(block(self.inplanes, planes))
+        return nn.Sequential(*layers)
+
+
+############################################################
+#  Region Proposal Network
+############################################################
+
+class RPN(nn.Module):
+    """Shared 3x3 + ReLU, then 1x1 class (2A) and 1x1 box (4A) heads
+    (modals.py:361-412).  Returns [logits [B,HWA,2], probs, deltas [B,HWA,4]]."""
+
+    def __init__(self, anchors_per_location, anchor_stride, depth):
+        super(RPN, self).__init__()
+        self.anchors_per_location = anchors_per_location
+        self.anchor_stride = anchor_stride
+        self.depth = depth
+        self.padding = SamePad2d(kernel_size=3, stride=self.anchor_stride)
+        self.conv_shared = nn.Conv2d(self.depth, 512, kernel_size=3, stride=self.anchor_stride)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv_class = nn.Conv2d(512, 2 * anchors_per_location, kernel_size=1, stride=1)
+        self.softmax = nn.Softmax(dim=2)
+        self.conv_bbox = nn.Conv2d(512, 4 * anchors_per_location, kernel_size=1, stride=1)
+
+    def forward(self, x):
+        B = x.shape[0]
+        x = nn_ops.conv_bn_act(x, self.conv_shared, relu=True, same=True)
+        # NHWC output == the reference's permute(0,2,3,1).contiguous()
+        logits = nn_ops.conv_bn_act(x, self.conv_class).permute(0, 2, 3, 1).reshape(B, -1, 2)
+        probs = self.softmax(logits)
+        bbox = nn_ops.conv_bn_act(x, self.conv_bbox).permute(0, 2, 3, 1).reshape(B, -1, 4)
+        return [logits, probs, bbox]
+
+
+############################################################
+#  Feature Pyramid Network Heads
+############################################################
+
+class Classifier(nn.Module):
+    def __init__(self, depth, pool_size, image_shape, num_classes):
+        super(Classifier, self).__init__()
+        self.depth = depth
+        self.pool_size = pool_size
+        self.image_shape = image_shape
+        self.num_classes = num_classes
+        self.conv1 = nn.Conv2d(self.depth, 1024, kernel_size=self.pool_size, stride=1)
+        self.bn1 = nn.BatchNorm2d(1024, eps=0.001, momentum=0.01)
+        self.conv2 = nn.Conv2d(1024, 1024, kernel_size=1, stride=1)
+        self.bn2 = nn.BatchNorm2d(1024, eps=0.001, momentum=0.01)
+        self.relu = nn.ReLU(inplace=True)
+        self.linear_class = nn.Linear(1024, num_classes)
+        self.softmax = nn.Softmax(dim=1)
+        self.linear_bbox = nn.Linear(1024, num_classes * 4)
+
+    def forward(self, x, rois, box_ind=None):
+        x = pyramid_roi_align([rois] + list(x), self.pool_size, self.image_shape, box_ind)
+        x = nn_ops.conv_bn_act(x, self.conv1, self.bn1, relu=True)
+        x = nn_ops.conv_bn_act(x, self.conv2, self.bn2, relu=True)
+        x = x.reshape(-1, 1024)
+        mrcnn_class_logits = self.linear_class(x)
+        mrcnn_probs = self.softmax(mrcnn_class_logits)
+        mrcnn_bbox = self.linear_bbox(x)
+        mrcnn_bbox = mrcnn_bbox.view(mrcnn_bbox.size()[0], -1, 4)
+        return [mrcnn_class_logits, mrcnn_probs, mrcnn_bbox]
+
+
+class Mask(nn.Module):
+    def __init__(self, depth, pool_size, image_shape, num_classes):
+        super(Mask, self).__init__()
+        self.depth = depth
+        self.pool_size = pool_size
+        self.image_shape = image_shape
+        self.num_classes = num_classes
+        self.padding = SamePad2d(kernel_size=3, stride=1)
+        self.conv1 = nn.Conv2d(self.depth, 256, kernel_size=3, stride=1)
+        self.bn1 = nn.BatchNorm2d(256, eps=0.001)
+        self.conv2 = nn.Conv2d(256, 256, kernel_size=3, stride=1)
+        self.bn2 = nn.BatchNorm2d(256, eps=0.001)
+        self.conv3 = nn.Conv2d(256, 256, kernel_size=3, stride=1)
+        self.bn3 = nn.BatchNorm2d(256, eps=0.001)
+        self.conv4 = nn.Conv2d(256, 256, kernel_size=3, stride=1)
+        self.bn4 = nn.BatchNorm2d(256, eps=0.001)
+        self.deconv = nn.ConvTranspose2d(256, 256, kernel_size=2, stride=2)
+        self.conv5 = nn.Conv2d(256, num_classes, kernel_size=1, stride=1)
+        self.sigmoid = nn.Sigmoid()
+        self.relu = nn.ReLU(inplace=True)
+
+    def forward(self, x, rois, cls_feature, box_ind=None):
+        x = pyramid_roi_align([rois] + list(x), self.pool_size, self.image_shape, box_ind)
+        x = torch.cat((cls_feature, x), dim=1)  # GLM channels first (modals.py:481)
+        x = x.contiguous(memory_format=torch.channels_last)
+        conv = nn_ops.conv_bn_act
+        x = conv(x, self.conv1, self.bn1, relu=True, same=True)
+        x = conv(x, self.conv2, self.bn2, relu=True, same=True)
+        x = conv(x, self.conv3, self.bn3, relu=True, same=True)
+        feat = conv(x, self.conv4, self.bn4, relu=True, same=True)
+        x = F.relu(F.conv_transpose2d(feat, self.deconv.weight, self.deconv.bias, stride=2))
+        x = conv(x, self.conv5)  # logits; the sigmoid lives in the losses (modals.py:497)
+        return x, feat

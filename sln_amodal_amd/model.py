@@ -1,0 +1,400 @@
+"""MaskRCNN orchestration with the reference's entry points (model.py:126-806):
+build / initialize_weights / set_trainable / load_weights / find_last /
+train_model / train_epoch / predict / detect / mold_inputs / unmold_detections.
+
+What is different from the reference, by design:
+  * batched: `predict` takes B images (the reference is batch 1, model.py:341,442);
+    per-image semantics (per-image NMS, sampling, loss means) are kept and the
+    step loss is the mean over images;
+  * no device->host sync inside a training step: fixed-capacity roi slots with
+    validity masks replace `len()`, `.any()`, `nonzero` control flow;
+  * native ops (NMS, crop_and_resize, pyramid crop, label decode / mask targets,
+    proposal decode) run through the C ABI in csrc/; convolutions go through
+    nn_ops.conv_bn_act;
+  * data-parallel training: one process per GPU, gradients all-reduced over RCCL
+    (parallel.py) -- the reference has no live multi-GPU path.
+"""
+import os
+import re
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import utils
+from .modal import loss as L
+from .modal.Functions import (build_rpn_targets, compose_image_meta, detection_layer,  # noqa: F401
+                              detection_target_layer, log, mold_image, proposal_layer)
+from .modal.deeplabv2 import DeepLabV2_ResNet101_MSC
+from .modal.modals import (FPN, RPN, Classifier, Mask, ResNet, pyramid_roi_align_image)
+
+LAYER_REGEX = {
+    "new": r"(fpn.C1.*)|(classifier.*)|(mask.*)|(layer_decoder.*)|(rpn.*)",
+    "rpn": r"(fpn.C3.*)|(fpn.C4.*)|(fpn.C5.*)|(fpn.P5\_.*)|(fpn.P4\_.*)|(fpn.P3\_.*)|(fpn.P2\_.*)|(rpn.*)",
+    "heads": r"(fpn.P5\_.*)|(fpn.P4\_.*)|(fpn.P3\_.*)|(fpn.P2\_.*)|(rpn.*)|(classifier.*)|(mask.*)|(layer_decoder.*)",
+    "3+": r"(fpn.C3.*)|(fpn.C4.*)|(fpn.C5.*)|(fpn.P5\_.*)|(fpn.P4\_.*)|(fpn.P3\_.*)|(fpn.P2\_.*)|(rpn.*)|(classifier.*)|(mask.*)|(layer_decoder.*)|(amodal_refine.*)",
+    "4+": r"(fpn.C4.*)|(fpn.C5.*)|(fpn.P5\_.*)|(fpn.P4\_.*)|(fpn.P3\_.*)|(fpn.P2\_.*)|(rpn.*)|(classifier.*)|(mask.*)|(layer_decoder.*)|(amodal_refine.*)",
+    "5+": r"(fpn.C5.*)|(fpn.P5\_.*)|(fpn.P4\_.*)|(fpn.P3\_.*)|(fpn.P2\_.*)|(rpn.*)|(classifier.*)|(mask.*)|(layer_decoder.*)|(amodal_refine.*)",
+    "layer": r"(mask.*)|(layer_decoder.*)",
+    "all": ".*",
+}
+
+
+class MaskRCNN(nn.Module):
+    def __init__(self, config, model_dir):
+        super(MaskRCNN, self).__init__()
+        self.config = config
+        self.model_dir = model_dir
+        self.set_log_dir()
+        self.build(config=config)
+        self.initialize_weights()
+        self.loss_history = []
+        self.val_loss_history = []
+        self.current_epoch = 0
+        self.layer_decoder = None
+        self.amodal_refine = None
+        self.GLM_modual = None
+
+    # ------------------------------------------------------------------ build
+    def build(self, config):
+        h, w = config.IMAGE_SHAPE[:2]
+        if getattr(config, "STRICT_IMAGE_DIVISIBILITY", False) and (h % 64 or w % 64):
+            raise Exception("Image size must be dividable by 2 at least 6 times "
+                            "to avoid fractions when downscaling and upscaling.")
+        resnet = ResNet(getattr(config, "ARCHITECTURE", "resnet101"), stage5=True)
+        C1, C2, C3, C4, C5 = resnet.stages()
+        self.fpn = FPN(C1, C2, C3, C4, C5, out_channels=256)
+        anchors = utils.generate_pyramid_anchors(config.RPN_ANCHOR_SCALES, config.RPN_ANCHOR_RATIOS,
+                                                 config.BACKBONE_SHAPES, config.BACKBONE_STRIDES,
+                                                 config.RPN_ANCHOR_STRIDE)
+        self.register_buffer("anchors", torch.from_numpy(anchors).float(), persistent=False)
+        self.register_buffer("anchors_f64", torch.from_numpy(anchors), persistent=False)
+        self.rpn = RPN(len(config.RPN_ANCHOR_RATIOS), config.RPN_ANCHOR_STRIDE, 256)
+        self.classifier = Classifier(256, config.POOL_SIZE, config.IMAGE_SHAPE, config.NUM_CLASSES)
+        self.mask = Mask(256, config.MASK_POOL_SIZE, config.IMAGE_SHAPE, config.NUM_CLASSES)
+        if config.DATA_TYPE == "amodal":
+            self.mask_vis = Mask(256, config.MASK_POOL_SIZE, config.IMAGE_SHAPE, config.NUM_CLASSES)
+        self._freeze_batchnorm()
+
+    def _freeze_batchnorm(self):
+        # model.py:192-197: BN parameters that exist at build() never train
+        for m in self.modules():
+            if isinstance(m, nn.BatchNorm2d):
+                for p in m.parameters():
+                    p.requires_grad = False
+
+    def initialize_weights(self):
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.xavier_uniform_(m.weight)
+                if m.bias is not None:
+                    m.bias.data.zero_()
+            elif isinstance(m, nn.BatchNorm2d):
+                m.weight.data.fill_(1)
+                m.bias.data.zero_()
+            elif isinstance(m, nn.Linear):
+                m.weight.data.normal_(0, 0.01)
+                m.bias.data.zero_()
+
+    def apply_amodal_heads(self, glm=True):
+        """The head surgery amodal_train.py:606-614 performs after construction:
+        two classes (background, layers), a 439-channel mask conv1 (256 roi +
+        183 GLM channels), re-sized classifier linears, and the frozen GLM."""
+        cfg = self.config
+        cfg.NUM_CLASSES = 1 + 1
+        self.mask.conv1 = nn.Conv2d(256 + cfg.GLM_CLASSES + 1, 256, kernel_size=3, stride=1)
+        self.mask.conv5 = nn.Conv2d(256, cfg.NUM_CLASSES, kernel_size=1, stride=1)
+        self.classifier.linear_class = nn.Linear(1024, cfg.NUM_CLASSES)
+        self.classifier.linear_bbox = nn.Linear(1024, cfg.NUM_CLASSES * 4)
+        self.mask.num_classes = self.classifier.num_classes = cfg.NUM_CLASSES
+        if glm:
+            self.GLM_modual = DeepLabV2_ResNet101_MSC(cfg.GLM_CLASSES)
+        return self
+
+    def set_trainable(self, layer_regex, model=None, indent=0, verbose=1, exclusive_off=True):
+        """Parameters whose name does not match are frozen.  Like the reference
+        (model.py:218-227) this only ever switches gradients OFF; pass
+        exclusive_off=False to also switch matching (non-BN, non-GLM) ones on."""
+        bn_names = {n + "." + pn for n, m in self.named_modules()
+                    if isinstance(m, nn.BatchNorm2d) for pn, _ in m.named_parameters(recurse=False)}
+        for name, p in self.named_parameters():
+            ok = bool(re.fullmatch(layer_regex, name))
+            if not ok:
+                p.requires_grad = False
+            elif not exclusive_off and not name.startswith("GLM_modual") and \
+                    not (name in bn_names and not name.startswith("mask.")):
+                p.requires_grad = True
+
+    # ------------------------------------------------------------ bookkeeping
+    def set_log_dir(self, model_path=None):
+        self.epoch = 0
+        if model_path:
+            m = re.match(r".*/\w+(\d{4})(\d{2})(\d{2})/mask\_rcnn\_\w+(\d{4})\.pth", model_path)
+            if m:
+                self.epoch = int(m.group(4))  # the reference reads group(6) of 4 (model.py:246-249)
+        self.log_dir = os.path.join(self.model_dir, "{}".format(str(self.config.NAME).lower()))
+        self.checkpoint_path = os.path.join(
+            self.log_dir, "mask_rcnn_{}_*epoch*.pth".format(str(self.config.NAME).lower())
+        ).replace("*epoch*", "{:04d}")
+
+    def find_last(self):
+        dir_names = next(os.walk(self.model_dir))[1]
+        key = str(self.config.NAME).lower()
+        dir_names = sorted(d for d in dir_names if d.startswith(key))
+        if not dir_names:
+            return None, None
+        dir_name = os.path.join(self.model_dir, dir_names[-1])
+        ckpts = sorted(f for f in next(os.walk(dir_name))[2] if f.startswith("mask_rcnn"))
+        if not ckpts:
+            return dir_name, None
+        return dir_name, os.path.join(dir_name, ckpts[-1])
+
+    def load_weights(self, filepath):
+        if os.path.exists(filepath):
+            self.load_state_dict(torch.load(filepath, map_location="cpu"), strict=False)
+        else:
+            print("Weight file not found ...")
+        self.set_log_dir(filepath)
+        os.makedirs(self.log_dir, exist_ok=True)
+
+    # --------------------------------------------------------------- forward
+    def _set_modes(self, mode):
+        if mode == "inference":
+            self.eval()
+        else:
+            self.train()
+            for m in self.modules():  # BN always in eval mode (model.py:525-531)
+                if isinstance(m, nn.BatchNorm2d):
+                    m.eval()
+        if self.GLM_modual is not None:
+            self.GLM_modual.eval()
+
+    def glm_probs(self, molded_images):
+        """Frozen global layer module (model.py:534-543): 513^2 bilinear resize ->
+        DeepLab-v2 MSC -> softmax -> [probs | argmax/255] = [B,183,65,65]."""
+        H, W = molded_images.shape[2], molded_images.shape[3]
+        self.GLM_modual.eval()  # model.py:537
+        with torch.no_grad():
+            s = self.config.GLM_SIZE
+            x = F.interpolate(molded_images, size=(s, s), mode="bilinear", align_corners=False)
+            logits = self.GLM_modual(x.contiguous(memory_format=torch.channels_last))
+            probs = F.softmax(logits, dim=1)
+            lab_small = torch.argmax(probs, dim=1)
+            probs = torch.cat((probs, lab_small.unsqueeze(1).float() / 255), dim=1)
+            gloable_lab = F.interpolate(lab_small.unsqueeze(1).float(), size=(H, W), mode="bilinear",
+                                        align_corners=False)
+        return probs.contiguous(memory_format=torch.channels_last), gloable_lab
+
+    def rpn_forward(self, molded_images):
+        maps = self.fpn(molded_images)
+        outs = [self.rpn(p) for p in maps]
+        rpn_class_logits, rpn_class, rpn_bbox = [torch.cat(list(o), dim=1) for o in zip(*outs)]
+        return maps, rpn_class_logits, rpn_class, rpn_bbox
+
+    def predict(self, input, mode, priorities=None):
+        """input = [molded_images [B,3,H,W], image_metas] (+ [gt_class_ids [B,N],
+        gt_boxes [B,N,4] pixels, gt_layer] for training; gt_layer is either the
+        uint64 labels [B,H,W] (as int64) or decoded planes [B,L,N,H,W] uint8)."""
+        molded_images = input[0]
+        image_metas = input[1]
+        self._set_modes(mode)
+        cfg = self.config
+        B, _, H, W = molded_images.shape
+        probs, gloable_lab = self.glm_probs(molded_images)
+        maps, rpn_class_logits, rpn_class, rpn_bbox = self.rpn_forward(molded_images)
+        mrcnn_feature_maps = maps[:4]
+        count = cfg.POST_NMS_ROIS_TRAINING if mode == "training" else cfg.POST_NMS_ROIS_INFERENCE
+        rpn_rois, num_rois = proposal_layer([rpn_class, rpn_bbox], proposal_count=count,
+                                            nms_threshold=cfg.RPN_NMS_THRESHOLD,
+                                            anchors=self.anchors, config=cfg, return_counts=True)
+        scale = torch.tensor([H, W, H, W], dtype=torch.float32, device=molded_images.device)
+
+        if mode == "inference":
+            return self._predict_inference(rpn_rois, num_rois, mrcnn_feature_maps, probs,
+                                           image_metas, scale)
+
+        gt_class_ids, gt_boxes, gt_layer = input[2], input[3], input[4]
+        gt_boxes = gt_boxes / scale
+        labels = gt_layer if gt_layer.dim() == 3 else None
+        pr = priorities or {}
+        tgt = detection_target_layer(rpn_rois, gt_class_ids, gt_boxes,
+                                     None if labels is not None else gt_layer, cfg,
+                                     num_proposals=num_rois, labels=labels,
+                                     priority_pos=pr.get("pos"), priority_neg=pr.get("neg"))
+        rois, roi_valid = tgt["rois"], tgt["roi_valid"]
+        R = rois.shape[1]
+        box_ind = torch.arange(B, dtype=torch.int32, device=rois.device).repeat_interleave(R)
+        box_ind = torch.where(roi_valid.reshape(-1), box_ind, torch.full_like(box_ind, -1))
+        # dead-end crop the reference computes for its (absent) refine net (model.py:651-663)
+        image_path = pyramid_roi_align_image([rois, molded_images.contiguous()], 32, cfg.IMAGE_SHAPE,
+                                             istrain=True, box_ind=box_ind).detach() / 140.0
+        GLM_feature = pyramid_roi_align_image([rois, probs], 16, (65, 65), istrain=True,
+                                              box_ind=box_ind).detach()
+        mrcnn_class_logits, mrcnn_class, mrcnn_bbox = self.classifier(mrcnn_feature_maps, rois, box_ind)
+        mrcnn_mask, _feat = self.mask(mrcnn_feature_maps, rois, GLM_feature, box_ind)
+        nc = mrcnn_class_logits.shape[1]
+        return {
+            "rpn_class_logits": rpn_class_logits, "rpn_bbox": rpn_bbox,
+            "target_class_ids": tgt["class_ids"], "target_deltas": tgt["deltas"],
+            "target_mask": tgt["masks"], "roi_valid": roi_valid, "rois": rois,
+            "mrcnn_class_logits": mrcnn_class_logits.view(B, R, nc),
+            "mrcnn_bbox": mrcnn_bbox.view(B, R, nc, 4),
+            "mrcnn_mask": mrcnn_mask.reshape(B, R, mrcnn_mask.shape[1], mrcnn_mask.shape[2],
+                                             mrcnn_mask.shape[3]),
+            "image_path": image_path, "gloable_lab": gloable_lab, "num_rois": num_rois,
+        }
+
+    def _predict_inference(self, rpn_rois, num_rois, maps, probs, image_metas, scale):
+        """Batch-1 inference tail (model.py:576-628), including the reference's
+        quirk of cropping the GLM map with PIXEL-coordinate boxes (model.py:588-594,
+        SURVEY.md M9) -- kept for bug-compatibility of `evaluate`."""
+        cfg = self.config
+        n = int(num_rois[0])
+        rois = rpn_rois[:1, :n]
+        _, mrcnn_class, mrcnn_bbox = self.classifier(maps, rois)
+        detections, keep = detection_layer(cfg, rois, mrcnn_class, mrcnn_bbox, image_metas)
+        if len(detections) == 0:
+            return [], []
+        detections[detections < 0] = 0.0
+        detections[detections > 1024] = 1024
+        cls_feature = pyramid_roi_align_image([detections[:, :4].contiguous().unsqueeze(0), probs], 16,
+                                              (65, 65), istrain=False).detach()
+        detection_boxes = (detections[:, :4] / scale).unsqueeze(0)
+        mrcnn_mask, _ = self.mask(maps, detection_boxes, cls_feature)
+        mrcnn_mask = mrcnn_mask.contiguous()
+        mrcnn_mask[:, 1] = torch.sigmoid(mrcnn_mask[:, 1:].sum(dim=1))
+        return [detections.unsqueeze(0), mrcnn_mask.unsqueeze(0)]
+
+    # -------------------------------------------------------------- training
+    def compute_losses(self, out, rpn_match, rpn_bbox):
+        return L.total_loss(rpn_match, rpn_bbox, out["rpn_class_logits"], out["rpn_bbox"],
+                            out["target_class_ids"], out["mrcnn_class_logits"],
+                            out["target_deltas"], out["mrcnn_bbox"], out["target_mask"],
+                            out["mrcnn_mask"], out["roi_valid"])
+
+    def make_optimizer(self, learning_rate):
+        """SGD, momentum, weight decay on everything but 'bn' parameters
+        (model.py:352-358)."""
+        wd = [p for n, p in self.named_parameters() if p.requires_grad and "bn" not in n]
+        no_wd = [p for n, p in self.named_parameters() if p.requires_grad and "bn" in n]
+        return torch.optim.SGD([{"params": wd, "weight_decay": self.config.WEIGHT_DECAY},
+                                {"params": no_wd}], lr=learning_rate,
+                               momentum=self.config.LEARNING_MOMENTUM)
+
+    def train_step(self, batch, optimizer, grad_sync=None, priorities=None):
+        """One optimisation step on a batch: predict -> six losses -> backward ->
+        (data-parallel gradient all-reduce) -> global-norm clip 5.0 -> SGD
+        (model.py:415-444).  `batch` = dict(images, image_metas, rpn_match, rpn_bbox,
+        gt_class_ids, gt_boxes, gt_layer).  Returns the loss tensor (no host sync)."""
+        out = self.predict([batch["images"], batch.get("image_metas"), batch["gt_class_ids"],
+                            batch["gt_boxes"], batch["gt_layer"]], mode="training",
+                           priorities=priorities)
+        loss, parts = self.compute_losses(out, batch["rpn_match"], batch["rpn_bbox"])
+        optimizer.zero_grad(set_to_none=True)
+        loss.backward()
+        params = [p for p in self.parameters() if p.requires_grad and p.grad is not None]
+        if grad_sync is not None:
+            grad_sync(params)
+        torch.nn.utils.clip_grad_norm_(params, self.config.GRADIENT_CLIP_NORM)
+        optimizer.step()
+        return loss.detach(), parts
+
+    def train_model(self, train_dataset, val_dataset, learning_rate, epochs, layers,
+                    grad_sync=None):
+        """Epoch loop of the reference (model.py:304-368).  `train_dataset` yields
+        batch dicts (see train_step)."""
+        if layers in LAYER_REGEX:
+            layers = LAYER_REGEX[layers]
+        log("\nStarting at epoch {}. LR={}\n".format(self.epoch + 1, learning_rate))
+        log("Checkpoint Path: {}".format(self.checkpoint_path))
+        self.set_trainable(layers)
+        optimizer = self.make_optimizer(learning_rate)
+        for epoch in range(epochs):
+            log("Epoch {}/{}.".format(epoch, epochs))
+            self.current_epoch += 1
+            self.train_epoch(train_dataset, optimizer, self.config.STEPS_PER_EPOCH, grad_sync)
+            os.makedirs(self.log_dir, exist_ok=True)
+            torch.save(self.state_dict(), self.checkpoint_path.format(self.epoch))
+            self.epoch += 1
+
+    def train_epoch(self, datagenerator, optimizer, steps, grad_sync=None):
+        loss_sum = torch.zeros((), device=self.anchors.device)
+        step = 0
+        for batch in datagenerator:
+            loss, _ = self.train_step(batch, optimizer, grad_sync)
+            loss_sum += loss / steps
+            step += 1
+            if step == steps:
+                break
+        return float(loss_sum)  # the one host sync of the epoch
+
+    # -------------------------------------------------------------- inference
+    def mold_inputs(self, images):
+        """Resize to IMAGE_MAX_DIM^2 (the reference squashes, utils.py:351-356),
+        subtract the mean pixel, build image metas (model.py:709-745)."""
+        cfg = self.config
+        molded, metas, windows = [], [], []
+        for image in images:
+            t = torch.from_numpy(np.ascontiguousarray(image)).permute(2, 0, 1).unsqueeze(0).float()
+            t = F.interpolate(t, size=(cfg.IMAGE_MAX_DIM, cfg.IMAGE_MAX_DIM), mode="bilinear",
+                              align_corners=False)
+            m = t[0].permute(1, 2, 0).numpy() - cfg.MEAN_PIXEL
+            window = (0, 0, cfg.IMAGE_MAX_DIM, cfg.IMAGE_MAX_DIM)
+            molded.append(m.astype(np.float32))
+            windows.append(window)
+            metas.append(compose_image_meta(0, image.shape, window,
+                                            np.zeros([cfg.NUM_CLASSES], dtype=np.int32)))
+        return np.stack(molded), np.stack(metas), np.stack(windows)
+
+    def detect(self, images, mode="inference"):
+        """List of HxWx3 images -> list of dicts(rois, class_ids, scores, masks)
+        (model.py:464-514)."""
+        results = []
+        with torch.no_grad():
+            for image in images:
+                molded, metas, windows = self.mold_inputs([image])
+                x = torch.from_numpy(molded.transpose(0, 3, 1, 2)).float().to(self.anchors.device)
+                detections, mrcnn_mask = self.predict([x, metas], mode=mode)
+                if len(detections) == 0:
+                    continue
+                det = detections[0].cpu().numpy()
+                msk = mrcnn_mask[0].permute(0, 2, 3, 1).cpu().numpy()
+                rois, class_ids, scores, masks = self.unmold_detections(det, msk, image.shape,
+                                                                        windows[0])
+                results.append({"rois": rois, "class_ids": class_ids, "scores": scores,
+                                "masks": masks})
+        return results
+
+    def unmold_detections(self, detections, mrcnn_mask, image_shape, window):
+        """Network outputs -> image-space boxes and full-size binary masks
+        (model.py:747-806, utils.py:447-465)."""
+        zero_ix = np.where(detections[:, 4] == 0)[0]
+        N = zero_ix[0] if zero_ix.shape[0] > 0 else detections.shape[0]
+        boxes = detections[:N, :4]
+        class_ids = detections[:N, 4].astype(np.int32)
+        class_ids[class_ids > 0] = 1
+        scores = detections[:N, 5]
+        masks = mrcnn_mask[np.arange(N), :, :, class_ids]
+        h_scale = image_shape[0] / (window[2] - window[0])
+        w_scale = image_shape[1] / (window[3] - window[1])
+        scales = np.array([h_scale, w_scale, h_scale, w_scale])
+        shifts = np.array([window[0], window[1], window[0], window[1]])
+        boxes = np.multiply(boxes - shifts, scales).astype(np.int32)
+        ok = (boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1]) > 0
+        boxes, class_ids, scores, masks = boxes[ok], class_ids[ok], scores[ok], masks[ok]
+        full = []
+        for i in range(boxes.shape[0]):
+            y1, x1, y2, x2 = boxes[i]
+            m = masks[i].astype(np.float64)
+            # scipy.misc.imresize semantics: min-max bytescale to uint8, bilinear, /255
+            lo, hi = m.min(), m.max()
+            byt = np.zeros_like(m) if hi == lo else np.floor((m - lo) * (255.0 / (hi - lo)) + 0.5)
+            t = torch.from_numpy(byt).float()[None, None]
+            r = F.interpolate(t, size=(int(y2 - y1), int(x2 - x1)), mode="bilinear",
+                              align_corners=False)[0, 0].numpy()
+            fm = np.zeros(image_shape[:2], dtype=np.uint8)
+            fm[y1:y2, x1:x2] = (np.floor(r) / 255.0 >= 0.5).astype(np.uint8)
+            full.append(fm)
+        full = np.stack(full, axis=-1) if full else np.empty((0,) + masks.shape[1:3])
+        return boxes, class_ids, scores, full
