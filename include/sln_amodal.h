@@ -159,6 +159,32 @@ int sln_pyramid_crop_bwd_f32(const float *grads, int g_cstride, int g_coffset, c
                              int B, int C, float *const *grad_maps, const int32_t *map_hw,
                              sln_stream_t stream);
 
+/* ---------------------------------------------------------------------------
+ * Convolution stacks (modal/modals.py:203-499 backbone / FPN / RPN / heads,
+ * modal/resnet_deeplab.py + modal/deeplabv2.py GLM): implicit-GEMM on the bf16
+ * matrix cores with split-bf16 operands (fp32-class accuracy, see csrc/conv.hip).
+ * Replaces the cuDNN calls behind nn.Conv2d (+ the separate BatchNorm / ReLU /
+ * residual-add / F.pad passes around them) on the reference's path.
+ *
+ * sln_conv_split_weights_f32: fp32 weights, element strides (s_o,s_i,s_kh,s_kw),
+ *   -> out [parts][O][KH][KW][I] bf16 (parts = 2 or 3).  flip=1 mirrors the taps.
+ * sln_conv2d_fwd_f32: x [N,H,W,Cin] NHWC fp32 (Cin % 8 == 0) -> y [N,OH,OW,Cout]
+ *   NHWC fp32, y = relu?(conv(x,w)*scale[c] + shift[c] + residual).  Taps that fall
+ *   outside the image read zero (pad_top / pad_left may differ from bottom/right:
+ *   TensorFlow 'SAME' padding).  scale/shift/residual may be NULL.
+ * sln_conv2d_wgrad_f32: dw[O][KH][KW][I] (fp32, O = Cout, I = Cin) = sum over
+ *   pixels of gy[pix][o] * x[pix @ tap][i]; split-K over pixel chunks with fp32
+ *   atomics into a callee-zeroed dw.
+ * ------------------------------------------------------------------------- */
+int sln_conv_split_weights_f32(const float *w, int O, int I, int KH, int KW, long s_o, long s_i,
+                               long s_kh, long s_kw, int flip, int parts, uint16_t *out,
+                               sln_stream_t stream);
+int sln_conv2d_fwd_f32(const float *x, int N, int H, int W, int Cin, const uint16_t *w_parts,
+                       int parts, int Cout, int KH, int KW, int stride_h, int stride_w, int dil_h,
+                       int dil_w, int pad_top, int pad_left, int OH, int OW, const float *scale,
+                       const float *shift, const float *residual, int relu, float *y,
+                       sln_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

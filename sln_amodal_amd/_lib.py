@@ -31,6 +31,10 @@ SIGNATURES = {
                                       _f, _p, _i, _i, _p]),
     "sln_pyramid_crop_bwd_f32": (_i, [_p, _i, _i, _p, _p, _p, _i, _i, _i, _i, _i, C.POINTER(_p),
                                       C.POINTER(_i), _p]),
+    "sln_conv_split_weights_f32": (_i, [_p, _i, _i, _i, _i, C.c_long, C.c_long, C.c_long, C.c_long,
+                                        _i, _i, _p, _p]),
+    "sln_conv2d_fwd_f32": (_i, [_p, _i, _i, _i, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
+                                _i, _p, _p, _p, _i, _p, _p]),
 }
 
 

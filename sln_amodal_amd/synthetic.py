@@ -46,46 +46,54 @@ def make_batch(config, B, H, W, n_obj=8, seed=1234, device="cuda", anchors_f64=N
             "rpn_bbox": rpn_bbox}
 
 
-def calibrate_batchnorm(model, images):
-    """Emulate pretrained BatchNorm statistics for a randomly initialised detector:
-    one forward pass with BN in training mode and momentum 1 copies the batch
-    statistics into running_mean / running_var (the reference always starts from a
-    COCO checkpoint whose BN statistics normalise the activations; with identity
-    statistics and Xavier weights a 100-layer backbone's activations explode).
-    Benchmark / test setup only; the timed step keeps BN frozen."""
-    import torch.nn as nn
+def _calibrate(forward):
+    """Run `forward()` with the un-fused torch conv path while every eval-mode
+    batch_norm call first overwrites its running statistics with the statistics of
+    its input (so layer k is calibrated on activations normalised by layers < k)."""
     import torch.nn.functional as F
-    bns = [m for m in model.fpn.modules() if isinstance(m, nn.BatchNorm2d)]
     from . import nn_ops
     saved = nn_ops.BACKEND
-
-    def hook(mod, inp, out=None):
-        x = inp[0]
-        mean = x.mean(dim=(0, 2, 3))
-        var = x.var(dim=(0, 2, 3), unbiased=False)
-        mod.running_mean.copy_(mean)
-        mod.running_var.copy_(var.clamp(min=1e-6))
-
-    # The fused conv path never calls the BN modules; calibrate layer by layer by
-    # running the un-fused torch ops and intercepting each BN's input.
     orig = F.batch_norm
+    count = [0]
 
     def patched(x, rm, rv, w=None, b=None, training=False, momentum=0.1, eps=1e-5):
         if not training:
             with torch.no_grad():
                 rm.copy_(x.mean(dim=(0, 2, 3)))
                 rv.copy_(x.var(dim=(0, 2, 3), unbiased=False).clamp(min=1e-6))
+            count[0] += 1
         return orig(x, rm, rv, w, b, training, momentum, eps)
 
     nn_ops.BACKEND = "torch"
     F.batch_norm = patched
     try:
         with torch.no_grad():
-            model.fpn(images)
+            forward()
     finally:
         F.batch_norm = orig
         nn_ops.BACKEND = saved
-    return len(bns)
+    return count[0]
+
+
+def calibrate_batchnorm(model, images):
+    """Emulate pretrained BatchNorm statistics for a randomly initialised detector
+    (the reference always starts from a COCO checkpoint whose BN statistics
+    normalise the activations; with identity statistics and Xavier weights a
+    100-layer backbone's activations explode and every proposal degenerates).
+    Benchmark / test setup only; the timed step keeps BN frozen."""
+    return _calibrate(lambda: model.fpn(images))
+
+
+def calibrate_glm(model, images):
+    """Same for the frozen DeepLab-v2 GLM (no checkpoint is available offline)."""
+    import torch.nn.functional as F
+    s = model.config.GLM_SIZE
+
+    def fwd():
+        x = F.interpolate(images, size=(s, s), mode="bilinear", align_corners=False)
+        model.GLM_modual.eval()
+        model.GLM_modual.base(x.contiguous(memory_format=torch.channels_last))
+    return _calibrate(fwd)
 
 
 def warm_start_rpn(model, batches, iters=60, lr=0.02):

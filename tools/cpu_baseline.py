@@ -1,0 +1,176 @@
+"""CPU baseline leg of bench.py: ONE train step of the same model on the host cores.
+
+A *port*, not the product: the conv stacks run on torch-CPU with this repo's
+module definitions (nn_ops "torch" backend), and every native op runs in the CPU
+oracle (oracle/sln_oracle.c: serial greedy NMS, OpenMP-over-boxes crop_and_resize
+forward, serial backward, label decode) -- the same algorithms the reference's CPU
+path uses.  Used only as a reported baseline beside the GPU
+number; never on the product path.
+"""
+import os
+import time
+
+import numpy as np
+import torch
+
+
+class _CropCPU(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, image, boxes, box_ind, ch, cw):
+        from oracle import oracle as orc
+        out = orc.crop_and_resize_fwd(image.detach().contiguous().numpy(), boxes.numpy(),
+                                      box_ind.numpy(), ch, cw, 0.0)
+        ctx.save_for_backward(boxes, box_ind)
+        ctx.shape = tuple(image.shape)
+        return torch.from_numpy(out)
+
+    @staticmethod
+    def backward(ctx, g):
+        from oracle import oracle as orc
+        boxes, box_ind = ctx.saved_tensors
+        gi = orc.crop_and_resize_bwd(g.contiguous().numpy(), boxes.numpy(), box_ind.numpy(), ctx.shape)
+        return torch.from_numpy(gi), None, None, None, None
+
+
+def _pyramid(boxes, maps, pool, area):
+    from oracle import oracle as orc
+    lv = torch.from_numpy(orc.roi_levels(boxes.numpy(), area))
+    out = torch.zeros((boxes.shape[0], maps[0].shape[1], pool, pool))
+    for i, level in enumerate(range(2, 6)):
+        ix = torch.nonzero(lv == level)[:, 0]
+        if ix.numel():
+            crops = _CropCPU.apply(maps[i], boxes[ix].contiguous(),
+                                   torch.zeros(ix.numel(), dtype=torch.int32), pool, pool)
+            out = out.index_add(0, ix, crops)
+    return out
+
+
+def run(arch="resnet101", dim=256, n_obj=8, seed=1234, glm_size=257, full_dim=1024):
+    from oracle import oracle as orc
+    from sln_amodal_amd import nn_ops
+    from sln_amodal_amd.config import Config
+    from sln_amodal_amd.model import MaskRCNN
+    from sln_amodal_amd.modal import loss as L
+    from sln_amodal_amd.modal.Functions import build_rpn_targets
+    import torch.nn.functional as F
+
+    cores = min(os.cpu_count() or 1, 64)   # more threads than this only oversubscribe torch-CPU
+    torch.set_num_threads(cores)
+    saved = nn_ops.BACKEND
+    nn_ops.BACKEND = "torch"
+
+    class Cfg(Config):
+        NAME = "cpu"
+        IMAGE_MAX_DIM = dim
+        IMAGE_MIN_DIM = dim
+        ARCHITECTURE = arch
+        GLM_SIZE = glm_size
+
+    cfg = Cfg()
+    torch.manual_seed(0)
+    model = MaskRCNN(cfg, "/tmp/sln_cpu_logs").apply_amodal_heads()
+    for p in model.GLM_modual.parameters():
+        p.requires_grad = False
+    opt = model.make_optimizer(cfg.LEARNING_RATE)
+    rng = np.random.RandomState(seed)
+    image = torch.from_numpy((rng.randint(0, 256, (1, dim, dim, 3)) - cfg.MEAN_PIXEL)
+                             .astype(np.float32)).permute(0, 3, 1, 2).contiguous()
+    yy, xx = np.mgrid[0:dim, 0:dim]
+    s = dim / 1024.0
+    masks = np.stack([((yy - rng.uniform(128, 896) * s) / (rng.uniform(48, 256) * s)) ** 2 +
+                      ((xx - rng.uniform(128, 896) * s) / (rng.uniform(48, 256) * s)) ** 2 <= 1.0
+                      for _ in range(n_obj)])
+    label = orc.encode_labels(masks)
+
+    t0 = time.perf_counter()
+    # ---- target generation that the GPU step also does on-device ----
+    planes = orc.label_decode(label, 1)                                   # [1,N,H,W]
+    N = planes.shape[1]
+    am = planes.sum(axis=0) > 0
+    gt = []
+    for i in range(N):
+        ys, xs = np.where(am[i])
+        gt.append([ys.min(), xs.min(), ys.max() + 1, xs.max() + 1])
+    gt_boxes = torch.tensor(gt, dtype=torch.float32)
+    rpn_match, rpn_bbox = build_rpn_targets((dim, dim, 3), model.anchors_f64,
+                                            torch.ones(1, N, dtype=torch.int32), gt_boxes[None], cfg)
+    # ---- forward ----
+    model._set_modes("training")
+    probs, _ = model.glm_probs(image)
+    maps, rpn_logits, rpn_probs, rpn_deltas = model.rpn_forward(image)
+    rois = orc.proposal_layer(rpn_probs[0].detach().numpy(), rpn_deltas[0].detach().numpy(),
+                              model.anchors.numpy(), 1000, cfg.RPN_NMS_THRESHOLD,
+                              image_hw=(dim, dim))
+    norm_gt = (gt_boxes / dim).numpy()
+    P = rois.shape[0]
+    rois_t, cls, deltas, tmask = orc.detection_target_layer(
+        rois, np.ones(N, np.int32), norm_gt, planes, np.random.RandomState(1).permutation(P),
+        np.random.RandomState(2).permutation(P))
+    if rois_t.shape[0] == 0:  # random-init detector without positives: sample rois anyway
+        rois_t = rois[:100]
+        cls = np.zeros(rois_t.shape[0], np.int32)
+        deltas = np.zeros((rois_t.shape[0], 4), np.float32)
+        tmask = np.zeros((rois_t.shape[0], 1, 32, 32), np.float32)
+    boxes = torch.from_numpy(np.ascontiguousarray(rois_t))
+    R = boxes.shape[0]
+    zeros = torch.zeros(R, dtype=torch.int32)
+    glm_feat = _CropCPU.apply(probs.contiguous(), boxes, zeros, 16, 16).detach()
+    fmaps = [m.contiguous() for m in maps[:4]]
+    area = float(dim * dim)
+    x = _pyramid(boxes, fmaps, cfg.POOL_SIZE, area)
+    x = nn_ops.conv_bn_act(x, model.classifier.conv1, model.classifier.bn1, relu=True)
+    x = nn_ops.conv_bn_act(x, model.classifier.conv2, model.classifier.bn2, relu=True).reshape(-1, 1024)
+    cls_logits = model.classifier.linear_class(x)
+    bbox = model.classifier.linear_bbox(x).view(R, -1, 4)
+    m = torch.cat((glm_feat, _pyramid(boxes, fmaps, cfg.MASK_POOL_SIZE, area)), dim=1)
+    mk = model.mask
+    m = nn_ops.conv_bn_act(m, mk.conv1, mk.bn1, relu=True, same=True)
+    m = nn_ops.conv_bn_act(m, mk.conv2, mk.bn2, relu=True, same=True)
+    m = nn_ops.conv_bn_act(m, mk.conv3, mk.bn3, relu=True, same=True)
+    m = nn_ops.conv_bn_act(m, mk.conv4, mk.bn4, relu=True, same=True)
+    m = F.relu(F.conv_transpose2d(m, mk.deconv.weight, mk.deconv.bias, stride=2))
+    m = nn_ops.conv_bn_act(m, mk.conv5)
+    loss, _ = L.total_loss(rpn_match.unsqueeze(2), rpn_bbox, rpn_logits, rpn_deltas,
+                           torch.from_numpy(cls)[None], cls_logits[None],
+                           torch.from_numpy(deltas)[None], bbox[None],
+                           torch.from_numpy(tmask)[None], m[None],
+                           torch.ones(1, R, dtype=torch.bool))
+    if not loss.requires_grad or float(loss) == 0.0:   # no positives: still time a backward
+        loss = L.compute_rpn_class_loss(rpn_match.unsqueeze(2), rpn_logits) + cls_logits.sum() * 0 + \
+            m.mean() * 1e-3 + bbox.mean() * 1e-3
+    opt.zero_grad(set_to_none=True)
+    loss.backward()
+    params = [p for p in model.parameters() if p.requires_grad and p.grad is not None]
+    torch.nn.utils.clip_grad_norm_(params, cfg.GRADIENT_CLIP_NORM)
+    opt.step()
+    dt = time.perf_counter() - t0
+    nn_ops.BACKEND = saved
+    cpu = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    # scale the bounded sample to the metric's unit (images/sec of 1024^2 images) by
+    # algorithmic FLOPs
+    bb = 435.1 if arch == "resnet101" else 280.0
+    def gflop(d, g):
+        s_ = (d / 1024.0) ** 2
+        return 3 * ((bb + 207.6) * s_ + 158.7) + 872.9 * (g / 513.0) ** 2
+    ratio = gflop(full_dim, 513) / gflop(dim, glm_size)
+    return {"value": round(1.0 / (dt * ratio), 6), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample_seconds": round(dt, 2), "flop_scale_to_full": round(ratio, 3), "cpu_model": cpu,
+            "sample": "1 train step on 1 synthetic %dx%d image, GLM at %d^2 (%s, stage=all, R=%d rois): "
+                      "torch-CPU conv stacks (%d threads) + oracle C NMS/crop/label decode; seconds "
+                      "scaled by algorithmic FLOPs to a %dx%d image with the GLM at 513^2" %
+                      (dim, dim, glm_size, arch, R, cores, full_dim, full_dim)}
+
+
+if __name__ == "__main__":
+    import json
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    print(json.dumps(run(sys.argv[1] if len(sys.argv) > 1 else "resnet50",
+                         int(sys.argv[2]) if len(sys.argv) > 2 else 256)))

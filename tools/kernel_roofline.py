@@ -1,0 +1,69 @@
+"""Per-kernel roofline measurements at the BASELINE configuration (bs 16, 1024^2):
+HIP-event timing on the launch stream, algorithmic bytes as defined in DESIGN.md
+("Measurement").  Imported by bench.py; results go into the JSON line."""
+import torch
+
+PEAK_HBM_GBS = 8000.0
+
+
+def _time(fn, iters=10, warmup=3):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / iters  # seconds per launch
+
+
+def measure(dev, B=16):
+    from sln_amodal_amd import ops
+    from sln_amodal_amd.modal.modals import _PyramidCrop
+    g = torch.Generator(device=dev).manual_seed(7)
+    out = {}
+    # ---- RoIAlign: mask-head crop, 1600 rois x 256 ch x 16x16 from P2..P5 (NHWC) ----
+    C, K, pool = 256, B * 100, 16
+    maps = [torch.randn(B, C, s, s, device=dev, generator=g).contiguous(memory_format=torch.channels_last)
+            for s in (256, 128, 64, 32)]
+    ctr = torch.rand(K, 2, device=dev, generator=g) * 0.6 + 0.2
+    size = torch.exp(torch.rand(K, 2, device=dev, generator=g) * 2.5 - 3.0)
+    boxes = torch.cat([ctr - size / 2, ctr + size / 2], 1).clamp(0, 1).contiguous()
+    ind = torch.arange(B, dtype=torch.int32, device=dev).repeat_interleave(100)
+    from sln_amodal_amd.modal.modals import roi_levels
+    lvl = roi_levels(boxes, (1024, 1024))
+    elems = K * C * pool * pool
+    t = _time(lambda: _PyramidCrop.apply(boxes, ind, lvl, pool, *maps))
+    out["roialign_fwd"] = {"kernel": "pyr_fwd_kernel<4>", "bound": "hbm", "bytes_per_elem": 20,
+                           "elems": elems, "ms": round(t * 1e3, 4),
+                           "achieved": round(elems * 20 / t / 1e9, 1), "peak": PEAK_HBM_GBS,
+                           "unit": "GB/s", "frac": round(elems * 20 / t / 1e9 / PEAK_HBM_GBS, 4)}
+    ms = [m.clone().requires_grad_(True) for m in maps]
+    o = _PyramidCrop.apply(boxes, ind, lvl, pool, *ms)
+    up = torch.randn_like(o)
+    t = _time(lambda: torch.autograd.grad(o, ms, up, retain_graph=True))
+    out["roialign_bwd"] = {"kernel": "pyr_bwd_kernel (+memset of 4 grad maps)", "bound": "hbm",
+                           "bytes_per_elem": 36, "elems": elems, "ms": round(t * 1e3, 4),
+                           "achieved": round(elems * 36 / t / 1e9, 1), "peak": PEAK_HBM_GBS,
+                           "unit": "GB/s", "frac": round(elems * 36 / t / 1e9 / PEAK_HBM_GBS, 4)}
+    # ---- NMS: 16 images x 6000 boxes ----
+    N = 6000
+    tl = torch.rand(B, N, 2, device=dev, generator=g) * 900
+    wh = torch.rand(B, N, 2, device=dev, generator=g) * 200 + 8
+    sc = torch.sort(torch.rand(B, N, device=dev, generator=g), dim=1, descending=True)[0]
+    dets = torch.cat([tl, (tl + wh).clamp(max=1024), sc.unsqueeze(2)], 2).contiguous()
+    t = _time(lambda: ops.nms_sorted(dets, 0.7, 1000))
+    out["nms"] = {"kernel": "nms_mask_kernel+nms_reduce_kernel", "bound": "latency",
+                  "us_per_image": round(t * 1e6 / B, 2), "ms_per_batch": round(t * 1e3, 4),
+                  "images": B, "boxes": N, "host_sync": False}
+    # ---- label decode: 16 x 1024^2 uint64 -> [16,1,8,1024,1024] u8 ----
+    lab = torch.randint(0, 1 << 40, (B, 1024, 1024), device=dev, generator=g, dtype=torch.int64)
+    t = _time(lambda: ops.label_decode(lab, 1, 8))
+    by = B * 1024 * 1024 * (8 + 8)
+    out["label_decode"] = {"kernel": "label_decode_kernel", "bound": "hbm", "bytes": by,
+                           "ms": round(t * 1e3, 4), "achieved": round(by / t / 1e9, 1),
+                           "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                           "frac": round(by / t / 1e9 / PEAK_HBM_GBS, 4)}
+    return out
