@@ -104,6 +104,15 @@ class _ConvFn(torch.autograd.Function):
             gx = _fwd(gz, wt, Ci, KH, KW, (1, 1), dil, dil[0] * (KH - 1) - pt, dil[1] * (KW - 1) - pl,
                       H, W, None, None, None, False)
             need_x = False
+        if need_x and KH == 1 and KW == 1 and Co % 8 == 0 and pads == (0, 0, 0, 0):
+            # strided 1x1: the data gradient lives on the stride lattice, zeros elsewhere
+            N, _, H, W = x.shape
+            wt = _split(weight, flip_swap=True)
+            OH, OW = gz.shape[2], gz.shape[3]
+            small = _fwd(gz, wt, Ci, 1, 1, (1, 1), (1, 1), 0, 0, OH, OW, None, None, None, False)
+            gx = torch.zeros((N, H, W, Ci), dtype=torch.float32, device=x.device).permute(0, 3, 1, 2)
+            gx[:, :, ::stride[0], ::stride[1]] = small
+            need_x = False
         if need_x or need_w:
             if pt == pb and pl == pr:
                 xin, pad = x, (pt, pl)

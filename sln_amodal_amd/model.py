@@ -122,9 +122,8 @@ class MaskRCNN(nn.Module):
             ok = bool(re.fullmatch(layer_regex, name))
             if not ok:
                 p.requires_grad = False
-            elif not exclusive_off and not name.startswith("GLM_modual") and \
-                    not (name in bn_names and not name.startswith("mask.")):
-                p.requires_grad = True
+            elif not exclusive_off and not name.startswith("GLM_modual") and name not in bn_names:
+                p.requires_grad = True   # BatchNorm stays frozen (model.py:192-197)
 
     # ------------------------------------------------------------ bookkeeping
     def set_log_dir(self, model_path=None):
@@ -205,9 +204,12 @@ class MaskRCNN(nn.Module):
         maps, rpn_class_logits, rpn_class, rpn_bbox = self.rpn_forward(molded_images)
         mrcnn_feature_maps = maps[:4]
         count = cfg.POST_NMS_ROIS_TRAINING if mode == "training" else cfg.POST_NMS_ROIS_INFERENCE
-        rpn_rois, num_rois = proposal_layer([rpn_class, rpn_bbox], proposal_count=count,
-                                            nms_threshold=cfg.RPN_NMS_THRESHOLD,
-                                            anchors=self.anchors, config=cfg, return_counts=True)
+        if priorities and "rpn_rois" in priorities:   # parity tests: externally fixed proposals
+            rpn_rois, num_rois = priorities["rpn_rois"], priorities["num_rois"]
+        else:
+            rpn_rois, num_rois = proposal_layer([rpn_class, rpn_bbox], proposal_count=count,
+                                                nms_threshold=cfg.RPN_NMS_THRESHOLD,
+                                                anchors=self.anchors, config=cfg, return_counts=True)
         scale = torch.tensor([H, W, H, W], dtype=torch.float32, device=molded_images.device)
 
         if mode == "inference":
@@ -243,6 +245,7 @@ class MaskRCNN(nn.Module):
             "mrcnn_mask": mrcnn_mask.reshape(B, R, mrcnn_mask.shape[1], mrcnn_mask.shape[2],
                                              mrcnn_mask.shape[3]),
             "image_path": image_path, "gloable_lab": gloable_lab, "num_rois": num_rois,
+            "rpn_rois": rpn_rois,
         }
 
     def _predict_inference(self, rpn_rois, num_rois, maps, probs, image_metas, scale):
