@@ -165,25 +165,40 @@ int sln_pyramid_crop_bwd_f32(const float *grads, int g_cstride, int g_coffset, c
  * matrix cores with split-bf16 operands (fp32-class accuracy, see csrc/conv.hip).
  * Replaces the cuDNN calls behind nn.Conv2d (+ the separate BatchNorm / ReLU /
  * residual-add / F.pad passes around them) on the reference's path.
+ * All activations are NHWC = [pixels][channels]; `parts` = 2 or 3 bf16 parts per
+ * fp32 value; "*_pad" channel counts are multiples of 8 (zero filled).
  *
- * sln_conv_split_weights_f32: fp32 weights, element strides (s_o,s_i,s_kh,s_kw),
- *   -> out [parts][O][KH][KW][I] bf16 (parts = 2 or 3).  flip=1 mirrors the taps.
- * sln_conv2d_fwd_f32: x [N,H,W,Cin] NHWC fp32 (Cin % 8 == 0) -> y [N,OH,OW,Cout]
- *   NHWC fp32, y = relu?(conv(x,w)*scale[c] + shift[c] + residual).  Taps that fall
- *   outside the image read zero (pad_top / pad_left may differ from bottom/right:
- *   TensorFlow 'SAME' padding).  scale/shift/residual may be NULL.
- * sln_conv2d_wgrad_f32: dw[O][KH][KW][I] (fp32, O = Cout, I = Cin) = sum over
- *   pixels of gy[pix][o] * x[pix @ tap][i]; split-K over pixel chunks with fp32
- *   atomics into a callee-zeroed dw.
+ * sln_conv_split_weights_f32  fp32 weights with element strides (s_o,s_i,s_kh,s_kw)
+ *     -> out [parts][O][KH][KW][I_pad] bf16.  flip=1 mirrors the taps (data grad).
+ * sln_act_split_f32           x [M][C] fp32 -> out [parts][M][C_pad] bf16.
+ * sln_conv_grad_prep_f32      gz = gy * (y > 0) * scale[c] (y, scale optional):
+ *     writes gu = gy*(y>0) fp32 [M][C] (optional), gz parts [parts][M][C_pad] and
+ *     the per-channel sum of gz into gbias [C] (optional, zeroed by the callee).
+ * sln_conv2d_fwd_f32          y [N,OH,OW,Cout] fp32 = relu?(conv(x,w)*scale[c] +
+ *     shift[c] + residual); x_parts [parts][N*H*W][Cin] (Cin % 8 == 0), w_parts
+ *     [parts][Cout][KH][KW][Cin].  Taps outside the image read zero (pad_top/left
+ *     may differ from bottom/right: TensorFlow 'SAME' padding).
+ * sln_conv2d_wgrad_f32        gw [Cout][KH][KW][Cin] fp32 (zeroed by the callee) =
+ *     sum over output pixels of gz[pix][co] * x[pix @ tap][ci]; split-K over pixel
+ *     ranges with fp32 atomics (summation order not deterministic).
  * ------------------------------------------------------------------------- */
-int sln_conv_split_weights_f32(const float *w, int O, int I, int KH, int KW, long s_o, long s_i,
-                               long s_kh, long s_kw, int flip, int parts, uint16_t *out,
+int sln_conv_split_weights_f32(const float *w, int O, int I, int I_pad, int KH, int KW, long s_o,
+                               long s_i, long s_kh, long s_kw, int flip, int parts, uint16_t *out,
                                sln_stream_t stream);
-int sln_conv2d_fwd_f32(const float *x, int N, int H, int W, int Cin, const uint16_t *w_parts,
-                       int parts, int Cout, int KH, int KW, int stride_h, int stride_w, int dil_h,
-                       int dil_w, int pad_top, int pad_left, int OH, int OW, const float *scale,
-                       const float *shift, const float *residual, int relu, float *y,
-                       sln_stream_t stream);
+int sln_act_split_f32(const float *x, int64_t M, int C, int C_pad, int parts, uint16_t *out,
+                      sln_stream_t stream);
+int sln_conv_grad_prep_f32(const float *gy, const float *y, const float *scale, int64_t M, int C,
+                           int C_pad, int parts, float *gu, uint16_t *gz_parts, float *gbias,
+                           sln_stream_t stream);
+int sln_conv2d_fwd_f32(const uint16_t *x_parts, int N, int H, int W, int Cin,
+                       const uint16_t *w_parts, int parts, int Cout, int KH, int KW, int stride_h,
+                       int stride_w, int dil_h, int dil_w, int pad_top, int pad_left, int OH, int OW,
+                       const float *scale, const float *shift, const float *residual, int relu,
+                       float *y, sln_stream_t stream);
+int sln_conv2d_wgrad_f32(const uint16_t *gz_parts, int Cout, int Cout_pad, const uint16_t *x_parts,
+                         int N, int H, int W, int Cin, int Cin_pad, int parts, int KH, int KW,
+                         int stride_h, int stride_w, int dil_h, int dil_w, int pad_top, int pad_left,
+                         int OH, int OW, float *gw, sln_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1,29 +1,47 @@
 """HIP convolution backend behind nn_ops.conv_bn_act (csrc/conv.hip).
 
-Forward and data-gradient run on the split-bf16 implicit-GEMM kernel (the data
-gradient of a stride-1 convolution is a forward convolution with mirrored,
-channel-swapped weights).  Weight gradients and strided data gradients still go
-through aten (MIOpen) in this revision -- DESIGN.md tracks what runs where.
+Per layer:  x --act_split--> xparts --conv_fwd(+BN affine, residual, ReLU)--> y
+backward:   gy --grad_prep(ReLU mask, BN scale, bias grad)--> gzparts
+            gx = conv_fwd(gzparts, mirrored/swapped weights)   (stride 1; strided
+                 1x1: lattice scatter)
+            gw = conv_wgrad(gzparts, xparts)
+Everything runs in libsln_amodal_hip.so; torch only owns the buffers.
 """
 import torch
 
 from . import _lib, ops
 
 PARTS = 3          # 3 = fp32-class accuracy (6 MFMA products); 2 = ~4e-6 per layer (3 products)
-_cache = {}
+class _NoCache(dict):
+    pass
+
+
+_cache = _NoCache()   # kept for tools that call _cache.clear(); caches live on the tensors
 
 
 def supports(conv, x):
-    return (x.dtype == torch.float32 and conv.groups == 1 and conv.in_channels % 8 == 0 and
-            conv.weight.dtype == torch.float32 and conv.padding_mode == "zeros")
+    return (x.dtype == torch.float32 and conv.groups == 1 and conv.weight.dtype == torch.float32 and
+            conv.padding_mode == "zeros")
 
 
-def _split(weight, flip_swap=False, parts=None):
-    """[parts][O][KH][KW][I] bf16, cached per (tensor, version)."""
+def _pad8(c):
+    return (c + 7) // 8 * 8
+
+
+def _split_weights(weight, flip_swap=False, parts=None):
+    """[parts][O][KH][KW][I_pad] bf16.  Cached on the tensor object itself (keyed by its
+    version counter), so the cache dies with the tensor and can never alias a new
+    tensor that happens to reuse the address."""
     parts = parts or PARTS
-    key = (weight.data_ptr(), flip_swap, parts)
-    hit = _cache.get(key)
-    if hit is not None and hit[0] == weight._version and hit[2] == tuple(weight.shape):
+    cache = getattr(weight, "_sln_wparts", None)
+    if cache is None:
+        cache = {}
+        try:
+            weight._sln_wparts = cache
+        except Exception:
+            pass
+    hit = cache.get((flip_swap, parts))
+    if hit is not None and hit[0] == weight._version:
         return hit[1]
     w = weight.detach()
     Co, Ci, KH, KW = w.shape
@@ -32,23 +50,16 @@ def _split(weight, flip_swap=False, parts=None):
         O, I, so, si = Ci, Co, s[1], s[0]
     else:
         O, I, so, si = Co, Ci, s[0], s[1]
-    out = torch.empty((parts, O, KH, KW, I), dtype=torch.bfloat16, device=w.device)
+    Ip = _pad8(I)
+    out = torch.empty((parts, O, KH, KW, Ip), dtype=torch.bfloat16, device=w.device)
     _lib.check(_lib.lib().sln_conv_split_weights_f32(
-        ops._ptr(w), O, I, KH, KW, so, si, s[2], s[3], 1 if flip_swap else 0, parts, ops._ptr(out),
-        ops._stream()), "sln_conv_split_weights_f32")
-    _cache[key] = (weight._version, out, tuple(weight.shape))
+        ops._ptr(w), O, I, Ip, KH, KW, so, si, s[2], s[3], 1 if flip_swap else 0, parts,
+        ops._ptr(out), ops._stream()), "sln_conv_split_weights_f32")
+    cache[(flip_swap, parts)] = (weight._version, out)
     return out
 
 
-def _fwd(x, wparts, Cout, KH, KW, stride, dil, pt, pl, OH, OW, scale, shift, residual, relu):
-    N, Cin, H, W = x.shape
-    y = torch.empty((N, Cout, OH, OW), dtype=torch.float32, device=x.device,
-                    memory_format=torch.channels_last)
-    _lib.check(_lib.lib().sln_conv2d_fwd_f32(
-        ops._ptr(x), N, H, W, Cin, ops._ptr(wparts), wparts.shape[0], Cout, KH, KW, stride[0],
-        stride[1], dil[0], dil[1], pt, pl, OH, OW, ops._ptr(scale), ops._ptr(shift),
-        ops._ptr(residual), 1 if relu else 0, ops._ptr(y), ops._stream()), "sln_conv2d_fwd_f32")
-    return y
+_split = _split_weights
 
 
 def _nhwc(t):
@@ -58,80 +69,120 @@ def _nhwc(t):
     return t.contiguous(memory_format=torch.channels_last)
 
 
+def act_parts(x, parts=None):
+    """x logical [N,C,H,W] (NHWC in memory) -> bf16 parts [P, N*H*W, C_pad].  Cached on
+    the tensor object: one activation often feeds several convs (block input ->
+    conv1 + downsample, ASPP's four branches, the P-maps -> RPN + heads)."""
+    parts = parts or PARTS
+    hit = getattr(x, "_sln_parts", None)
+    if hit is not None and hit[0] == (x._version, parts):
+        return hit[1]
+    xc = _nhwc(x.detach())
+    N, C, H, W = xc.shape
+    Cp = _pad8(C)
+    out = torch.empty((parts, N * H * W, Cp), dtype=torch.bfloat16, device=x.device)
+    _lib.check(_lib.lib().sln_act_split_f32(ops._ptr(xc), N * H * W, C, Cp, parts, ops._ptr(out),
+                                            ops._stream()), "sln_act_split_f32")
+    try:
+        x._sln_parts = ((x._version, parts), out)
+    except Exception:
+        pass
+    return out
+
+
+def _fwd(xparts, N, H, W, wparts, Cout, KH, KW, stride, dil, pt, pl, OH, OW, scale, shift, residual,
+         relu):
+    y = torch.empty((N, OH, OW, Cout), dtype=torch.float32, device=xparts.device).permute(0, 3, 1, 2)
+    _lib.check(_lib.lib().sln_conv2d_fwd_f32(
+        ops._ptr(xparts), N, H, W, xparts.shape[2], ops._ptr(wparts), wparts.shape[0], Cout, KH, KW,
+        stride[0], stride[1], dil[0], dil[1], pt, pl, OH, OW, ops._ptr(scale), ops._ptr(shift),
+        ops._ptr(residual), 1 if relu else 0, ops._ptr(y), ops._stream()), "sln_conv2d_fwd_f32")
+    return y
+
+
+def _grad_prep(gy, y, scale, want_gu, want_bias, parts):
+    gy = _nhwc(gy)
+    N, C, H, W = gy.shape
+    M, Cp = N * H * W, _pad8(C)
+    gz = torch.empty((parts, M, Cp), dtype=torch.bfloat16, device=gy.device)
+    gu = gy
+    write_gu = want_gu and y is not None
+    if write_gu:
+        gu = torch.empty((N, H, W, C), dtype=torch.float32, device=gy.device).permute(0, 3, 1, 2)
+    gb = torch.empty((C,), dtype=torch.float32, device=gy.device) if want_bias else None
+    _lib.check(_lib.lib().sln_conv_grad_prep_f32(
+        ops._ptr(gy), ops._ptr(y), ops._ptr(scale), M, C, Cp, parts,
+        ops._ptr(gu) if write_gu else None, ops._ptr(gz), ops._ptr(gb), ops._stream()),
+        "sln_conv_grad_prep_f32")
+    return gz, (gu if want_gu else None), gb
+
+
 class _ConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, bn_scale, bn_shift, residual, relu, stride, dil, pads):
-        x = _nhwc(x)
+        parts = PARTS
         Co, Ci, KH, KW = weight.shape
         N, _, H, W = x.shape
         pt, pb, pl, pr = pads
         OH = (H + pt + pb - dil[0] * (KH - 1) - 1) // stride[0] + 1
         OW = (W + pl + pr - dil[1] * (KW - 1) - 1) // stride[1] + 1
-        scale = bn_scale
-        shift = bn_shift
+        scale, shift = bn_scale, bn_shift
         if bias is not None:
             shift = bias * bn_scale + bn_shift if bn_scale is not None else bias
         if shift is not None:
             shift = shift.detach().contiguous()
         if scale is not None:
             scale = scale.detach().contiguous()
-        res = _nhwc(residual) if residual is not None else None
-        y = _fwd(x, _split(weight), Co, KH, KW, stride, dil, pt, pl, OH, OW, scale, shift, res, relu)
-        ctx.save_for_backward(x, weight, scale, y if relu else None)
-        ctx.cfg = (stride, dil, pads, relu, bias is not None, residual is not None)
+        res = _nhwc(residual.detach()) if residual is not None else None
+        xp = act_parts(x, parts)
+        y = _fwd(xp, N, H, W, _split_weights(weight, parts=parts), Co, KH, KW, stride, dil, pt, pl,
+                 OH, OW, scale, shift, res, relu)
+        need_w = ctx.needs_input_grad[1]
+        ctx.save_for_backward(xp if need_w else None, weight, scale, y if relu else None)
+        ctx.cfg = (stride, dil, pads, relu, bias is not None, residual is not None, (N, Ci, H, W),
+                   parts)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, weight, scale, y = ctx.saved_tensors
-        stride, dil, pads, relu, has_bias, has_res = ctx.cfg
+        xp, weight, scale, y = ctx.saved_tensors
+        stride, dil, pads, relu, has_bias, has_res, xshape, parts = ctx.cfg
         pt, pb, pl, pr = pads
         Co, Ci, KH, KW = weight.shape
-        gu = _nhwc(gy)
-        if relu:
-            gu = gu * (y > 0)
-        g_res = gu if (has_res and ctx.needs_input_grad[5]) else None
-        gz = gu * scale.view(1, -1, 1, 1) if scale is not None else gu
-        gz = _nhwc(gz)
-        g_bias = None
-        if has_bias and ctx.needs_input_grad[2]:
-            g_bias = gz.sum(dim=(0, 2, 3))
-        gx = gw = None
+        N, _, H, W = xshape
+        OH, OW = gy.shape[2], gy.shape[3]
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-        if need_x and stride == (1, 1) and Co % 8 == 0:
-            N, _, H, W = x.shape
-            wt = _split(weight, flip_swap=True)
-            gx = _fwd(gz, wt, Ci, KH, KW, (1, 1), dil, dil[0] * (KH - 1) - pt, dil[1] * (KW - 1) - pl,
-                      H, W, None, None, None, False)
-            need_x = False
-        if need_x and KH == 1 and KW == 1 and Co % 8 == 0 and pads == (0, 0, 0, 0):
-            # strided 1x1: the data gradient lives on the stride lattice, zeros elsewhere
-            N, _, H, W = x.shape
-            wt = _split(weight, flip_swap=True)
-            OH, OW = gz.shape[2], gz.shape[3]
-            small = _fwd(gz, wt, Ci, 1, 1, (1, 1), (1, 1), 0, 0, OH, OW, None, None, None, False)
-            gx = torch.zeros((N, H, W, Ci), dtype=torch.float32, device=x.device).permute(0, 3, 1, 2)
-            gx[:, :, ::stride[0], ::stride[1]] = small
-            need_x = False
-        if need_x or need_w:
-            if pt == pb and pl == pr:
-                xin, pad = x, (pt, pl)
+        want_res = has_res and ctx.needs_input_grad[5]
+        want_bias = has_bias and ctx.needs_input_grad[2]
+        gz, g_res, g_bias = _grad_prep(gy, y, scale, want_res, want_bias, parts)
+        gx = gw = None
+        if need_x:
+            wt = _split_weights(weight, flip_swap=True, parts=parts)
+            if stride == (1, 1):
+                gx = _fwd(gz, N, OH, OW, wt, Ci, KH, KW, (1, 1), dil, dil[0] * (KH - 1) - pt,
+                          dil[1] * (KW - 1) - pl, H, W, None, None, None, False)
+            elif KH == 1 and KW == 1 and pads == (0, 0, 0, 0):
+                # strided 1x1: the gradient lives on the stride lattice, zero elsewhere
+                small = _fwd(gz, N, OH, OW, wt, Ci, 1, 1, (1, 1), (1, 1), 0, 0, OH, OW, None, None,
+                             None, False)
+                gx = torch.zeros((N, H, W, Ci), dtype=torch.float32, device=gy.device).permute(0, 3, 1, 2)
+                gx[:, :, ::stride[0], ::stride[1]] = small
             else:
-                xin, pad = torch.nn.functional.pad(x, (pl, pr, pt, pb)), (0, 0)
-            g_in, gw, _ = torch.ops.aten.convolution_backward(
-                gz, xin, weight, None, list(stride), list(pad), list(dil), False, [0, 0], 1,
-                [need_x, need_w, False])
-            if need_x:
-                gx = g_in
-                if pad == (0, 0) and (pt or pb or pl or pr):
-                    gx = g_in[:, :, pt:g_in.shape[2] - pb, pl:g_in.shape[3] - pr]
+                raise NotImplementedError("data gradient of a strided %dx%d conv" % (KH, KW))
+        if need_w:
+            gw_t = torch.empty((Co, KH, KW, Ci), dtype=torch.float32, device=gy.device)
+            _lib.check(_lib.lib().sln_conv2d_wgrad_f32(
+                ops._ptr(gz), Co, gz.shape[2], ops._ptr(xp), N, H, W, Ci, xp.shape[2], parts, KH, KW,
+                stride[0], stride[1], dil[0], dil[1], pt, pl, OH, OW, ops._ptr(gw_t), ops._stream()),
+                "sln_conv2d_wgrad_f32")
+            gw = gw_t.permute(0, 3, 1, 2)  # logical [Co,Ci,KH,KW]
         return gx, gw, g_bias, None, None, g_res, None, None, None, None
 
 
-def conv_bn_act(x, conv, bn, relu, residual, pads):
+def conv_bn_act(x, conv, bn, relu, residual, pads, weight=None):
     from .nn_ops import bn_affine
     scale = shift = None
     if bn is not None:
         scale, shift = bn_affine(bn)
-    return _ConvFn.apply(x, conv.weight, conv.bias, scale, shift, residual, bool(relu),
-                         tuple(conv.stride), tuple(conv.dilation), tuple(pads))
+    return _ConvFn.apply(x, conv.weight if weight is None else weight, conv.bias, scale, shift,
+                         residual, bool(relu), tuple(conv.stride), tuple(conv.dilation), tuple(pads))

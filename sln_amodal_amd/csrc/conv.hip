@@ -1,26 +1,32 @@
-// Implicit-GEMM convolution for gfx950 on the bf16 matrix cores with fp32-class
-// accuracy ("split-bf16"): every fp32 operand x is represented as a sum of P bf16
-// parts, x ~= x0 + x1 (+ x2), xi = bf16_rne(x - x0 - ... - x(i-1)); the product
-// A*B is accumulated in fp32 from the dominant part-pairs:
-//   P = 2 : a0*b0 + a0*b1 + a1*b0                     (rel. error ~4e-6 per layer)
-//   P = 3 : ... + a1*b1 + a0*b2 + a2*b0               (rel. error ~1e-7, fp32 class)
-// v_mfma_f32_32x32x16_bf16 runs at 16x the rate of the fp32-input MFMA
-// (MI355X_MICROARCH.md), so 3 / 6 bf16 MFMAs per fp32-equivalent product still
-// leave 5.3x / 2.7x the fp32-MFMA roofline.  Accumulation is fp32 inside the MFMA.
+// Implicit-GEMM convolution stack for gfx950 on the bf16 matrix cores with
+// fp32-class accuracy ("split-bf16").
 //
-// GEMM view (NHWC activations): M = N*OH*OW output pixels, N = Cout,
-// K = KH*KW*Cin walked tap by tap in 32-channel chunks.
-//   A[m][k] = x[n, oh*s - pad + kh*d, ow*s - pad + kw*d, ci]   (fp32 in HBM, split
-//             on the fly while staging to LDS; out-of-image taps are zero = the
-//             reference's SamePad2d / conv padding)
-//   B[k][n] = w[cout][kh][kw][ci], pre-split once per weight update into
-//             [P][Cout][KH*KW*Cin] bf16 (sln_conv_split_weights_f32).
-// Tile 128x128x32, 256 threads = 4 waves (2x2), each wave 64x64 = 2x2 MFMA tiles of
-// 32x32 (64 accumulator VGPRs).  LDS rows are 32 bf16 + 8 pad (80 B): the
-// ds_read_b128 fragment reads of 16 consecutive rows hit 16 distinct 4-bank groups
-// (conflict-free).  One LDS stage + register prefetch of the next k-step.
-// Epilogue: y = relu?( acc*scale[c] + shift[c] + residual ) -- bias and the frozen
-// BatchNorm affine are folded into scale/shift by the caller.
+// Every fp32 operand v is represented as a sum of P bf16 parts,
+//   v ~= v0 + v1 (+ v2),   vi = bf16_rne(v - v0 - ... - v(i-1)),
+// and a product of two operands is accumulated in fp32 (inside the MFMA) from
+// the dominant part pairs:
+//   P = 2 : a0*b0 + a0*b1 + a1*b0                    (~4e-6 relative per layer)
+//   P = 3 : ... + a1*b1 + a0*b2 + a2*b0              (~1e-7, the accuracy of fp32)
+// v_mfma_f32_32x32x16_bf16 issues at 16x the rate of the fp32-input MFMA
+// (MI355X_MICROARCH.md), so 3 / 6 bf16 MFMAs per fp32-equivalent product leave
+// 5.3x / 2.7x the fp32-MFMA roofline.
+//
+// Data flow of one conv layer (all activations NHWC = [pixels][channels]):
+//   act_split      x fp32 -> xparts [P][M][Cp] bf16 (one HBM-bound pass; the
+//                  consumer GEMMs then need no VALU work at all on their operands)
+//   conv_fwd       y = relu?( conv(xparts, wparts)*scale + shift + residual )
+//   grad_prep      gz = gy * (y>0) * scale  -> gzparts (+ fp32 gu, + bias grad)
+//   conv_fwd       gx = conv(gzparts, wTparts)        (data gradient, stride 1)
+//   conv_wgrad     gw[co][tap][ci] = sum_pix gz[pix][co] * x[pix@tap][ci]
+//                  ("TN" GEMM: both operands are pixel-major, fragments are
+//                  fetched with the ds_read_b64_tr_b16 transposing LDS read)
+//
+// conv_fwd GEMM view: M = N*OH*OW output pixels, N = Cout, K = KH*KW*Cin walked
+// tap by tap in 32-channel chunks; taps outside the image read zero (the
+// reference's SamePad2d / conv padding).  Tile 128x128x32, 256 threads = 4 waves
+// (2x2), each wave 64x64 = 2x2 MFMA tiles of 32x32.  LDS rows are 32 bf16 + 8 pad
+// (80 B): the ds_read_b128 fragment reads of 16 consecutive rows hit 16 distinct
+// 4-bank groups (conflict-free).  Register prefetch of the next k-step.
 #include "common.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -32,18 +38,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 #define BK 32
 #define LDK 40  // padded row length in bf16 (80 B)
 
-struct ConvParams {
-    const float *x;
-    const __bf16 *w;      // [P][Cout][Ktot]
-    const float *scale;   // [Cout] or null (=1)
-    const float *shift;   // [Cout] or null (=0)
-    const float *residual;  // [M][Cout] or null
-    float *y;             // [M][Cout]
-    long w_part_stride;
-    int N, H, W, Cin, Cout, KH, KW, sh, sw, dh, dw, pt, pl, OH, OW, relu;
-    int M, Ktot, cin_chunks, gm, gn;
-};
-
+// ---------------------------------------------------------------- elementwise
 __device__ __forceinline__ void split4(const float4 v, bf16x4 *parts, int P) {
     float r[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -59,6 +54,145 @@ __device__ __forceinline__ void split4(const float4 v, bf16x4 *parts, int P) {
     }
 }
 
+// x [M][C] fp32 -> parts [P][M][Cp] bf16 (channels C..Cp-1 zero).  C % 4 == 0 fast path.
+__global__ __launch_bounds__(256) void act_split_kernel(const float *__restrict__ x, long M, int C,
+                                                        int Cp, int P, __bf16 *__restrict__ parts) {
+    const int q4 = Cp / 4;
+    const long total = M * q4;
+    const long pstride = M * Cp;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long m = e / q4;
+        const int c = (int)(e - m * q4) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c + 3 < C && (C & 3) == 0) {
+            v = *(const float4 *)(x + m * C + c);
+        } else {
+            float t[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < 4; ++j)
+                if (c + j < C) t[j] = x[m * C + c + j];
+            v = make_float4(t[0], t[1], t[2], t[3]);
+        }
+        bf16x4 ps[3];
+        split4(v, ps, P);
+        for (int p = 0; p < P; ++p) *(bf16x4 *)(parts + p * pstride + m * Cp + c) = ps[p];
+    }
+}
+
+// gz = gy * (y > 0 ? 1 : 0) * scale[c]; writes gu = gy*(y>0) (fp32, optional), the
+// bf16 parts of gz, and accumulates the per-channel sum of gz (bias gradient).
+__global__ __launch_bounds__(256) void grad_prep_kernel(const float *__restrict__ gy,
+                                                        const float *__restrict__ y,
+                                                        const float *__restrict__ scale, long M, int C,
+                                                        int Cp, int P, float *__restrict__ gu,
+                                                        __bf16 *__restrict__ parts,
+                                                        float *__restrict__ gbias) {
+    extern __shared__ float s_bias[];
+    if (gbias) {
+        for (int c = threadIdx.x; c < C; c += 256) s_bias[c] = 0.f;
+        __syncthreads();
+    }
+    const int q4 = Cp / 4;
+    const long total = M * q4;
+    const long pstride = M * Cp;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long m = e / q4;
+        const int c = (int)(e - m * q4) * 4;
+        float g[4] = {0.f, 0.f, 0.f, 0.f};
+        const bool vec = (c + 3 < C) && (C & 3) == 0;
+        if (vec) {
+            const float4 v = *(const float4 *)(gy + m * C + c);
+            g[0] = v.x; g[1] = v.y; g[2] = v.z; g[3] = v.w;
+            if (y) {
+                const float4 yy = *(const float4 *)(y + m * C + c);
+                if (!(yy.x > 0.f)) g[0] = 0.f;
+                if (!(yy.y > 0.f)) g[1] = 0.f;
+                if (!(yy.z > 0.f)) g[2] = 0.f;
+                if (!(yy.w > 0.f)) g[3] = 0.f;
+            }
+            if (gu) *(float4 *)(gu + m * C + c) = make_float4(g[0], g[1], g[2], g[3]);
+        } else {
+            for (int j = 0; j < 4; ++j)
+                if (c + j < C) {
+                    float v = gy[m * C + c + j];
+                    if (y && !(y[m * C + c + j] > 0.f)) v = 0.f;
+                    g[j] = v;
+                    if (gu) gu[m * C + c + j] = v;
+                }
+        }
+        if (scale)
+            for (int j = 0; j < 4; ++j)
+                if (c + j < C) g[j] *= scale[c + j];
+        if (gbias)
+            for (int j = 0; j < 4; ++j)
+                if (c + j < C && g[j] != 0.f) atomicAdd(&s_bias[c + j], g[j]);
+        bf16x4 ps[3];
+        split4(make_float4(g[0], g[1], g[2], g[3]), ps, P);
+        for (int p = 0; p < P; ++p) *(bf16x4 *)(parts + p * pstride + m * Cp + c) = ps[p];
+    }
+    if (gbias) {
+        __syncthreads();
+        for (int c = threadIdx.x; c < C; c += 256)
+            if (s_bias[c] != 0.f) atomicAdd(gbias + c, s_bias[c]);
+    }
+}
+
+// fp32 weights (any strides) -> [P][O][KH][KW][Ip] bf16 parts (i >= I zero).
+// flip=1 mirrors the taps (with O/I swapped through the strides this expresses the
+// data-gradient convolution as a forward convolution).
+__global__ __launch_bounds__(256) void split_weights_kernel(const float *__restrict__ w, int O, int I,
+                                                            int Ip, int KH, int KW, long s_o, long s_i,
+                                                            long s_kh, long s_kw, int flip, int P,
+                                                            __bf16 *__restrict__ out) {
+    const long total = (long)O * KH * KW * Ip;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int i = (int)(idx % Ip);
+        long r = idx / Ip;
+        const int kw = (int)(r % KW); r /= KW;
+        const int kh = (int)(r % KH);
+        const int o = (int)(r / KH);
+        const int skh = flip ? KH - 1 - kh : kh, skw = flip ? KW - 1 - kw : kw;
+        float v = (i < I) ? w[o * s_o + i * s_i + skh * s_kh + skw * s_kw] : 0.f;
+        for (int pp = 0; pp < P; ++pp) {
+            const __bf16 h = (__bf16)v;
+            out[(long)pp * total + idx] = h;
+            v -= (float)h;
+        }
+    }
+}
+
+// ------------------------------------------------------------------- forward
+struct ConvParams {
+    const __bf16 *x;      // [P][Min][Cin] parts (Min = N*H*W)
+    const __bf16 *w;      // [P][Cout][Ktot]
+    const float *scale;   // [Cout] or null (=1)
+    const float *shift;   // [Cout] or null (=0)
+    const float *residual;  // [M][Cout] or null
+    float *y;             // [M][Cout]
+    long x_part_stride, w_part_stride;
+    int N, H, W, Cin, Cout, KH, KW, sh, sw, dh, dw, pt, pl, OH, OW, relu;
+    int M, Ktot, cin_chunks, gm, gn;
+};
+
+template <int P>
+__device__ __forceinline__ void mfma_products(const bf16x8 (&a)[P], const bf16x8 (&b)[P], f32x16 &c) {
+    // smallest terms first
+    if (P == 3) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], c, 0, 0, 0);
+    }
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], c, 0, 0, 0);
+}
+
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    // Blocks are dealt round-robin over the 8 XCDs; give each XCD a contiguous run
+    // of tiles so that the tiles sharing an operand panel share an L2 (bijective).
+    const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, loc = bid / 8;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+}
+
 template <int P>
 __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvParams p) {
     __shared__ __attribute__((aligned(16))) __bf16 sA[P][BM][LDK];
@@ -67,26 +201,19 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvParams p) {
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const int wr = wave >> 1, wc = wave & 1;
-
-    // XCD-aware tile order: blocks are dealt round-robin over the 8 XCDs; give each
-    // XCD a contiguous run of tiles so the Cout-tiles of one pixel block share an L2.
-    const int nblk = p.gm * p.gn;
-    int bid = blockIdx.x;
-    {
-        const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, loc = bid / 8;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-    }
+    const int bid = xcd_remap(blockIdx.x, p.gm * p.gn);
     const int m0 = (bid / p.gn) * BM;
     const int n0 = (bid % p.gn) * BN;
 
-    // ---- per-thread A rows: 4 rows (t>>3)+32*i, channel quad (t&7)*4 ----
-    const int acol = (t & 7) * 4;
-    int a_ih0[4], a_iw0[4];
-    long a_nbase[4];
-    bool a_ok[4];
+    // each thread stages two 16-B chunks per part for A and for B:
+    // row = (t>>2) + 64*i (i = 0,1), chunk = t&3 (8 bf16 each)
+    const int chunk = (t & 3) * 8;
+    int a_ih0[2], a_iw0[2];
+    long a_nbase[2];
+    bool a_ok[2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + (t >> 3) + 32 * i;
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + (t >> 2) + 64 * i;
         a_ok[i] = m < p.M;
         const int mm = a_ok[i] ? m : 0;
         const int n = mm / (p.OH * p.OW);
@@ -96,50 +223,52 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvParams p) {
         a_iw0[i] = ow * p.sw - p.pl;
         a_nbase[i] = (long)n * p.H * p.W;
     }
-    // ---- per-thread B row: cout n0 + (t>>1), k half (t&1)*16 ----
-    const int brow = t >> 1, bhalf = (t & 1) * 16;
-    const bool b_ok = (n0 + brow) < p.Cout;
-    const __bf16 *bptr = p.w + (long)(n0 + brow) * p.Ktot;
+    bool b_ok[2];
+    const __bf16 *bptr[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (t >> 2) + 64 * i;
+        b_ok[i] = (n0 + row) < p.Cout;
+        bptr[i] = p.w + (long)(n0 + (b_ok[i] ? row : 0)) * p.Ktot;
+    }
 
-    float4 ra[4];
-    bf16x8 rb[P][2];
+    bf16x8 ra[P][2], rb[P][2];
     const int nk = p.KH * p.KW * p.cin_chunks;
+    const bf16x8 zero8 = {};
 
     auto load_tile = [&](int ks) {
         const int tap = ks / p.cin_chunks;
         const int ci0 = (ks - tap * p.cin_chunks) * BK;
         const int kh = tap / p.KW, kw = tap - kh * p.KW;
-        const int ci = ci0 + acol;
+        const int ci = ci0 + chunk;
+        const bool cok = ci < p.Cin;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 2; ++i) {
             const int ih = a_ih0[i] + kh * p.dh, iw = a_iw0[i] + kw * p.dw;
-            const bool ok = a_ok[i] && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W && ci < p.Cin;
-            ra[i] = ok ? *(const float4 *)(p.x + ((a_nbase[i] + (long)ih * p.W + iw) * p.Cin + ci))
-                       : make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool ok = a_ok[i] && cok && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+            const long off = (a_nbase[i] + (long)ih * p.W + iw) * p.Cin + ci;
+#pragma unroll
+            for (int pp = 0; pp < P; ++pp)
+                ra[pp][i] = ok ? *(const bf16x8 *)(p.x + pp * p.x_part_stride + off) : zero8;
         }
-        const long koff = (long)tap * p.Cin + ci0 + bhalf;
+        const long koff = (long)tap * p.Cin + ci;
 #pragma unroll
-        for (int pp = 0; pp < P; ++pp)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const bool ok = b_ok && (ci0 + bhalf + 8 * q) < p.Cin;
-                bf16x8 z = {};
-                rb[pp][q] = ok ? *(const bf16x8 *)(bptr + pp * p.w_part_stride + koff + 8 * q) : z;
-            }
+            for (int pp = 0; pp < P; ++pp)
+                rb[pp][i] = (b_ok[i] && cok) ? *(const bf16x8 *)(bptr[i] + pp * p.w_part_stride + koff)
+                                             : zero8;
     };
     auto store_tile = [&]() {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            bf16x4 parts[3];
-            split4(ra[i], parts, P);
-            const int row = (t >> 3) + 32 * i;
+        for (int i = 0; i < 2; ++i) {
+            const int row = (t >> 2) + 64 * i;
 #pragma unroll
-            for (int pp = 0; pp < P; ++pp) *(bf16x4 *)&sA[pp][row][acol] = parts[pp];
+            for (int pp = 0; pp < P; ++pp) {
+                *(bf16x8 *)&sA[pp][row][chunk] = ra[pp][i];
+                *(bf16x8 *)&sB[pp][row][chunk] = rb[pp][i];
+            }
         }
-#pragma unroll
-        for (int pp = 0; pp < P; ++pp)
-#pragma unroll
-            for (int q = 0; q < 2; ++q) *(bf16x8 *)&sB[pp][brow][bhalf + 8 * q] = rb[pp][q];
     };
 
     f32x16 acc[2][2];
@@ -170,18 +299,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvParams p) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    f32x16 c = acc[i][j];
-                    if (P == 3) {
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], c, 0, 0, 0);
-                    }
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], c, 0, 0, 0);
-                    acc[i][j] = c;
-                }
+                for (int j = 0; j < 2; ++j) mfma_products<P>(a[i], b[j], acc[i][j]);
         }
         __syncthreads();
         if (ks + 1 < nk) {
@@ -212,58 +330,217 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvParams p) {
     }
 }
 
-// ---- weight preparation: fp32 weights (any strides) -> [P][O][KH][KW][I] bf16 parts.
-// flip=1 mirrors the taps (used, with O/I swapped through the strides, to express
-// the data-gradient convolution as a forward convolution).
-__global__ __launch_bounds__(256) void split_weights_kernel(const float *__restrict__ w, int O, int I,
-                                                            int KH, int KW, long s_o, long s_i,
-                                                            long s_kh, long s_kw, int flip, int P,
-                                                            __bf16 *__restrict__ out) {
-    const long total = (long)O * KH * KW * I;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-        const int i = (int)(idx % I);
-        long r = idx / I;
-        const int kw = (int)(r % KW); r /= KW;
-        const int kh = (int)(r % KH);
-        const int o = (int)(r / KH);
-        const int skh = flip ? KH - 1 - kh : kh, skw = flip ? KW - 1 - kw : kw;
-        float v = w[o * s_o + i * s_i + skh * s_kh + skw * s_kw];
-        for (int pp = 0; pp < P; ++pp) {
-            const __bf16 h = (__bf16)v;
-            out[(long)pp * total + idx] = h;
-            v -= (float)h;
+// ------------------------------------------------------------ weight gradient
+// gw[co][tap][ci] += sum over a pixel range of gz[pix][co] * x[pix@tap][ci].
+// "TN" GEMM: M = Cout, N = one tap's Cin slice, K = output pixels.  Both operand
+// tiles are staged pixel-major ([k][m], rows of 128 bf16 + 32 pad = 320 B so that
+// the four k-rows of a transposing read sit 16 banks apart) and the MFMA fragments
+// (8 consecutive k per lane) are fetched with two ds_read_b64_tr_b16 each.
+// Split-K over pixel chunks, fp32 atomics into the (callee-zeroed) gradient.
+#define WLD 160  // padded row length in bf16 (320 B)
+
+struct WgradParams {
+    const __bf16 *gz;   // [P][M][Cop]
+    const __bf16 *x;    // [P][Min][Cip]
+    float *gw;          // [Cout][KH][KW][Cin]
+    long gz_part_stride, x_part_stride;
+    int N, H, W, Cin, Cip, Cout, Cop, KH, KW, sh, sw, dh, dw, pt, pl, OH, OW;
+    int M, gm, gn_per_tap, ksplit, pix_per_split;
+};
+
+__device__ __forceinline__ bf16x8 tr_frag(const __bf16 *tile, int k0, int m0, int lane) {
+    // lane 4q+p of a 16-lane group addresses row k0+q, columns m0+4p..+3; the group
+    // receives the 4x16 block transposed: lane i gets column m0+i, rows k0..k0+3.
+    const int li = lane & 15, q = li >> 2, pq = li & 3;
+    typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+    const __bf16 *p0 = tile + (k0 + q) * WLD + m0 + 4 * pq;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)p0);
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(p0 + 4 * WLD));
+    bf16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+}
+
+template <int P>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
+    __shared__ __attribute__((aligned(16))) __bf16 sA[P][BK][WLD];  // [k=pix][m=co]
+    __shared__ __attribute__((aligned(16))) __bf16 sB[P][BK][WLD];  // [k=pix][n=ci]
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int ntile = p.gm * p.gn_per_tap * p.KH * p.KW;
+    int bid = blockIdx.x;
+    const int split = bid / ntile;
+    bid -= split * ntile;
+    const int mt = bid % p.gm;
+    int rest = bid / p.gm;
+    const int nt = rest % p.gn_per_tap;
+    const int tap = rest / p.gn_per_tap;
+    const int kh = tap / p.KW, kw = tap - kh * p.KW;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    // staging: a tile part is 32 rows x 128 bf16 = 32 x 16 chunks of 16 B; thread t
+    // handles rows (t>>4) and (t>>4)+16, chunk t&15
+    const int ch = (t & 15) * 8;
+    const bool a_cok = (m0 + ch) < p.Cop;
+    const bool b_cok = (n0 + ch) < p.Cip;
+    const int pix_begin = split * p.pix_per_split;
+    const int pix_end = min(p.M, pix_begin + p.pix_per_split);
+    const int nk = (pix_end - pix_begin + BK - 1) / BK;
+    const bf16x8 zero8 = {};
+    bf16x8 ra[P][2], rb[P][2];
+
+    auto load_tile = [&](int ks) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int pix = pix_begin + ks * BK + (t >> 4) + 16 * i;
+            const bool pok = pix < pix_end;
+            const long aoff = (long)pix * p.Cop + m0 + ch;
+            // input pixel of this output pixel under the tap
+            const int pp_ = pok ? pix : 0;
+            const int n = pp_ / (p.OH * p.OW);
+            const int rem = pp_ - n * (p.OH * p.OW);
+            const int oh = rem / p.OW, ow = rem - oh * p.OW;
+            const int ih = oh * p.sh - p.pt + kh * p.dh, iw = ow * p.sw - p.pl + kw * p.dw;
+            const bool xok = pok && b_cok && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+            const long boff = (((long)n * p.H + ih) * p.W + iw) * p.Cip + n0 + ch;
+#pragma unroll
+            for (int pp = 0; pp < P; ++pp) {
+                ra[pp][i] = (pok && a_cok) ? *(const bf16x8 *)(p.gz + pp * p.gz_part_stride + aoff) : zero8;
+                rb[pp][i] = xok ? *(const bf16x8 *)(p.x + pp * p.x_part_stride + boff) : zero8;
+            }
         }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = (t >> 4) + 16 * i;
+#pragma unroll
+            for (int pp = 0; pp < P; ++pp) {
+                *(bf16x8 *)&sA[pp][row][ch] = ra[pp][i];
+                *(bf16x8 *)&sB[pp][row][ch] = rb[pp][i];
+            }
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (nk > 0) {
+        load_tile(0);
+        store_tile();
+    }
+    __syncthreads();
+    const int g = lane >> 4;
+    for (int ks = 0; ks < nk; ++ks) {
+        if (ks + 1 < nk) load_tile(ks + 1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 a[2][P], b[2][P];
+            const int k0 = kk * 16 + 8 * (g >> 1);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int pp = 0; pp < P; ++pp) {
+                    a[i][pp] = tr_frag(&sA[pp][0][0], k0, wr * 64 + i * 32 + 16 * (g & 1), lane);
+                    b[i][pp] = tr_frag(&sB[pp][0][0], k0, wc * 64 + i * 32 + 16 * (g & 1), lane);
+                }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) mfma_products<P>(a[i], b[j], acc[i][j]);
+        }
+        __syncthreads();
+        if (ks + 1 < nk) {
+            store_tile();
+            __syncthreads();
+        }
+    }
+    // epilogue: row = co, col = ci; atomics (split-K partial sums)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int ci = n0 + wc * 64 + j * 32 + (lane & 31);
+        if (ci >= p.Cin) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (co >= p.Cout) continue;
+                const float v = acc[i][j][r];
+                if (v != 0.f) atomicAdd(p.gw + ((long)co * p.KH * p.KW + tap) * p.Cin + ci, v);
+            }
     }
 }
 
-extern "C" int sln_conv_split_weights_f32(const float *w, int O, int I, int KH, int KW, long s_o,
-                                          long s_i, long s_kh, long s_kw, int flip, int parts,
+// ---------------------------------------------------------------- C ABI
+static inline int ew_grid(long total) {
+    long g = (total + 255) / 256;
+    if (g > 4096) g = 4096;
+    return (int)(g < 1 ? 1 : g);
+}
+
+extern "C" int sln_conv_split_weights_f32(const float *w, int O, int I, int I_pad, int KH, int KW,
+                                          long s_o, long s_i, long s_kh, long s_kw, int flip, int parts,
                                           uint16_t *out, sln_stream_t stream) {
     sln_enter();
-    if (!w || !out || O < 1 || I < 1 || KH < 1 || KW < 1 || parts < 2 || parts > 3) return SLN_ERR_INVALID_ARG;
-    const long total = (long)O * KH * KW * I;
-    int gx = sln_div_up(total, 256);
-    if (gx > 4096) gx = 4096;
-    hipLaunchKernelGGL(split_weights_kernel, dim3(gx), dim3(256), 0, (hipStream_t)stream, w, O, I, KH, KW,
-                       s_o, s_i, s_kh, s_kw, flip, parts, (__bf16 *)out);
+    if (!w || !out || O < 1 || I < 1 || I_pad < I || KH < 1 || KW < 1 || parts < 2 || parts > 3)
+        return SLN_ERR_INVALID_ARG;
+    const long total = (long)O * KH * KW * I_pad;
+    hipLaunchKernelGGL(split_weights_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, w, O,
+                       I, I_pad, KH, KW, s_o, s_i, s_kh, s_kw, flip, parts, (__bf16 *)out);
     return sln_launch_status();
 }
 
-extern "C" int sln_conv2d_fwd_f32(const float *x, int N, int H, int W, int Cin, const uint16_t *w_parts,
-                                  int parts, int Cout, int KH, int KW, int stride_h, int stride_w,
-                                  int dil_h, int dil_w, int pad_top, int pad_left, int OH, int OW,
-                                  const float *scale, const float *shift, const float *residual,
-                                  int relu, float *y, sln_stream_t stream) {
+extern "C" int sln_act_split_f32(const float *x, int64_t M, int C, int C_pad, int parts, uint16_t *out,
+                                 sln_stream_t stream) {
     sln_enter();
-    if (!x || !w_parts || !y || N < 0 || H < 1 || W < 1 || Cin < 1 || Cout < 1 || KH < 1 || KW < 1 ||
+    if (M < 0 || C < 1 || C_pad < C || (C_pad & 7) || parts < 2 || parts > 3) return SLN_ERR_INVALID_ARG;
+    if (M == 0) return SLN_OK;
+    if (!x || !out) return SLN_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(act_split_kernel, dim3(ew_grid(M * (C_pad / 4))), dim3(256), 0, (hipStream_t)stream,
+                       x, (long)M, C, C_pad, parts, (__bf16 *)out);
+    return sln_launch_status();
+}
+
+extern "C" int sln_conv_grad_prep_f32(const float *gy, const float *y, const float *scale, int64_t M,
+                                      int C, int C_pad, int parts, float *gu, uint16_t *gz_parts,
+                                      float *gbias, sln_stream_t stream) {
+    sln_enter();
+    if (M < 0 || C < 1 || C_pad < C || (C_pad & 7) || parts < 2 || parts > 3) return SLN_ERR_INVALID_ARG;
+    if (!gy || !gz_parts) return SLN_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (gbias && hipMemsetAsync(gbias, 0, sizeof(float) * C, st) != hipSuccess) return SLN_ERR_LAUNCH;
+    if (M == 0) return SLN_OK;
+    int grid = ew_grid(M * (C_pad / 4));
+    if (gbias && grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(grad_prep_kernel, dim3(grid), dim3(256), gbias ? sizeof(float) * C : 0, st, gy, y,
+                       scale, (long)M, C, C_pad, parts, gu, (__bf16 *)gz_parts, gbias);
+    return sln_launch_status();
+}
+
+extern "C" int sln_conv2d_fwd_f32(const uint16_t *x_parts, int N, int H, int W, int Cin,
+                                  const uint16_t *w_parts, int parts, int Cout, int KH, int KW,
+                                  int stride_h, int stride_w, int dil_h, int dil_w, int pad_top,
+                                  int pad_left, int OH, int OW, const float *scale, const float *shift,
+                                  const float *residual, int relu, float *y, sln_stream_t stream) {
+    sln_enter();
+    if (!x_parts || !w_parts || !y || N < 0 || H < 1 || W < 1 || Cin < 1 || Cout < 1 || KH < 1 || KW < 1 ||
         stride_h < 1 || stride_w < 1 || dil_h < 1 || dil_w < 1 || OH < 1 || OW < 1)
         return SLN_ERR_INVALID_ARG;
     if (parts != 2 && parts != 3) return SLN_ERR_INVALID_ARG;
-    if (Cin % 8 != 0) return SLN_ERR_UNSUPPORTED;  // 16-B vector loads along channels
+    if (Cin % 8 != 0) return SLN_ERR_UNSUPPORTED;  // 16-B vector loads along (padded) channels
     if (N == 0) return SLN_OK;
     ConvParams p;
-    p.x = x; p.w = (const __bf16 *)w_parts; p.scale = scale; p.shift = shift; p.residual = residual;
-    p.y = y;
+    p.x = (const __bf16 *)x_parts; p.w = (const __bf16 *)w_parts;
+    p.scale = scale; p.shift = shift; p.residual = residual; p.y = y;
     p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW;
     p.sh = stride_h; p.sw = stride_w; p.dh = dil_h; p.dw = dil_w; p.pt = pad_top; p.pl = pad_left;
     p.OH = OH; p.OW = OW; p.relu = relu;
@@ -271,6 +548,7 @@ extern "C" int sln_conv2d_fwd_f32(const float *x, int N, int H, int W, int Cin, 
     if (M > 2147483647L - BM) return SLN_ERR_UNSUPPORTED;
     p.M = (int)M;
     p.Ktot = KH * KW * Cin;
+    p.x_part_stride = (long)N * H * W * Cin;
     p.w_part_stride = (long)Cout * p.Ktot;
     p.cin_chunks = sln_div_up(Cin, BK);
     p.gm = sln_div_up(M, BM);
@@ -281,5 +559,51 @@ extern "C" int sln_conv2d_fwd_f32(const float *x, int N, int H, int W, int Cin, 
         hipLaunchKernelGGL(conv_fwd_kernel<2>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, p);
     else
         hipLaunchKernelGGL(conv_fwd_kernel<3>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, p);
+    return sln_launch_status();
+}
+
+extern "C" int sln_conv2d_wgrad_f32(const uint16_t *gz_parts, int Cout, int Cout_pad,
+                                    const uint16_t *x_parts, int N, int H, int W, int Cin, int Cin_pad,
+                                    int parts, int KH, int KW, int stride_h, int stride_w, int dil_h,
+                                    int dil_w, int pad_top, int pad_left, int OH, int OW, float *gw,
+                                    sln_stream_t stream) {
+    sln_enter();
+    if (!gz_parts || !x_parts || !gw || N < 0 || H < 1 || W < 1 || Cin < 1 || Cout < 1 || KH < 1 || KW < 1 ||
+        OH < 1 || OW < 1 || Cin_pad < Cin || Cout_pad < Cout || (Cin_pad & 7) || (Cout_pad & 7))
+        return SLN_ERR_INVALID_ARG;
+    if (parts != 2 && parts != 3) return SLN_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(gw, 0, sizeof(float) * (size_t)Cout * KH * KW * Cin, st) != hipSuccess)
+        return SLN_ERR_LAUNCH;
+    if (N == 0) return SLN_OK;
+    WgradParams p;
+    p.gz = (const __bf16 *)gz_parts; p.x = (const __bf16 *)x_parts; p.gw = gw;
+    p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cip = Cin_pad; p.Cout = Cout; p.Cop = Cout_pad;
+    p.KH = KH; p.KW = KW; p.sh = stride_h; p.sw = stride_w; p.dh = dil_h; p.dw = dil_w;
+    p.pt = pad_top; p.pl = pad_left; p.OH = OH; p.OW = OW;
+    const long M = (long)N * OH * OW;
+    if (M > 2147483647L - BK) return SLN_ERR_UNSUPPORTED;
+    p.M = (int)M;
+    p.gz_part_stride = M * Cout_pad;
+    p.x_part_stride = (long)N * H * W * Cin_pad;
+    p.gm = sln_div_up(Cout, BM);
+    p.gn_per_tap = sln_div_up(Cin, BN);
+    const long ntile = (long)p.gm * p.gn_per_tap * KH * KW;
+    // split the pixel range so that ~8 blocks per CU are in flight, >= 2048 pixels each
+    long ks = (256L * 8 + ntile - 1) / ntile;
+    const long max_ks = (M + 2047) / 2048;
+    if (ks > max_ks) ks = max_ks;
+    if (ks < 1) ks = 1;
+    long pps = (M + ks - 1) / ks;
+    pps = ((pps + BK - 1) / BK) * BK;
+    ks = (M + pps - 1) / pps;
+    p.ksplit = (int)ks;
+    p.pix_per_split = (int)pps;
+    const long nblk = ntile * ks;
+    if (nblk > 2147483647L) return SLN_ERR_UNSUPPORTED;
+    if (parts == 2)
+        hipLaunchKernelGGL(conv_wgrad_kernel<2>, dim3((unsigned)nblk), dim3(256), 0, st, p);
+    else
+        hipLaunchKernelGGL(conv_wgrad_kernel<3>, dim3((unsigned)nblk), dim3(256), 0, st, p);
     return sln_launch_status();
 }

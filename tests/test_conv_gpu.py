@@ -21,6 +21,9 @@ CASES = [
     (64, 64, 3, 2, 1, (0, 1, 0, 1), 32, 32, 2),      # asymmetric SAME padding
     (256, 1024, 7, 1, 1, (0, 0, 0, 0), 7, 7, 5),     # classifier "FC" conv
     (8, 8, 3, 1, 1, (1, 1, 1, 1), 5, 5, 1),
+    (3, 64, 7, 2, 1, (3, 3, 3, 3), 64, 64, 2),        # stem: Cin padded 3 -> 8
+    (512, 6, 1, 1, 1, (0, 0, 0, 0), 20, 20, 2),       # RPN class head: Cout 6
+    (439, 256, 3, 1, 1, (1, 1, 1, 1), 16, 16, 2),     # mask conv1: ragged Cin
 ]
 
 
@@ -67,7 +70,7 @@ def test_conv_forward_matches_fp64_reference(case, parts):
         conv_hip.PARTS = old
 
 
-@pytest.mark.parametrize("case", [CASES[1], CASES[2], CASES[3], CASES[5], CASES[7]])
+@pytest.mark.parametrize("case", [CASES[1], CASES[2], CASES[3], CASES[5], CASES[8], CASES[11], CASES[12]])
 def test_conv_backward_matches_autograd_of_unfused_ops(case):
     from sln_amodal_amd import conv_hip
     Cin, Cout, k, stride, dil, pads, H, W, N = case
