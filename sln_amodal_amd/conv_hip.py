@@ -11,7 +11,10 @@ import torch
 
 from . import _lib, ops
 
-PARTS = 3          # 3 = fp32-class accuracy (6 MFMA products); 2 = ~4e-6 per layer (3 products)
+import os
+
+# 3 = fp32-class accuracy (6 MFMA products); 2 = ~4e-6 per layer (3 products)
+PARTS = int(os.environ.get("SLN_CONV_PARTS", "3"))
 class _NoCache(dict):
     pass
 
@@ -90,13 +93,35 @@ def act_parts(x, parts=None):
     return out
 
 
+# bench.py sets this to a list to collect (start_event, end_event, flops, kernel) per
+# launch on the launch stream (torch's current stream) -- the live roofline numbers.
+PROFILE = None
+
+
+def _prof_begin():
+    if PROFILE is None:
+        return None
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    return e
+
+
+def _prof_end(e0, flops, name):
+    if e0 is not None:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        PROFILE.append((e0, e1, flops, name))
+
+
 def _fwd(xparts, N, H, W, wparts, Cout, KH, KW, stride, dil, pt, pl, OH, OW, scale, shift, residual,
-         relu):
+         relu, cin=None):
     y = torch.empty((N, OH, OW, Cout), dtype=torch.float32, device=xparts.device).permute(0, 3, 1, 2)
+    e0 = _prof_begin()
     _lib.check(_lib.lib().sln_conv2d_fwd_f32(
         ops._ptr(xparts), N, H, W, xparts.shape[2], ops._ptr(wparts), wparts.shape[0], Cout, KH, KW,
         stride[0], stride[1], dil[0], dil[1], pt, pl, OH, OW, ops._ptr(scale), ops._ptr(shift),
         ops._ptr(residual), 1 if relu else 0, ops._ptr(y), ops._stream()), "sln_conv2d_fwd_f32")
+    _prof_end(e0, 2.0 * N * OH * OW * Cout * KH * KW * (cin or wparts.shape[4]), "conv_fwd_kernel<%d>" % wparts.shape[0])
     return y
 
 
@@ -136,7 +161,7 @@ class _ConvFn(torch.autograd.Function):
         res = _nhwc(residual.detach()) if residual is not None else None
         xp = act_parts(x, parts)
         y = _fwd(xp, N, H, W, _split_weights(weight, parts=parts), Co, KH, KW, stride, dil, pt, pl,
-                 OH, OW, scale, shift, res, relu)
+                 OH, OW, scale, shift, res, relu, cin=Ci)
         need_w = ctx.needs_input_grad[1]
         ctx.save_for_backward(xp if need_w else None, weight, scale, y if relu else None)
         ctx.cfg = (stride, dil, pads, relu, bias is not None, residual is not None, (N, Ci, H, W),
@@ -160,21 +185,23 @@ class _ConvFn(torch.autograd.Function):
             wt = _split_weights(weight, flip_swap=True, parts=parts)
             if stride == (1, 1):
                 gx = _fwd(gz, N, OH, OW, wt, Ci, KH, KW, (1, 1), dil, dil[0] * (KH - 1) - pt,
-                          dil[1] * (KW - 1) - pl, H, W, None, None, None, False)
+                          dil[1] * (KW - 1) - pl, H, W, None, None, None, False, cin=Co)
             elif KH == 1 and KW == 1 and pads == (0, 0, 0, 0):
                 # strided 1x1: the gradient lives on the stride lattice, zero elsewhere
                 small = _fwd(gz, N, OH, OW, wt, Ci, 1, 1, (1, 1), (1, 1), 0, 0, OH, OW, None, None,
-                             None, False)
+                             None, False, cin=Co)
                 gx = torch.zeros((N, H, W, Ci), dtype=torch.float32, device=gy.device).permute(0, 3, 1, 2)
                 gx[:, :, ::stride[0], ::stride[1]] = small
             else:
                 raise NotImplementedError("data gradient of a strided %dx%d conv" % (KH, KW))
         if need_w:
             gw_t = torch.empty((Co, KH, KW, Ci), dtype=torch.float32, device=gy.device)
+            e0 = _prof_begin()
             _lib.check(_lib.lib().sln_conv2d_wgrad_f32(
                 ops._ptr(gz), Co, gz.shape[2], ops._ptr(xp), N, H, W, Ci, xp.shape[2], parts, KH, KW,
                 stride[0], stride[1], dil[0], dil[1], pt, pl, OH, OW, ops._ptr(gw_t), ops._stream()),
                 "sln_conv2d_wgrad_f32")
+            _prof_end(e0, 2.0 * N * OH * OW * Co * KH * KW * Ci, "conv_wgrad_kernel<%d>" % parts)
             gw = gw_t.permute(0, 3, 1, 2)  # logical [Co,Ci,KH,KW]
         return gx, gw, g_bias, None, None, g_res, None, None, None, None
 

@@ -237,8 +237,12 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvParams p) {
     const bf16x8 zero8 = {};
 
     auto load_tile = [&](int ks) {
-        const int tap = ks / p.cin_chunks;
-        const int ci0 = (ks - tap * p.cin_chunks) * BK;
+        // channel-chunk major, tap minor: the KH*KW shifted windows of one 32-channel
+        // slab are read in consecutive k-steps, so the re-reads hit L1/L2
+        const int ntap = p.KH * p.KW;
+        const int cc = ks / ntap;
+        const int tap = ks - cc * ntap;
+        const int ci0 = cc * BK;
         const int kh = tap / p.KW, kw = tap - kh * p.KW;
         const int ci = ci0 + chunk;
         const bool cok = ci < p.Cin;
