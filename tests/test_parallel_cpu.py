@@ -1,0 +1,70 @@
+"""Multi-process data-parallel path on CPU: world_size 2, gloo backend.  The
+bucketed gradient all-reducer must leave every rank with the mean gradient and
+identical parameters after an SGD step."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, hooks, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from sln_amodal_amd import parallel
+    r, _, w = parallel.init_distributed(backend="gloo")
+    assert (r, w) == (rank, world)
+    torch.manual_seed(100 + rank)                       # ranks start from DIFFERENT weights
+    model = torch.nn.Sequential(torch.nn.Linear(7, 13), torch.nn.ReLU(), torch.nn.Linear(13, 3),
+                                torch.nn.Linear(3, 5))
+    for p in model[3].parameters():                     # an unused, trainable layer (no grad arrives)
+        p.requires_grad_(True)
+    parallel.broadcast_parameters(model)
+    params = [p for p in model.parameters() if p.requires_grad]
+    red = parallel.GradientAllReducer(params, bucket_bytes=256)   # several buckets
+    if hooks:
+        red.attach()
+    opt = torch.optim.SGD(params, lr=0.1)
+    g = torch.Generator().manual_seed(rank)             # disjoint data shards
+    for step in range(3):
+        x = torch.randn(4, 7, generator=g)
+        opt.zero_grad(set_to_none=True)
+        model[2](model[1](model[0](x))).square().mean().backward()
+        local = [p.grad.clone() if p.grad is not None else torch.zeros_like(p) for p in params]
+        red.finish() if hooks else red(params)
+        gathered = [torch.zeros_like(torch.cat([l.reshape(-1) for l in local])) for _ in range(world)]
+        dist.all_gather(gathered, torch.cat([l.reshape(-1) for l in local]))
+        mean = sum(gathered) / world
+        got = torch.cat([p.grad.reshape(-1) for p in params])
+        assert torch.allclose(got, mean, atol=1e-7), (rank, step)
+        opt.step()
+    flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    all_flat = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(all_flat, flat)
+    assert torch.equal(all_flat[0], all_flat[1])
+    dist.destroy_process_group()
+    out.put(rank)
+
+
+@pytest.mark.parametrize("hooks", [True, False])
+def test_gradient_allreduce_world2_gloo(hooks):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, hooks, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert sorted(q.get(timeout=5) for _ in range(2)) == [0, 1]

@@ -273,5 +273,73 @@ def main():
          g_pmask=pmask.grad.numpy())
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--modules" not in sys.argv:
     main()
+
+
+def module_goldens():
+    """Module-level goldens: the reference's nn.Modules (CPU, torch 2.10) with the
+    name-keyed deterministic initialisation of tests/_util.key_init_."""
+    import json
+    ref_modals, ref_F = ref_harness.install()
+    from tests._util import key_init_
+    import config as ref_config
+    import model as ref_model
+    import modal.deeplabv2 as ref_dl
+    torch.manual_seed(0)
+    # ---- FPN (ResNet-50) + RPN on a 64x64 image ----
+    resnet = ref_modals.ResNet("resnet50", stage5=True)
+    fpn = ref_modals.FPN(*resnet.stages(), out_channels=256).eval()
+    rpn = ref_modals.RPN(3, 1, 256).eval()
+    key_init_(fpn); key_init_(rpn)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 3, 64, 64, generator=g)
+    with torch.no_grad():
+        p = fpn(x)
+        r = rpn(p[0])
+    print("fpn out abs mean", [float(t.abs().mean()) for t in p], "rpn", float(r[0].abs().mean()))
+    save("module_fpn_rpn", x=x.numpy(), p2=p[0].numpy(), p3=p[1].numpy(), p5=p[3].numpy(),
+         p6=p[4].numpy(), rpn_logits=r[0].numpy(), rpn_probs=r[1].numpy(), rpn_bbox=r[2].numpy())
+    # ---- heads on fixed maps / rois (native ops: oracle) ----
+    C = 256
+    maps = [torch.randn(1, C, s, s, generator=g) * 0.5 for s in (32, 16, 8, 4)]
+    R = 12
+    ctr = torch.rand(R, 2, generator=g) * 0.6 + 0.2
+    size = torch.exp(torch.rand(R, 2, generator=g) * 3.0 - 3.2)
+    rois = torch.cat([ctr - size / 2, ctr + size / 2], 1).clamp(0, 1).unsqueeze(0)
+    cls = ref_modals.Classifier(256, 7, (128, 128, 3), 2).eval()
+    msk = ref_modals.Mask(256, 16, (128, 128, 3), 2).eval()
+    msk.conv1 = torch.nn.Conv2d(439, 256, kernel_size=3, stride=1)
+    key_init_(cls); key_init_(msk)
+    glm_feat = torch.randn(R, 183, 16, 16, generator=g) * 0.3
+    with torch.no_grad():
+        c_out = cls([m.clone() for m in maps], rois.clone())
+        m_out, m_feat = msk([m.clone() for m in maps], rois.clone(), glm_feat)
+    save("module_heads", native=np.array("oracle"), rois=rois.numpy(), glm_feat=glm_feat.numpy(),
+         cls_logits=c_out[0].numpy(), cls_probs=c_out[1].numpy(), cls_bbox=c_out[2].numpy(),
+         mask_logits=m_out.numpy(), **{"map%d" % i: m.numpy() for i, m in enumerate(maps)})
+    # ---- DeepLab-v2 MSC (ResNet-101) on a 97x97 image ----
+    glm = ref_dl.DeepLabV2_ResNet101_MSC(182).eval()
+    key_init_(glm)
+    xg = torch.randn(1, 3, 97, 97, generator=g)
+    with torch.no_grad():
+        lg = glm(xg)
+    print("glm logits", tuple(lg.shape), float(lg.abs().mean()))
+    save("module_glm", x=xg.numpy(), logits=lg.numpy())
+    # ---- state-dict keys and shapes of the model after the amodal head surgery ----
+    cfg = small_config(ref_config, 128, num_classes=81)
+    m = ref_model.MaskRCNN(cfg, tempfile.mkdtemp())
+    cfg.NUM_CLASSES = 2
+    m.mask.conv1 = torch.nn.Conv2d(439, 256, kernel_size=3, stride=1)
+    m.mask.conv5 = torch.nn.Conv2d(256, 2, kernel_size=1, stride=1)
+    m.classifier.linear_class = torch.nn.Linear(1024, 2)
+    m.classifier.linear_bbox = torch.nn.Linear(1024, 8)
+    m.GLM_modual = glm
+    keys = {k: list(v.shape) for k, v in m.state_dict().items()}
+    with open(os.path.join(OUT, "state_dict_keys.json"), "w") as f:
+        json.dump(keys, f)
+    print("state dict keys", len(keys))
+
+
+if __name__ == "__main__" and "--modules" in sys.argv:
+    module_goldens()
