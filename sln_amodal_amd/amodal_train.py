@@ -1,0 +1,179 @@
+"""CLI entry point with the reference's surface (amodal_train.py:507-675):
+
+    python amodal_train.py train    --dataset DIR|--synthetic --model PATH --logs DIR --limit N
+    python amodal_train.py evaluate --dataset DIR|--synthetic --model PATH --limit N
+
+`Amodalfig` (amodal_train.py:38-54) and the head surgery (606-614) are kept; the
+three training stages (642-663: heads x2, 4+ x3, all @ lr/10) are kept.  Dataset I/O
+is reduced to what the hot path consumes: an image + the uint64 'layer' label from
+the reference's `<name>.npz` files (`np.load(path)['layer']`, amodal_train.py:238),
+or synthetic COCOA-shape batches generated on the device.
+"""
+import argparse
+import glob
+import os
+
+import numpy as np
+import torch
+
+from . import parallel, synthetic
+from .config import Config
+from .model import MaskRCNN
+from .modal.Functions import build_rpn_targets, extract_bboxes_from_labels
+
+COCO_MODEL_PATH = "./checkpoints/mask_rcnn_coco.pth"
+GLM_MODEL_PATH = "./checkpoints/deeplabv2.pth"
+DEFAULT_LOGS_DIR = os.path.join(os.getcwd(), "logs")
+
+
+class Amodalfig(Config):
+    NAME = "coco"
+    IMAGES_PER_GPU = 16
+    BATCH_SIZE = 16
+    NUM_CLASSES = 1 + 80  # replaced by 1 + 1 in apply_amodal_heads(), as in the reference
+
+
+class InferenceConfig(Amodalfig):
+    GPU_COUNT = 1
+    IMAGES_PER_GPU = 1
+    BATCH_SIZE = 1
+    DETECTION_MIN_CONFIDENCE = 0
+
+
+class AmodalDataset(object):
+    """Iterable of training batches (dicts, see MaskRCNN.train_step)."""
+
+    def __init__(self, config, model, root=None, limit=-1, seed=1234, device="cuda", max_objects=8):
+        self.config, self.model, self.device, self.seed = config, model, device, seed
+        self.max_objects = max_objects
+        self.files = []
+        if root:
+            self.files = sorted(glob.glob(os.path.join(root, "**", "*.npz"), recursive=True))
+            if limit and limit > 0:
+                self.files = self.files[:limit]
+
+    def _load_real(self, paths):
+        from PIL import Image
+        dim = self.config.IMAGE_MAX_DIM
+        imgs, labs = [], []
+        for p in paths:
+            layer = np.load(p)["layer"].astype(np.uint64)
+            stem = p[:-4]
+            img_path = next((stem + e for e in (".jpg", ".png", ".jpeg") if os.path.exists(stem + e)), None)
+            img = np.asarray(Image.open(img_path).convert("RGB")) if img_path else \
+                np.zeros(layer.shape + (3,), np.uint8)
+            t = torch.from_numpy(img).permute(2, 0, 1)[None].float()
+            imgs.append(torch.nn.functional.interpolate(t, size=(dim, dim), mode="bilinear",
+                                                        align_corners=False)[0])
+            # nearest resize of the label (utils.py:358-362 resize_layer, order 0)
+            ys = (np.arange(dim) * layer.shape[0] / dim).astype(np.int64)
+            xs = (np.arange(dim) * layer.shape[1] / dim).astype(np.int64)
+            labs.append(torch.from_numpy(layer[ys][:, xs].view(np.int64)))
+        mean = torch.tensor(np.asarray(self.config.MEAN_PIXEL), dtype=torch.float32).view(1, 3, 1, 1)
+        images = (torch.stack(imgs) - mean).to(self.device).contiguous(memory_format=torch.channels_last)
+        labels = torch.stack(labs).to(self.device)
+        boxes = extract_bboxes_from_labels(labels, self.max_objects).float()
+        present = (boxes[..., 2] > boxes[..., 0]) & (boxes[..., 3] > boxes[..., 1])
+        ids = present.to(torch.int32)
+        match, bbox = build_rpn_targets((dim, dim, 3), self.model.anchors_f64, ids, boxes, self.config)
+        return {"images": images, "image_metas": None, "gt_class_ids": ids, "gt_boxes": boxes,
+                "gt_layer": labels, "rpn_match": match.unsqueeze(2), "rpn_bbox": bbox}
+
+    def __iter__(self):
+        B, dim, step = self.config.BATCH_SIZE, self.config.IMAGE_MAX_DIM, 0
+        while True:
+            if self.files:
+                idx = [(step * B + i) % len(self.files) for i in range(B)]
+                yield self._load_real([self.files[i] for i in idx])
+            else:
+                yield synthetic.make_batch(self.config, B, dim, dim, n_obj=self.max_objects,
+                                           seed=self.seed + step, device=self.device,
+                                           anchors_f64=self.model.anchors_f64)
+            step += 1
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description="Train / evaluate SLN-Amodal on MI355X.")
+    ap.add_argument("command", metavar="<command>", help="'train' or 'evaluate'")
+    ap.add_argument("--dataset", default=None, metavar="/path/to/dataset/")
+    ap.add_argument("--synthetic", action="store_true", help="synthetic COCOA-shape batches")
+    ap.add_argument("--model", default="none", metavar="/path/to/weights.pth | last | none")
+    ap.add_argument("--logs", default=DEFAULT_LOGS_DIR, metavar="/path/to/logs/")
+    ap.add_argument("--limit", default=500, type=int)
+    ap.add_argument("--data_type", default="COCOA")
+    ap.add_argument("--arch", default="resnet101", choices=["resnet50", "resnet101"])
+    ap.add_argument("--image-dim", default=1024, type=int)
+    ap.add_argument("--batch", default=None, type=int, help="images per GPU")
+    ap.add_argument("--steps-per-epoch", default=None, type=int)
+    args = ap.parse_args(argv)
+
+    rank, local, world = parallel.init_distributed()
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(local)
+
+    base = Amodalfig if args.command == "train" else InferenceConfig
+
+    class RunConfig(base):
+        IMAGE_MAX_DIM = args.image_dim
+        IMAGE_MIN_DIM = args.image_dim
+        ARCHITECTURE = args.arch
+
+    config = RunConfig()
+    if args.batch:
+        config.BATCH_SIZE = args.batch
+    if args.steps_per_epoch:
+        config.STEPS_PER_EPOCH = args.steps_per_epoch
+    if rank == 0:
+        config.display()
+    torch.manual_seed(0)
+    model = MaskRCNN(config=config, model_dir=args.logs)
+    model_path = args.model
+    if model_path.lower() == "last":
+        model_path = model.find_last()[1]
+    if args.command == "train" and model_path and model_path.lower() != "none":
+        model.load_weights(model_path)              # before the head surgery, like the reference
+    model.apply_amodal_heads()
+    if os.path.exists(GLM_MODEL_PATH):
+        model.GLM_modual.load_state_dict(torch.load(GLM_MODEL_PATH, map_location="cpu"))
+    if args.command != "train" and model_path and model_path.lower() != "none":
+        model.load_weights(model_path)
+    model.to(device)
+    for p in model.GLM_modual.parameters():
+        p.requires_grad = False
+    parallel.broadcast_parameters(model)
+    data = AmodalDataset(config, model, None if args.synthetic else args.dataset, args.limit,
+                         seed=1234 + rank, device=device)
+
+    if args.command == "train":
+        if not os.path.exists(str(model_path)):     # no checkpoint: emulate pretrained statistics
+            first = next(iter(data))
+            synthetic.calibrate_batchnorm(model, first["images"][:4])
+            synthetic.calibrate_glm(model, first["images"][:2])
+        params = lambda: [p for p in model.parameters() if p.requires_grad]
+        for lr, epochs, layers in ((config.LEARNING_RATE, 2, "heads"), (config.LEARNING_RATE, 3, "4+"),
+                                   (config.LEARNING_RATE / 10, 1, "all")):
+            model.set_trainable(".*", exclusive_off=False)   # the reference can only switch off
+            for p in model.GLM_modual.parameters():
+                p.requires_grad = False
+            from .model import LAYER_REGEX
+            model.set_trainable(LAYER_REGEX[layers])
+            reducer = parallel.GradientAllReducer(params()).attach()
+            model.train_model(data, None, learning_rate=lr, epochs=epochs, layers=layers,
+                              grad_sync=(lambda ps: reducer.finish()) if world > 1 else None)
+    elif args.command == "evaluate":
+        n = 0
+        for batch in data:
+            img = (batch["images"][0].permute(1, 2, 0).cpu().numpy() + config.MEAN_PIXEL).clip(0, 255)
+            res = model.detect([img.astype(np.uint8)])
+            k = res[0]["rois"].shape[0] if res else 0
+            if rank == 0:
+                print("image %d: %d detections" % (n, k))
+            n += 1
+            if n >= max(1, min(args.limit, 2 if args.synthetic else args.limit)):
+                break
+    else:
+        raise SystemExit("'{}' is not recognized. Use 'train' or 'evaluate'".format(args.command))
+
+
+if __name__ == "__main__":
+    main()
