@@ -51,7 +51,7 @@ def dominant_kernel_roofline(prof, elapsed, parts):
         return {"bound": "mfma", "achieved": None, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": None, "traffic": None}
     by = {}
-    for e0, e1, fl, name in prof:
+    for e0, e1, fl, name, _shape in prof:
         d = by.setdefault(name, [0.0, 0.0, 0])
         d[0] += e0.elapsed_time(e1) * 1e-3
         d[1] += fl
@@ -173,6 +173,15 @@ def main():
                               "algorithmic_gflop_per_image": round(gflop, 1)},
         }
         out["roofline"] = dominant_kernel_roofline(prof, elapsed, conv_hip.PARTS)
+        if os.environ.get("SLN_PROFILE_SHAPES"):
+            agg = {}
+            for e0, e1, fl, name, shape in prof:
+                d = agg.setdefault(shape, [0.0, 0.0, 0])
+                d[0] += e0.elapsed_time(e1); d[1] += fl; d[2] += 1
+            tot = sum(v[0] for v in agg.values())
+            for shape, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:45]:
+                print("%6.2f%% %8.2f ms/step n=%4d %6.1f TF  %s" % (100 * v[0] / tot, v[0] / args.steps,
+                      v[2] // args.steps, v[1] / v[0] / 1e9, shape), file=sys.stderr)
         try:
             from tools import kernel_roofline
             out["roofline_kernels"] = kernel_roofline.measure(dev)
