@@ -177,7 +177,9 @@ int sln_pyramid_crop_bwd_f32(const float *grads, int g_cstride, int g_coffset, c
  * sln_conv2d_fwd_f32          y [N,OH,OW,Cout] fp32 = relu?(conv(x,w)*scale[c] +
  *     shift[c] + residual); x_parts [parts][N*H*W][Cin] (Cin % 8 == 0), w_parts
  *     [parts][Cout][KH][KW][Cin].  Taps outside the image read zero (pad_top/left
- *     may differ from bottom/right: TensorFlow 'SAME' padding).
+ *     may differ from bottom/right: TensorFlow 'SAME' padding).  y_parts (optional):
+ *     the output's own parts [parts][N*OH*OW][Cout_pad], written by the epilogue
+ *     (fused sln_act_split_f32 for the next layer); pad channels are NOT written.
  * sln_conv2d_wgrad_f32        gw [Cout][KH][KW][Cin] fp32 (zeroed by the callee) =
  *     sum over output pixels of gz[pix][co] * x[pix @ tap][ci]; split-K over pixel
  *     ranges with fp32 atomics (summation order not deterministic).
@@ -194,7 +196,7 @@ int sln_conv2d_fwd_f32(const uint16_t *x_parts, int N, int H, int W, int Cin,
                        const uint16_t *w_parts, int parts, int Cout, int KH, int KW, int stride_h,
                        int stride_w, int dil_h, int dil_w, int pad_top, int pad_left, int OH, int OW,
                        const float *scale, const float *shift, const float *residual, int relu,
-                       float *y, sln_stream_t stream);
+                       float *y, uint16_t *y_parts, sln_stream_t stream);
 int sln_conv2d_wgrad_f32(const uint16_t *gz_parts, int Cout, int Cout_pad, const uint16_t *x_parts,
                          int N, int H, int W, int Cin, int Cin_pad, int parts, int KH, int KW,
                          int stride_h, int stride_w, int dil_h, int dil_w, int pad_top, int pad_left,

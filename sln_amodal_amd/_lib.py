@@ -36,7 +36,7 @@ SIGNATURES = {
     "sln_act_split_f32": (_i, [_p, C.c_int64, _i, _i, _i, _p, _p]),
     "sln_conv_grad_prep_f32": (_i, [_p, _p, _p, C.c_int64, _i, _i, _i, _p, _p, _p, _p]),
     "sln_conv2d_fwd_f32": (_i, [_p, _i, _i, _i, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
-                                _i, _p, _p, _p, _i, _p, _p]),
+                                _i, _p, _p, _p, _i, _p, _p, _p]),
     "sln_conv2d_wgrad_f32": (_i, [_p, _i, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
                                   _i, _i, _i, _i, _p, _p]),
 }

@@ -19,6 +19,7 @@ class _NoCache(dict):
     pass
 
 
+FUSE_OUTPUT_SPLIT = True   # conv epilogue writes the output's parts (skips the next act_split)
 _cache = _NoCache()   # kept for tools that call _cache.clear(); caches live on the tensors
 
 
@@ -116,13 +117,20 @@ def _prof_end(e0, flops, name, shape=""):
 
 
 def _fwd(xparts, N, H, W, wparts, Cout, KH, KW, stride, dil, pt, pl, OH, OW, scale, shift, residual,
-         relu, cin=None):
+         relu, cin=None, out_parts=False):
     y = torch.empty((N, OH, OW, Cout), dtype=torch.float32, device=xparts.device).permute(0, 3, 1, 2)
+    yp = None
+    if out_parts:   # the epilogue also emits the output's bf16 parts (next layer's operand)
+        alloc = torch.empty if Cout % 8 == 0 else torch.zeros   # pad channels must be zero
+        yp = alloc((wparts.shape[0], N * OH * OW, _pad8(Cout)), dtype=torch.bfloat16, device=xparts.device)
     e0 = _prof_begin()
     _lib.check(_lib.lib().sln_conv2d_fwd_f32(
         ops._ptr(xparts), N, H, W, xparts.shape[2], ops._ptr(wparts), wparts.shape[0], Cout, KH, KW,
         stride[0], stride[1], dil[0], dil[1], pt, pl, OH, OW, ops._ptr(scale), ops._ptr(shift),
-        ops._ptr(residual), 1 if relu else 0, ops._ptr(y), ops._stream()), "sln_conv2d_fwd_f32")
+        ops._ptr(residual), 1 if relu else 0, ops._ptr(y), ops._ptr(yp), ops._stream()),
+        "sln_conv2d_fwd_f32")
+    if yp is not None:
+        y._sln_parts = ((y._version, wparts.shape[0]), yp)
     _prof_end(e0, 2.0 * N * OH * OW * Cout * KH * KW * (cin or wparts.shape[4]), "conv_fwd_kernel<%d>" % wparts.shape[0],
               "fwd N%d %dx%d C%d->%d k%d s%d d%d" % (N, H, W, cin or wparts.shape[4], Cout, KH, stride[0], dil[0]))
     return y
@@ -164,7 +172,7 @@ class _ConvFn(torch.autograd.Function):
         res = _nhwc(residual.detach()) if residual is not None else None
         xp = act_parts(x, parts)
         y = _fwd(xp, N, H, W, _split_weights(weight, parts=parts), Co, KH, KW, stride, dil, pt, pl,
-                 OH, OW, scale, shift, res, relu, cin=Ci)
+                 OH, OW, scale, shift, res, relu, cin=Ci, out_parts=FUSE_OUTPUT_SPLIT)
         need_w = ctx.needs_input_grad[1]
         ctx.save_for_backward(xp if need_w else None, weight, scale, y if relu else None)
         ctx.cfg = (stride, dil, pads, relu, bias is not None, residual is not None, (N, Ci, H, W),

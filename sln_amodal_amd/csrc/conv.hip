@@ -168,7 +168,9 @@ struct ConvParams {
     const float *shift;   // [Cout] or null (=0)
     const float *residual;  // [M][Cout] or null
     float *y;             // [M][Cout]
-    long x_part_stride, w_part_stride;
+    __bf16 *yparts;       // [P][M][Cop] or null: the output's own bf16 parts (fused act_split)
+    long x_part_stride, w_part_stride, y_part_stride;
+    int Cop;
     int N, H, W, Cin, Cout, KH, KW, sh, sw, dh, dw, pt, pl, OH, OW, relu;
     int M, Ktot, cin_chunks, gm, gn;
 };
@@ -195,8 +197,12 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 
 template <int P>
 __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvParams p) {
-    __shared__ __attribute__((aligned(16))) __bf16 sA[P][BM][LDK];
-    __shared__ __attribute__((aligned(16))) __bf16 sB[P][BN][LDK];
+    // one LDS region: operand tiles during the k-loop, fp32 staging tile in the epilogue
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * P * BM * LDK * 2];
+    typedef __bf16 (*tile_t)[BM][LDK];
+    tile_t sA = (tile_t)smem;
+    tile_t sB = (tile_t)(smem + P * BM * LDK * 2);
+    static_assert(2 * P * BM * LDK * 2 >= 64 * 132 * 4, "staging tile must fit");
 
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
@@ -312,25 +318,74 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvParams p) {
         }
     }
 
-    // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
+    // ---- epilogue through LDS: coalesced 16-B stores of y (and of its bf16 parts) ----
+    // C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).  The 128x128
+    // fp32 tile is staged in two 64-row halves ([64][132] floats, reusing the operand
+    // tiles), read back row-major: thread t owns columns 4*(t&31)..+3 of rows
+    // (t>>5) + 8q.  Per element: v = acc*scale[c] + shift[c] (+ residual) (ReLU).
+    float(*stage)[132] = (float(*)[132])smem;
+    const bool vec_ok = (p.Cout & 3) == 0;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int c = n0 + wc * 64 + j * 32 + (lane & 31);
-        if (c >= p.Cout) continue;
-        const float sc = p.scale ? p.scale[c] : 1.0f;
-        const float sf = p.shift ? p.shift[c] : 0.0f;
+    for (int h = 0; h < 2; ++h) {
+        if (wr == h) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        stage[i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)][wc * 64 + j * 32 + (lane & 31)] =
+                            acc[i][j][r];
+        }
+        __syncthreads();
+        const int c = n0 + 4 * (t & 31);
+        if (c < p.Cout) {
+            float sc[4] = {1.f, 1.f, 1.f, 1.f}, sf[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (c + e < p.Cout) {
+                    if (p.scale) sc[e] = p.scale[c + e];
+                    if (p.shift) sf[e] = p.shift[c + e];
+                }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int row = (t >> 5) + 8 * q;
+                const int m = m0 + h * 64 + row;
                 if (m >= p.M) continue;
-                float v = acc[i][j][r] * sc + sf;
+                const float4 a4 = *(const float4 *)&stage[row][4 * (t & 31)];
+                float v[4] = {a4.x * sc[0] + sf[0], a4.y * sc[1] + sf[1], a4.z * sc[2] + sf[2],
+                              a4.w * sc[3] + sf[3]};
                 const long o = (long)m * p.Cout + c;
-                if (p.residual) v += p.residual[o];
-                if (p.relu) v = fmaxf(v, 0.0f);
-                p.y[o] = v;
+                if (vec_ok) {
+                    if (p.residual) {
+                        const float4 r4 = *(const float4 *)(p.residual + o);
+                        v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+                    }
+                    if (p.relu) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                    }
+                    *(float4 *)(p.y + o) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+                    for (int e = 0; e < 4; ++e)
+                        if (c + e < p.Cout) {
+                            if (p.residual) v[e] += p.residual[o + e];
+                            if (p.relu) v[e] = fmaxf(v[e], 0.f);
+                            p.y[o + e] = v[e];
+                        } else {
+                            v[e] = 0.f;
+                        }
+                }
+                if (p.yparts) {   // fused act_split of the output (Cop % 8 == 0, c % 4 == 0)
+                    bf16x4 ps[3];
+                    split4(make_float4(v[0], v[1], v[2], v[3]), ps, P);
+#pragma unroll
+                    for (int pp = 0; pp < P; ++pp)
+                        *(bf16x4 *)(p.yparts + pp * p.y_part_stride + (long)m * p.Cop + c) = ps[pp];
+                }
             }
+        }
+        __syncthreads();
     }
 }
 
@@ -534,7 +589,8 @@ extern "C" int sln_conv2d_fwd_f32(const uint16_t *x_parts, int N, int H, int W, 
                                   const uint16_t *w_parts, int parts, int Cout, int KH, int KW,
                                   int stride_h, int stride_w, int dil_h, int dil_w, int pad_top,
                                   int pad_left, int OH, int OW, const float *scale, const float *shift,
-                                  const float *residual, int relu, float *y, sln_stream_t stream) {
+                                  const float *residual, int relu, float *y, uint16_t *y_parts,
+                                  sln_stream_t stream) {
     sln_enter();
     if (!x_parts || !w_parts || !y || N < 0 || H < 1 || W < 1 || Cin < 1 || Cout < 1 || KH < 1 || KW < 1 ||
         stride_h < 1 || stride_w < 1 || dil_h < 1 || dil_w < 1 || OH < 1 || OW < 1)
@@ -545,6 +601,8 @@ extern "C" int sln_conv2d_fwd_f32(const uint16_t *x_parts, int N, int H, int W, 
     ConvParams p;
     p.x = (const __bf16 *)x_parts; p.w = (const __bf16 *)w_parts;
     p.scale = scale; p.shift = shift; p.residual = residual; p.y = y;
+    p.yparts = (__bf16 *)y_parts;
+    p.Cop = (Cout + 7) / 8 * 8;
     p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW;
     p.sh = stride_h; p.sw = stride_w; p.dh = dil_h; p.dw = dil_w; p.pt = pad_top; p.pl = pad_left;
     p.OH = OH; p.OW = OW; p.relu = relu;
@@ -554,6 +612,7 @@ extern "C" int sln_conv2d_fwd_f32(const uint16_t *x_parts, int N, int H, int W, 
     p.Ktot = KH * KW * Cin;
     p.x_part_stride = (long)N * H * W * Cin;
     p.w_part_stride = (long)Cout * p.Ktot;
+    p.y_part_stride = (long)N * OH * OW * p.Cop;
     p.cin_chunks = sln_div_up(Cin, BK);
     p.gm = sln_div_up(M, BM);
     p.gn = sln_div_up(Cout, BN);

@@ -58,7 +58,7 @@ def conv_bn_act(x, conv, bn=None, relu=False, residual=None, same=False):
     hip = _hip_conv() if BACKEND in ("auto", "hip") else None
     if hip is not None and x.is_cuda and hip.supports(conv, x):
         return hip.conv_bn_act(x, conv, bn, relu, residual, (pt, pb, pl, pr))
-    if BACKEND == "hip":
+    if BACKEND == "hip" and conv.in_channels >= 8:   # (3-channel stems are aten by design)
         raise RuntimeError("HIP conv backend requested but unavailable for this layer")
     if pt == pb and pl == pr:
         y = F.conv2d(x, conv.weight, conv.bias, stride, (pt, pl), dilation)
