@@ -60,8 +60,17 @@ def dominant_kernel_roofline(prof, elapsed, parts):
     secs, flops, n = by[name]
     ach = flops / secs / 1e12
     mult = 6 if parts == 3 else 3
+    traffic = None
+    try:   # HBM bytes per launch from the committed rocprofv3 PMC passes (not collectable live)
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_v3_pmc_traffic.json")))[name]
+        traffic = {"hbm_read_bytes_per_launch_raw": pmc["read_bytes_per_launch_raw"],
+                   "hbm_read_bytes_per_launch_x2_corrected": pmc["read_bytes_per_launch_x2_gfx950_wide_load_correction"],
+                   "hbm_write_bytes_per_launch": pmc["write_bytes_per_launch"],
+                   "source": "profiles/r1_v3_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"}
+    except Exception:
+        pass
     return {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-            "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+            "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
             "launches": n, "avg_launch_us": round(secs / n * 1e6, 2),
             "algorithmic_tflop_per_launch": round(flops / n / 1e12, 5),
             "share_of_step_time": round(secs / elapsed, 4),
