@@ -92,6 +92,8 @@ def main():
     ap.add_argument("--stage", default="all", choices=["all", "heads"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--conv-backend", default="auto", choices=["auto", "hip", "torch"])
+    ap.add_argument("--parts", type=int, default=None, choices=[2, 3],
+                    help="bf16 parts per fp32 operand in the conv stack (default 3 = fp32-class)")
     args = ap.parse_args()
 
     from sln_amodal_amd import nn_ops, parallel, synthetic
@@ -104,6 +106,9 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     nn_ops.BACKEND = args.conv_backend
+    if args.parts:
+        from sln_amodal_amd import conv_hip as _ch
+        _ch.PARTS = args.parts
 
     class BenchConfig(Config):
         NAME = "bench"
@@ -175,7 +180,9 @@ def main():
                                    (args.stage, args.batch, args.dim, args.dim),
                        "arch": args.arch, "images_per_gpu": args.batch, "image_dim": args.dim,
                        "stage": args.stage, "parallelism": "dp%d" % world,
-                       "conv_backend": nn_ops.BACKEND, "final_loss": round(final_loss, 5)},
+                       "conv_backend": nn_ops.BACKEND, "conv_split_parts": conv_hip.PARTS,
+                       "final_loss": round(final_loss, 5),
+                       "max_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)},
             "step_roofline": {"bound": "mfma", "kernel": "whole train step (all kernels)",
                               "achieved": round(achieved, 3), "peak": PEAK_F32_MFMA_TFLOPS,
                               "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),

@@ -232,3 +232,39 @@ def test_detect_inference_path_runs():
         if n:   # like the reference, an image without surviving boxes yields an empty mask stack
             assert r["masks"].shape == (200, 180, n) and r["masks"].dtype == np.uint8
             assert (r["class_ids"] == 1).all()
+
+
+def test_config2_resnet50_fpn_forward_800x800_bs8():
+    """BASELINE config #2: ResNet-50 + FPN forward-only, 8 x 800x800 (not a multiple of
+    64: the reference's build() rejects it, model.py:153-157; shapes are consistent)."""
+    from sln_amodal_amd.config import Config
+    from sln_amodal_amd.model import MaskRCNN
+    from sln_amodal_amd.modal.Functions import proposal_layer
+
+    class C(Config):
+        NAME = "c2"
+        IMAGE_MAX_DIM = 800
+        ARCHITECTURE = "resnet50"
+
+    torch.manual_seed(0)
+    cfg = C()
+    m = MaskRCNN(cfg, "/tmp/sln_logs").cuda()
+    assert cfg.BACKBONE_SHAPES.tolist() == [[200, 200], [100, 100], [50, 50], [25, 25], [13, 13]]
+    x = torch.randn(8, 3, 800, 800, device="cuda")
+    with torch.no_grad():
+        maps, logits, probs, bbox = m.rpn_forward(x)
+        rois, num = proposal_layer([probs, bbox], 1000, 0.7, m.anchors, cfg, return_counts=True)
+    assert [tuple(t.shape[2:]) for t in maps] == [(200, 200), (100, 100), (50, 50), (25, 25), (13, 13)]
+    A = m.anchors.shape[0]
+    assert A == 3 * (200 * 200 + 100 * 100 + 50 * 50 + 25 * 25 + 13 * 13)
+    assert probs.shape == (8, A, 2) and bbox.shape == (8, A, 4)
+    assert rois.shape == (8, 1000, 4) and bool((num > 0).all())
+    assert float(rois.min()) >= 0.0 and float(rois.max()) <= 1.0
+
+
+def test_cli_evaluate_synthetic_runs(tmp_path):
+    """BASELINE config #1 plumbing: `amodal_train.py evaluate` on 2 synthetic 512x512
+    images with ResNet-50 (here on the GPU product path)."""
+    from sln_amodal_amd import amodal_train
+    amodal_train.main(["evaluate", "--synthetic", "--arch", "resnet50", "--image-dim", "512",
+                       "--limit", "2", "--logs", str(tmp_path)])
