@@ -245,9 +245,16 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvParams p) {
     auto load_tile = [&](int ks) {
         // channel-chunk major, tap minor: the KH*KW shifted windows of one 32-channel
         // slab are read in consecutive k-steps, so the re-reads hit L1/L2
+        // Order: channel-chunk PAIR major, tap, then the two 32-channel chunks of the
+        // pair (= one 128-B line of a pixel's bf16 row): the second chunk's loads hit
+        // the L1 lines the first one fetched, and the KH*KW shifted windows of a pair
+        // are read in consecutive steps (L2 hits).
         const int ntap = p.KH * p.KW;
-        const int cc = ks / ntap;
-        const int tap = ks - cc * ntap;
+        const int pair = ks / (2 * ntap);
+        const int rem2 = ks - pair * 2 * ntap;
+        const int npair = min(2, p.cin_chunks - 2 * pair);   // last pair may hold one chunk
+        const int tap = rem2 / npair;
+        const int cc = 2 * pair + (rem2 - tap * npair);
         const int ci0 = cc * BK;
         const int kh = tap / p.KW, kw = tap - kh * p.KW;
         const int ci = ci0 + chunk;
