@@ -331,9 +331,9 @@ class Classifier(nn.Module):
         x = nn_ops.conv_bn_act(x, self.conv1, self.bn1, relu=True)
         x = nn_ops.conv_bn_act(x, self.conv2, self.bn2, relu=True)
         x = x.reshape(-1, 1024)
-        mrcnn_class_logits = self.linear_class(x)
+        mrcnn_class_logits = nn_ops.linear(x, self.linear_class)
         mrcnn_probs = self.softmax(mrcnn_class_logits)
-        mrcnn_bbox = self.linear_bbox(x)
+        mrcnn_bbox = nn_ops.linear(x, self.linear_bbox)
         mrcnn_bbox = mrcnn_bbox.view(mrcnn_bbox.size()[0], -1, 4)
         return [mrcnn_class_logits, mrcnn_probs, mrcnn_bbox]
 
@@ -368,6 +368,6 @@ class Mask(nn.Module):
         x = conv(x, self.conv2, self.bn2, relu=True, same=True)
         x = conv(x, self.conv3, self.bn3, relu=True, same=True)
         feat = conv(x, self.conv4, self.bn4, relu=True, same=True)
-        x = F.relu(F.conv_transpose2d(feat, self.deconv.weight, self.deconv.bias, stride=2))
+        x = nn_ops.deconv2x2_relu(feat, self.deconv)
         x = conv(x, self.conv5)  # logits; the sigmoid lives in the losses (modals.py:497)
         return x, feat

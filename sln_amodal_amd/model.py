@@ -389,15 +389,17 @@ class MaskRCNN(nn.Module):
         full = []
         for i in range(boxes.shape[0]):
             y1, x1, y2, x2 = boxes[i]
+            # utils.py:447-465 -> scipy.misc.imresize(mask, (h, w), interp='bilinear'):
+            # min-max bytescale to uint8, PIL bilinear resize, then /255 >= 0.5
+            from PIL import Image
             m = masks[i].astype(np.float64)
-            # scipy.misc.imresize semantics: min-max bytescale to uint8, bilinear, /255
             lo, hi = m.min(), m.max()
-            byt = np.zeros_like(m) if hi == lo else np.floor((m - lo) * (255.0 / (hi - lo)) + 0.5)
-            t = torch.from_numpy(byt).float()[None, None]
-            r = F.interpolate(t, size=(int(y2 - y1), int(x2 - x1)), mode="bilinear",
-                              align_corners=False)[0, 0].numpy()
+            byt = np.zeros(m.shape, np.uint8) if hi == lo else \
+                ((m - lo) * (255.0 / (hi - lo)) + 0.5).clip(0, 255).astype(np.uint8)
+            r = np.asarray(Image.fromarray(byt).resize((int(x2 - x1), int(y2 - y1)), Image.BILINEAR),
+                           dtype=np.float32)
             fm = np.zeros(image_shape[:2], dtype=np.uint8)
-            fm[y1:y2, x1:x2] = (np.floor(r) / 255.0 >= 0.5).astype(np.uint8)
+            fm[y1:y2, x1:x2] = (r / 255.0 >= 0.5).astype(np.uint8)
             full.append(fm)
         full = np.stack(full, axis=-1) if full else np.empty((0,) + masks.shape[1:3])
         return boxes, class_ids, scores, full

@@ -84,3 +84,33 @@ def max_pool_same(x, kernel, stride):
 def upsample2x_add(lateral, top):
     """FPN merge: lateral + nearest-2x(top)  (modal/modals.py:243-246)."""
     return lateral + F.interpolate(top, scale_factor=2, mode="nearest")
+
+
+def deconv2x2_relu(x, deconv):
+    """ConvTranspose2d(kernel 2, stride 2) + ReLU of the mask head (modal/modals.py:494-495)
+    on the HIP conv stack: every output pixel (2i+a, 2j+b) depends on one input pixel, so
+    the layer is a 1x1 convolution to 4*Cout channels (rows ordered (a, b, cout)) followed
+    by a depth-to-space shuffle; bias and ReLU commute with the shuffle and are fused in
+    the conv epilogue.  Autograd sees plain views of `deconv.weight`, so the weight
+    gradient arrives in the parameter's own [Cin, Cout, 2, 2] layout."""
+    hip = _hip_conv() if BACKEND in ("auto", "hip") else None
+    if hip is None or not x.is_cuda:
+        return F.relu(F.conv_transpose2d(x, deconv.weight, deconv.bias, stride=2))
+    Ci, Co = deconv.weight.shape[0], deconv.weight.shape[1]
+    w2 = deconv.weight.permute(2, 3, 1, 0).reshape(4 * Co, Ci, 1, 1)
+    b2 = deconv.bias.repeat(4) if deconv.bias is not None else None
+    y = hip._ConvFn.apply(x, w2, b2, None, None, None, True, (1, 1), (1, 1), (0, 0, 0, 0))
+    N, _, H, W = y.shape
+    y = y.permute(0, 2, 3, 1).reshape(N, H, W, 2, 2, Co).permute(0, 1, 3, 2, 4, 5)
+    return y.reshape(N, 2 * H, 2 * W, Co).permute(0, 3, 1, 2)      # logical NCHW, NHWC in memory
+
+
+def linear(x, lin):
+    """nn.Linear on [R, C] rows through the same GEMM kernel (a 1x1 conv on R 1x1 'images')."""
+    hip = _hip_conv() if BACKEND in ("auto", "hip") else None
+    if hip is None or not x.is_cuda or x.shape[1] % 8:
+        return F.linear(x, lin.weight, lin.bias)
+    R, C = x.shape
+    y = hip._ConvFn.apply(x.reshape(R, C, 1, 1), lin.weight.reshape(lin.out_features, C, 1, 1), lin.bias,
+                          None, None, None, False, (1, 1), (1, 1), (0, 0, 0, 0))
+    return y.reshape(R, lin.out_features)
