@@ -15,6 +15,8 @@ import os
 
 # 3 = fp32-class accuracy (6 MFMA products); 2 = ~4e-6 per layer (3 products)
 PARTS = int(os.environ.get("SLN_CONV_PARTS", "3"))
+# parts used while autograd is disabled (the frozen GLM, inference): None = same as PARTS
+PARTS_NOGRAD = int(os.environ["SLN_CONV_PARTS_NOGRAD"]) if os.environ.get("SLN_CONV_PARTS_NOGRAD") else None
 class _NoCache(dict):
     pass
 
@@ -157,6 +159,8 @@ class _ConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, bn_scale, bn_shift, residual, relu, stride, dil, pads):
         parts = PARTS
+        if PARTS_NOGRAD and not any(ctx.needs_input_grad):
+            parts = PARTS_NOGRAD
         Co, Ci, KH, KW = weight.shape
         N, _, H, W = x.shape
         pt, pb, pl, pr = pads

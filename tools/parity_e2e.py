@@ -30,9 +30,10 @@ g = torch.Generator(device="cuda").manual_seed(5)
 pr = {"pos": torch.rand(B, 1000, device="cuda", generator=g), "neg": torch.rand(B, 1000, device="cuda", generator=g)}
 res = {}
 fixed = None
-for name, be, parts in (("torch", "torch", 3), ("hip3", "hip_or_torch", 3), ("hip2", "hip_or_torch", 2)):
+for name, be, parts in (("torch", "torch", 3), ("hip3", "hip_or_torch", 3), ("hip3glm2", "hip_or_torch", 3), ("hip2", "hip_or_torch", 2)):
     nn_ops.BACKEND = "torch" if be == "torch" else "auto"
     conv_hip.PARTS = parts
+    conv_hip.PARTS_NOGRAD = 2 if name == "hip3glm2" else None
     conv_hip._cache.clear()
     m.zero_grad(set_to_none=True)
     out = m.predict([batch["images"], None, batch["gt_class_ids"], batch["gt_boxes"], batch["gt_layer"]],
@@ -53,7 +54,7 @@ for name, be, parts in (("torch", "torch", 3), ("hip3", "hip_or_torch", 3), ("hi
                  {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None})
     print(name, "loss %.7f" % loss.item(), "gradnorm %.6f" % gn.item(), "valid rois", int(out["roi_valid"].sum()),
           {k: round(v.item(), 6) for k, v in parts_d.items()})
-for k in ("hip3", "hip2"):
+for k in ("hip3", "hip3glm2", "hip2"):
     d = {n: abs(res[k][1][n] - res["torch"][1][n]) for n in res[k][1]}
     ga, gb = res[k][4], res["torch"][4]
     print("   grads only in one backend:", sorted(set(ga) ^ set(gb))[:12])
