@@ -176,6 +176,43 @@ def test_pyramid_golden_through_hip_crop():
         assert np.allclose(fm.grad.cpu().numpy(), g["grad%d" % i], rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("pool", [16, 8, 14, 7])
+def test_pyramid_crop_backward_vs_oracle_all_regimes(orc, pool):
+    """sln_pyramid_crop_bwd_f32 against the oracle's serial crop_and_resize backward, one
+    level at a time: tiny rois (many bins per pixel), level-sized rois, whole-map rois
+    (footprint > crop -> scatter branch), rois partly outside the map (skipped bins),
+    padded slots, a channel count that is not a multiple of the 64-channel block."""
+    from sln_amodal_amd.modal.modals import _PyramidCrop
+    gen = torch.Generator().manual_seed(pool)
+    B, C = 2, 72
+    sizes = [(64, 64), (32, 32), (16, 16), (8, 8)]
+    K = 96
+    ctr = torch.rand(K, 2, generator=gen)
+    half = torch.cat([torch.rand(24, 2, generator=gen) * 0.02,          # tiny
+                      torch.rand(40, 2, generator=gen) * 0.15 + 0.03,   # level sized
+                      torch.rand(16, 2, generator=gen) * 0.5 + 0.3,     # huge / out of bounds
+                      torch.rand(16, 2, generator=gen) * 0.1])
+    boxes = torch.cat([ctr - half, ctr + half], dim=1)[:, [0, 1, 2, 3]].float()
+    boxes[90] = torch.tensor([0.0, 0.0, 1.0, 1.0])
+    boxes[91] = torch.tensor([0.25, 0.25, 0.25, 0.25])                 # zero extent
+    level = torch.randint(2, 6, (K,), generator=gen).int()
+    ind = torch.randint(0, B, (K,), generator=gen).int()
+    ind[5] = -1                                                         # padded slot
+    maps = [torch.randn(B, C, h, w, generator=gen).cuda().contiguous(memory_format=torch.channels_last)
+            .requires_grad_(True) for h, w in sizes]
+    out = _PyramidCrop.apply(boxes.cuda(), ind.cuda(), level.cuda(), pool, *maps)
+    up = torch.randn(K, C, pool, pool, generator=gen)
+    out.backward(up.cuda().contiguous(memory_format=torch.channels_last))
+    for i, (h, w) in enumerate(sizes):
+        sel = np.nonzero((level.numpy() == i + 2) & (ind.numpy() >= 0))[0]
+        want = orc.crop_and_resize_bwd(up.numpy()[sel], boxes.numpy()[sel], ind.numpy()[sel], (B, C, h, w))
+        got = maps[i].grad.cpu().numpy()
+        assert np.allclose(got, want, rtol=1e-5, atol=1e-5), (i, np.abs(got - want).max())
+        fwd = orc.crop_and_resize_fwd(maps[i].detach().cpu().numpy(), boxes.numpy()[sel], ind.numpy()[sel],
+                                      pool, pool)
+        assert np.array_equal(out.detach().cpu().numpy()[sel], fwd)
+
+
 def test_crop_full_size_linearity_and_adjoint():
     """BASELINE size: [16,256,256,256] P2 map, 1600 rois, 16x16 bins (NHWC)."""
     from sln_amodal_amd.roialign.roi_align.crop_and_resize import CropAndResizeFunction

@@ -44,7 +44,7 @@ def measure(dev, B=16):
     o = _PyramidCrop.apply(boxes, ind, lvl, pool, *ms)
     up = torch.randn_like(o)
     t = _time(lambda: torch.autograd.grad(o, ms, up, retain_graph=True))
-    out["roialign_bwd"] = {"kernel": "pyr_bwd_kernel (+memset of 4 grad maps)", "bound": "hbm",
+    out["roialign_bwd"] = {"kernel": "pyr_bwd_patch_kernel (+memset of 4 grad maps)", "bound": "hbm",
                            "bytes_per_elem": 36, "elems": elems, "ms": round(t * 1e3, 4),
                            "achieved": round(elems * 36 / t / 1e9, 1), "peak": PEAK_HBM_GBS,
                            "unit": "GB/s", "frac": round(elems * 36 / t / 1e9 / PEAK_HBM_GBS, 4)}
