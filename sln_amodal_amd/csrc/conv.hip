@@ -39,11 +39,11 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 #define LDK 40  // padded row length in bf16 (80 B)
 
 // ---------------------------------------------------------------- elementwise
-__device__ __forceinline__ void split4(const float4 v, bf16x4 *parts, int P) {
+template <int P>
+__device__ __forceinline__ void split4(const float4 v, bf16x4 *parts) {
     float r[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-    for (int p = 0; p < 3; ++p) {
-        if (p >= P) break;
+    for (int p = 0; p < P; ++p) {
         bf16x4 h;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -55,8 +55,9 @@ __device__ __forceinline__ void split4(const float4 v, bf16x4 *parts, int P) {
 }
 
 // x [M][C] fp32 -> parts [P][M][Cp] bf16 (channels C..Cp-1 zero).  C % 4 == 0 fast path.
+template <int P>
 __global__ __launch_bounds__(256) void act_split_kernel(const float *__restrict__ x, long M, int C,
-                                                        int Cp, int P, __bf16 *__restrict__ parts) {
+                                                        int Cp, __bf16 *__restrict__ parts) {
     const int q4 = Cp / 4;
     const long total = M * q4;
     const long pstride = M * Cp;
@@ -72,67 +73,105 @@ __global__ __launch_bounds__(256) void act_split_kernel(const float *__restrict_
                 if (c + j < C) t[j] = x[m * C + c + j];
             v = make_float4(t[0], t[1], t[2], t[3]);
         }
-        bf16x4 ps[3];
-        split4(v, ps, P);
+        bf16x4 ps[P];
+        split4<P>(v, ps);
+#pragma unroll
         for (int p = 0; p < P; ++p) *(bf16x4 *)(parts + p * pstride + m * Cp + c) = ps[p];
     }
 }
 
 // gz = gy * (y > 0 ? 1 : 0) * scale[c]; writes gu = gy*(y>0) (fp32, optional), the
 // bf16 parts of gz, and accumulates the per-channel sum of gz (bias gradient).
+// A thread keeps one channel quad and walks rows (no index division, bias sums stay in
+// registers until the end); two rows are in flight per iteration.
+__device__ __forceinline__ void grad_prep_row(const float *__restrict__ gy, const float *__restrict__ y,
+                                              long m, int c, int C, bool vec, float g[4]) {
+    g[0] = g[1] = g[2] = g[3] = 0.f;
+    if (vec) {
+        const float4 v = *(const float4 *)(gy + m * C + c);
+        g[0] = v.x; g[1] = v.y; g[2] = v.z; g[3] = v.w;
+        if (y) {
+            const float4 yy = *(const float4 *)(y + m * C + c);
+            if (!(yy.x > 0.f)) g[0] = 0.f;
+            if (!(yy.y > 0.f)) g[1] = 0.f;
+            if (!(yy.z > 0.f)) g[2] = 0.f;
+            if (!(yy.w > 0.f)) g[3] = 0.f;
+        }
+    } else {
+        for (int j = 0; j < 4; ++j)
+            if (c + j < C) {
+                float v = gy[m * C + c + j];
+                if (y && !(y[m * C + c + j] > 0.f)) v = 0.f;
+                g[j] = v;
+            }
+    }
+}
+
+template <int P>
+__device__ __forceinline__ void grad_prep_emit(float g[4], long m, int c, int C, int Cp, bool vec,
+                                               const float sc[4], float acc[4], long pstride,
+                                               float *__restrict__ gu, __bf16 *__restrict__ parts) {
+    if (gu) {
+        if (vec) *(float4 *)(gu + m * C + c) = make_float4(g[0], g[1], g[2], g[3]);
+        else
+            for (int j = 0; j < 4; ++j)
+                if (c + j < C) gu[m * C + c + j] = g[j];
+    }
+    for (int j = 0; j < 4; ++j) { g[j] *= sc[j]; acc[j] += g[j]; }
+    bf16x4 ps[P];
+    split4<P>(make_float4(g[0], g[1], g[2], g[3]), ps);
+#pragma unroll
+    for (int p = 0; p < P; ++p) *(bf16x4 *)(parts + p * pstride + m * Cp + c) = ps[p];
+}
+
+template <int P>
 __global__ __launch_bounds__(256) void grad_prep_kernel(const float *__restrict__ gy,
                                                         const float *__restrict__ y,
                                                         const float *__restrict__ scale, long M, int C,
-                                                        int Cp, int P, float *__restrict__ gu,
+                                                        int Cp, float *__restrict__ gu,
                                                         __bf16 *__restrict__ parts,
                                                         float *__restrict__ gbias) {
-    extern __shared__ float s_bias[];
-    if (gbias) {
-        for (int c = threadIdx.x; c < C; c += 256) s_bias[c] = 0.f;
-        __syncthreads();
-    }
+    __shared__ float s_bias[1024];
     const int q4 = Cp / 4;
-    const long total = M * q4;
+    int tw = 1, sh = 0;                       // tw = channel quads per block row (power of two)
+    while (tw < q4 && tw < 256) { tw <<= 1; ++sh; }
+    const int R = 256 >> sh;                  // rows per block pass
+    const int cq_l = threadIdx.x & (tw - 1), r0 = threadIdx.x >> sh;
     const long pstride = M * Cp;
-    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-        const long m = e / q4;
-        const int c = (int)(e - m * q4) * 4;
-        float g[4] = {0.f, 0.f, 0.f, 0.f};
-        const bool vec = (c + 3 < C) && (C & 3) == 0;
-        if (vec) {
-            const float4 v = *(const float4 *)(gy + m * C + c);
-            g[0] = v.x; g[1] = v.y; g[2] = v.z; g[3] = v.w;
-            if (y) {
-                const float4 yy = *(const float4 *)(y + m * C + c);
-                if (!(yy.x > 0.f)) g[0] = 0.f;
-                if (!(yy.y > 0.f)) g[1] = 0.f;
-                if (!(yy.z > 0.f)) g[2] = 0.f;
-                if (!(yy.w > 0.f)) g[3] = 0.f;
+    const long rstep = (long)gridDim.x * R;
+    for (int ct = 0; ct * tw < q4; ++ct) {
+        const int c = (ct * tw + cq_l) * 4;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        if (c < Cp) {
+            const bool vec = (c + 3 < C) && (C & 3) == 0;
+            float sc[4];
+            for (int j = 0; j < 4; ++j) sc[j] = (c + j < C) ? (scale ? scale[c + j] : 1.f) : 0.f;
+            long m = (long)blockIdx.x * R + r0;
+            for (; m + rstep < M; m += 2 * rstep) {
+                float g0[4], g1[4];
+                grad_prep_row(gy, y, m, c, C, vec, g0);
+                grad_prep_row(gy, y, m + rstep, c, C, vec, g1);
+                grad_prep_emit<P>(g0, m, c, C, Cp, vec, sc, acc, pstride, gu, parts);
+                grad_prep_emit<P>(g1, m + rstep, c, C, Cp, vec, sc, acc, pstride, gu, parts);
             }
-            if (gu) *(float4 *)(gu + m * C + c) = make_float4(g[0], g[1], g[2], g[3]);
-        } else {
-            for (int j = 0; j < 4; ++j)
-                if (c + j < C) {
-                    float v = gy[m * C + c + j];
-                    if (y && !(y[m * C + c + j] > 0.f)) v = 0.f;
-                    g[j] = v;
-                    if (gu) gu[m * C + c + j] = v;
-                }
+            if (m < M) {
+                float g0[4];
+                grad_prep_row(gy, y, m, c, C, vec, g0);
+                grad_prep_emit<P>(g0, m, c, C, Cp, vec, sc, acc, pstride, gu, parts);
+            }
         }
-        if (scale)
+        if (gbias) {
+            for (int i = threadIdx.x; i < tw * 4; i += 256) s_bias[i] = 0.f;
+            __syncthreads();
             for (int j = 0; j < 4; ++j)
-                if (c + j < C) g[j] *= scale[c + j];
-        if (gbias)
-            for (int j = 0; j < 4; ++j)
-                if (c + j < C && g[j] != 0.f) atomicAdd(&s_bias[c + j], g[j]);
-        bf16x4 ps[3];
-        split4(make_float4(g[0], g[1], g[2], g[3]), ps, P);
-        for (int p = 0; p < P; ++p) *(bf16x4 *)(parts + p * pstride + m * Cp + c) = ps[p];
-    }
-    if (gbias) {
-        __syncthreads();
-        for (int c = threadIdx.x; c < C; c += 256)
-            if (s_bias[c] != 0.f) atomicAdd(gbias + c, s_bias[c]);
+                if (acc[j] != 0.f) atomicAdd(&s_bias[cq_l * 4 + j], acc[j]);
+            __syncthreads();
+            for (int i = threadIdx.x; i < tw * 4; i += 256) {
+                const int cc = ct * tw * 4 + i;
+                if (cc < C && s_bias[i] != 0.f) atomicAdd(gbias + cc, s_bias[i]);
+            }
+            __syncthreads();
+        }
     }
 }
 
@@ -385,7 +424,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvParams p) {
                 }
                 if (p.yparts) {   // fused act_split of the output (Cop % 8 == 0, c % 4 == 0)
                     bf16x4 ps[3];
-                    split4(make_float4(v[0], v[1], v[2], v[3]), ps, P);
+                    split4<P>(make_float4(v[0], v[1], v[2], v[3]), ps);
 #pragma unroll
                     for (int pp = 0; pp < P; ++pp)
                         *(bf16x4 *)(p.yparts + pp * p.y_part_stride + (long)m * p.Cop + c) = ps[pp];
@@ -571,8 +610,12 @@ extern "C" int sln_act_split_f32(const float *x, int64_t M, int C, int C_pad, in
     if (M < 0 || C < 1 || C_pad < C || (C_pad & 7) || parts < 2 || parts > 3) return SLN_ERR_INVALID_ARG;
     if (M == 0) return SLN_OK;
     if (!x || !out) return SLN_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(act_split_kernel, dim3(ew_grid(M * (C_pad / 4))), dim3(256), 0, (hipStream_t)stream,
-                       x, (long)M, C, C_pad, parts, (__bf16 *)out);
+    if (parts == 2)
+        hipLaunchKernelGGL(act_split_kernel<2>, dim3(ew_grid(M * (C_pad / 4))), dim3(256), 0,
+                           (hipStream_t)stream, x, (long)M, C, C_pad, (__bf16 *)out);
+    else
+        hipLaunchKernelGGL(act_split_kernel<3>, dim3(ew_grid(M * (C_pad / 4))), dim3(256), 0,
+                           (hipStream_t)stream, x, (long)M, C, C_pad, (__bf16 *)out);
     return sln_launch_status();
 }
 
@@ -585,10 +628,16 @@ extern "C" int sln_conv_grad_prep_f32(const float *gy, const float *y, const flo
     hipStream_t st = (hipStream_t)stream;
     if (gbias && hipMemsetAsync(gbias, 0, sizeof(float) * C, st) != hipSuccess) return SLN_ERR_LAUNCH;
     if (M == 0) return SLN_OK;
-    int grid = ew_grid(M * (C_pad / 4));
-    if (gbias && grid > 1024) grid = 1024;
-    hipLaunchKernelGGL(grad_prep_kernel, dim3(grid), dim3(256), gbias ? sizeof(float) * C : 0, st, gy, y,
-                       scale, (long)M, C, C_pad, parts, gu, (__bf16 *)gz_parts, gbias);
+    int tw = 1;
+    while (tw < C_pad / 4 && tw < 256) tw <<= 1;
+    long grid = sln_div_up(M, (long)(256 / tw) * 2);
+    if (grid > 2048) grid = 2048;
+    if (parts == 2)
+        hipLaunchKernelGGL(grad_prep_kernel<2>, dim3((unsigned)grid), dim3(256), 0, st, gy, y, scale, (long)M,
+                           C, C_pad, gu, (__bf16 *)gz_parts, gbias);
+    else
+        hipLaunchKernelGGL(grad_prep_kernel<3>, dim3((unsigned)grid), dim3(256), 0, st, gy, y, scale, (long)M,
+                           C, C_pad, gu, (__bf16 *)gz_parts, gbias);
     return sln_launch_status();
 }
 
