@@ -24,8 +24,10 @@
 // conv_fwd GEMM view: M = N*OH*OW output pixels, N = Cout, K = KH*KW*Cin walked
 // tap by tap in 32-channel chunks; taps outside the image read zero (the
 // reference's SamePad2d / conv padding).  Tile 128x128x32, 256 threads = 4 waves
-// (2x2), each wave 64x64 = 2x2 MFMA tiles of 32x32.  LDS rows are 32 bf16 + 8 pad
-// (80 B): the ds_read_b128 fragment reads of 16 consecutive rows hit 16 distinct
+// (2x2), each wave 64x64 = 2x2 MFMA tiles of 32x32.  Forward LDS rows are 32 bf16
+// (64 B) with the 16-B chunk index XOR-swizzled by row bits 2..3 (48 KB per block, 3
+// blocks per CU); the wgrad tiles keep 8 bf16 of row padding (80 B).  Either way the
+// ds_read_b128 fragment reads of a 16-lane group hit 16 distinct
 // 4-bank groups (conflict-free).  Register prefetch of the next k-step.
 #include "common.h"
 
@@ -237,11 +239,14 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 template <int P>
 __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvParams p) {
     // one LDS region: operand tiles during the k-loop, fp32 staging tile in the epilogue
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * P * BM * LDK * 2];
-    typedef __bf16 (*tile_t)[BM][LDK];
+    // Operand rows are 32 bf16 = 64 B, unpadded; the 16-B chunk index is XOR-swizzled
+    // with bits 2..3 of the row, so the 16 rows a ds_read_b128 group touches cover
+    // all 16 four-bank groups (conflict-free) and a block needs 48 KB -> 3 blocks/CU.
+    constexpr int TILE_B = 2 * P * BM * BK * 2, STAGE_B = 64 * 132 * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[TILE_B > STAGE_B ? TILE_B : STAGE_B];
+    typedef __bf16 (*tile_t)[BM][BK];
     tile_t sA = (tile_t)smem;
-    tile_t sB = (tile_t)(smem + P * BM * LDK * 2);
-    static_assert(2 * P * BM * LDK * 2 >= 64 * 132 * 4, "staging tile must fit");
+    tile_t sB = (tile_t)(smem + P * BM * BK * 2);
 
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
@@ -315,14 +320,15 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvParams p) {
                 rb[pp][i] = (b_ok[i] && cok) ? *(const bf16x8 *)(bptr[i] + pp * p.w_part_stride + koff)
                                              : zero8;
     };
+    const int schunk = ((t & 3) ^ ((t >> 4) & 3)) * 8;   // swizzled chunk of this thread's rows
     auto store_tile = [&]() {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int row = (t >> 2) + 64 * i;
 #pragma unroll
             for (int pp = 0; pp < P; ++pp) {
-                *(bf16x8 *)&sA[pp][row][chunk] = ra[pp][i];
-                *(bf16x8 *)&sB[pp][row][chunk] = rb[pp][i];
+                *(bf16x8 *)&sA[pp][row][schunk] = ra[pp][i];
+                *(bf16x8 *)&sB[pp][row][schunk] = rb[pp][i];
             }
         }
     };
@@ -339,7 +345,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvParams p) {
     store_tile();
     __syncthreads();
 
-    const int frow = lane & 31, fk = (lane >> 5) * 8;
+    const int frow = lane & 31, fsw = (frow >> 2) & 3, fhi = lane >> 5;
     for (int ks = 0; ks < nk; ++ks) {
         if (ks + 1 < nk) load_tile(ks + 1);
 #pragma unroll
@@ -349,8 +355,8 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvParams p) {
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int pp = 0; pp < P; ++pp) {
-                    a[i][pp] = *(const bf16x8 *)&sA[pp][wr * 64 + i * 32 + frow][kk * 16 + fk];
-                    b[i][pp] = *(const bf16x8 *)&sB[pp][wc * 64 + i * 32 + frow][kk * 16 + fk];
+                    a[i][pp] = *(const bf16x8 *)&sA[pp][wr * 64 + i * 32 + frow][((kk * 2 + fhi) ^ fsw) * 8];
+                    b[i][pp] = *(const bf16x8 *)&sB[pp][wc * 64 + i * 32 + frow][((kk * 2 + fhi) ^ fsw) * 8];
                 }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
