@@ -399,6 +399,17 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvParams p) {
                     if (p.scale) sc[e] = p.scale[c + e];
                     if (p.shift) sf[e] = p.shift[c + e];
                 }
+            // all residual rows of this half are requested before the first store: the
+            // loads cannot be moved across the y stores by the compiler (may alias)
+            float4 res4[8];
+            if (vec_ok && p.residual) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int m = m0 + h * 64 + (t >> 5) + 8 * q;
+                    res4[q] = m < p.M ? *(const float4 *)(p.residual + (long)m * p.Cout + c)
+                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const int row = (t >> 5) + 8 * q;
@@ -410,7 +421,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvParams p) {
                 const long o = (long)m * p.Cout + c;
                 if (vec_ok) {
                     if (p.residual) {
-                        const float4 r4 = *(const float4 *)(p.residual + o);
+                        const float4 r4 = res4[q];
                         v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
                     }
                     if (p.relu) {
