@@ -26,8 +26,7 @@
 // reference's SamePad2d / conv padding).  Tile 128x128x32, 256 threads = 4 waves
 // (2x2), each wave 64x64 = 2x2 MFMA tiles of 32x32.  Forward LDS rows are 32 bf16
 // (64 B) with the 16-B chunk index XOR-swizzled by row bits 2..3 (48 KB per block, 3
-// blocks per CU); the wgrad tiles keep 8 bf16 of row padding (80 B).  Either way the
-// ds_read_b128 fragment reads of a 16-lane group hit 16 distinct
+// blocks per CU): the ds_read_b128 fragment reads of a 16-lane group hit 16 distinct
 // 4-bank groups (conflict-free).  Register prefetch of the next k-step.
 #include "common.h"
 
@@ -38,7 +37,6 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 #define BM 128
 #define BN 128
 #define BK 32
-#define LDK 40  // padded row length in bf16 (80 B)
 
 // ---------------------------------------------------------------- elementwise
 template <int P>
@@ -459,6 +457,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvParams p) {
 // the four k-rows of a transposing read sit 16 banks apart) and the MFMA fragments
 // (8 consecutive k per lane) are fetched with two ds_read_b64_tr_b16 each.
 // Split-K over pixel chunks, fp32 atomics into the (callee-zeroed) gradient.
+// (An unpadded XOR-swizzled image, 3 blocks/CU, measured 1-3 % slower here.)
 #define WLD 160  // padded row length in bf16 (320 B)
 
 struct WgradParams {
@@ -725,9 +724,10 @@ extern "C" int sln_conv2d_wgrad_f32(const uint16_t *gz_parts, int Cout, int Cout
     p.gm = sln_div_up(Cout, BM);
     p.gn_per_tap = sln_div_up(Cin, BN);
     const long ntile = (long)p.gm * p.gn_per_tap * KH * KW;
-    // split the pixel range so that ~8 blocks per CU are in flight, >= 2048 pixels each
-    long ks = (256L * 8 + ntile - 1) / ntile;
-    const long max_ks = (M + 2047) / 2048;
+    // split the pixel range: ~24 blocks per CU (short blocks balance the tail; swept 2..32
+    // on the train step), but at least 1024 pixels (32 k-steps) per block
+    long ks = (256L * 24 + ntile - 1) / ntile;
+    const long max_ks = (M + 1023) / 1024;
     if (ks > max_ks) ks = max_ks;
     if (ks < 1) ks = 1;
     long pps = (M + ks - 1) / ks;
