@@ -62,11 +62,11 @@ def dominant_kernel_roofline(prof, elapsed, parts):
     mult = 6 if parts == 3 else 3
     traffic = None
     try:   # HBM bytes per launch from the committed rocprofv3 PMC passes (not collectable live)
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_v3_pmc_traffic.json")))[name]
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_v5_pmc_traffic.json")))[name]
         traffic = {"hbm_read_bytes_per_launch_raw": pmc["read_bytes_per_launch_raw"],
                    "hbm_read_bytes_per_launch_x2_corrected": pmc["read_bytes_per_launch_x2_gfx950_wide_load_correction"],
                    "hbm_write_bytes_per_launch": pmc["write_bytes_per_launch"],
-                   "source": "profiles/r1_v3_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"}
+                   "source": "profiles/r1_v5_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"}
     except Exception:
         pass
     return {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
