@@ -13,6 +13,8 @@ Backends
             Interim backend for layer shapes the HIP kernels do not cover yet;
             DESIGN.md lists which layers run where.
 """
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -36,10 +38,30 @@ def same_pad(in_size, kernel, stride):
     return before, total - before
 
 
+CACHE_BN_AFFINE = os.environ.get("SLN_CACHE_BN_AFFINE", "1") != "0"
+BN_CACHE_STATS = [0, 0]   # hits, misses
+
+
 def bn_affine(bn):
-    """Frozen BatchNorm2d -> (scale, shift) per channel, fp32."""
-    scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
-    shift = bn.bias - bn.running_mean * scale
+    """Frozen BatchNorm2d -> (scale, shift) per channel, fp32.  With frozen affine
+    parameters (the whole hot path: model.py:192-197 of the reference) the pair only
+    changes when a checkpoint is loaded, so it is cached on the module, keyed by the
+    version counters of its four tensors.  (In-place edits made through `.data` do not
+    bump those counters: delete `bn._sln_affine` after such an edit.)"""
+    frozen = CACHE_BN_AFFINE and not (bn.weight.requires_grad or bn.bias.requires_grad)
+    if frozen:
+        key = (bn.weight._version, bn.bias._version, bn.running_mean._version,
+               bn.running_var._version, bn.weight.data_ptr(), bn.running_var.data_ptr())
+        hit = getattr(bn, "_sln_affine", None)
+        if hit is not None and hit[0] == key:
+            BN_CACHE_STATS[0] += 1
+            return hit[1], hit[2]
+        BN_CACHE_STATS[1] += 1
+    with torch.set_grad_enabled(not frozen):
+        scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
+        shift = bn.bias - bn.running_mean * scale
+    if frozen:
+        bn._sln_affine = (key, scale, shift)
     return scale, shift
 
 
