@@ -180,6 +180,13 @@ int sln_pyramid_crop_bwd_f32(const float *grads, int g_cstride, int g_coffset, c
  *     may differ from bottom/right: TensorFlow 'SAME' padding).  y_parts (optional):
  *     the output's own parts [parts][N*OH*OW][Cout_pad], written by the epilogue
  *     (fused sln_act_split_f32 for the next layer); pad channels are NOT written.
+ * sln_conv2d_fwd_ms_f32       the same convolution over up to 4 image groups of different
+ *     sizes in ONE launch: group q = seg_nhw[3q..3q+2] = (N, H, W); inputs and outputs
+ *     are the groups' [pixels][channels] rows back to back.  Replaces the per-scale
+ *     Python loop of the multi-scale GLM (modal/msc_deeplab.py:29-37 runs the same
+ *     network at scales 1, 0.5, 0.75 one after the other): 65^2 / 49^2 / 33^2 maps
+ *     alone fill 1.4 / 0.8 / 0.4 rounds of the chip's resident tiles, together 2.5.
+ *     Results are bit-identical to per-group sln_conv2d_fwd_f32 calls.
  * sln_conv2d_wgrad_f32        gw [Cout][KH][KW][Cin] fp32 (zeroed by the callee) =
  *     sum over output pixels of gz[pix][co] * x[pix @ tap][ci]; split-K over pixel
  *     ranges with fp32 atomics (summation order not deterministic).
@@ -197,6 +204,11 @@ int sln_conv2d_fwd_f32(const uint16_t *x_parts, int N, int H, int W, int Cin,
                        int stride_w, int dil_h, int dil_w, int pad_top, int pad_left, int OH, int OW,
                        const float *scale, const float *shift, const float *residual, int relu,
                        float *y, uint16_t *y_parts, sln_stream_t stream);
+int sln_conv2d_fwd_ms_f32(const uint16_t *x_parts, int nseg, const int32_t *seg_nhw, int Cin,
+                          const uint16_t *w_parts, int parts, int Cout, int KH, int KW, int stride_h,
+                          int stride_w, int dil_h, int dil_w, int pad_top, int pad_left, int pad_bottom,
+                          int pad_right, const float *scale, const float *shift, const float *residual,
+                          int relu, float *y, uint16_t *y_parts, sln_stream_t stream);
 int sln_conv2d_wgrad_f32(const uint16_t *gz_parts, int Cout, int Cout_pad, const uint16_t *x_parts,
                          int N, int H, int W, int Cin, int Cin_pad, int parts, int KH, int KW,
                          int stride_h, int stride_w, int dil_h, int dil_w, int pad_top, int pad_left,

@@ -138,6 +138,88 @@ def _fwd(xparts, N, H, W, wparts, Cout, KH, KW, stride, dil, pt, pl, OH, OW, sca
     return y
 
 
+class MultiScale(object):
+    """Image groups of different sizes (the GLM's three scales, modal/msc_deeplab.py:29-37)
+    carried as ONE flat NHWC buffer so that every layer is a single launch over all of
+    them (sln_conv2d_fwd_ms_f32).  Forward only, no autograd: the GLM is frozen.
+    segs = [(N, H, W), ...]; y = fp32 [sum N*H*W, C]; parts = bf16 [P, sum N*H*W, C_pad]."""
+
+    def __init__(self, segs, y, parts=None):
+        self.segs, self.y, self.parts = list(segs), y, parts
+
+    @classmethod
+    def pack(cls, tensors):
+        """[N_s, C, H_s, W_s] tensors -> one flat buffer (one copy per scale)."""
+        C = tensors[0].shape[1]
+        segs = [(t.shape[0], t.shape[2], t.shape[3]) for t in tensors]
+        y = torch.cat([t.detach().permute(0, 2, 3, 1).reshape(-1, C) for t in tensors], dim=0)
+        return cls(segs, y.contiguous())
+
+    def tensors(self):
+        """Per-scale logical [N, C, H, W] views (channels-last in memory)."""
+        out, m = [], 0
+        C = self.y.shape[1]
+        for N, H, W in self.segs:
+            n = N * H * W
+            out.append(self.y[m:m + n].view(N, H, W, C).permute(0, 3, 1, 2))
+            m += n
+        return out
+
+    def get_parts(self, parts):
+        if self.parts is None or self.parts.shape[0] != parts:
+            M, C = self.y.shape
+            out = torch.empty((parts, M, _pad8(C)), dtype=torch.bfloat16, device=self.y.device)
+            _lib.check(_lib.lib().sln_act_split_f32(ops._ptr(self.y), M, C, _pad8(C), parts, ops._ptr(out),
+                                                    ops._stream()), "sln_act_split_f32")
+            self.parts = out
+        return self.parts
+
+
+def conv_bn_act_ms(x, conv, bn, relu, residual, pads):
+    """conv (+bias) -> frozen-BN affine -> (+residual) -> ReLU on a MultiScale, one launch."""
+    import ctypes as C
+    from .nn_ops import bn_affine
+    if torch.is_grad_enabled() and (conv.weight.requires_grad or
+                                    (conv.bias is not None and conv.bias.requires_grad)):
+        raise RuntimeError("MultiScale convolutions are forward-only (frozen GLM)")
+    parts = PARTS_NOGRAD or PARTS
+    scale = shift = None
+    if bn is not None:
+        scale, shift = bn_affine(bn)
+    if conv.bias is not None:
+        shift = conv.bias * scale + shift if scale is not None else conv.bias
+    scale = scale.detach().contiguous() if scale is not None else None
+    shift = shift.detach().contiguous() if shift is not None else None
+    Co, Ci, KH, KW = conv.weight.shape
+    pt, pb, pl, pr = pads
+    sh, sw = conv.stride
+    dh, dw = conv.dilation
+    osegs, flops = [], 0.0
+    for N, H, W in x.segs:
+        OH = (H + pt + pb - dh * (KH - 1) - 1) // sh + 1
+        OW = (W + pl + pr - dw * (KW - 1) - 1) // sw + 1
+        osegs.append((N, OH, OW))
+        flops += 2.0 * N * OH * OW * Co * KH * KW * Ci
+    M = sum(n * h * w for n, h, w in osegs)
+    xp = x.get_parts(parts)
+    wp = _split_weights(conv.weight, parts=parts)
+    y = torch.empty((M, Co), dtype=torch.float32, device=x.y.device)
+    alloc = torch.empty if Co % 8 == 0 else torch.zeros
+    yp = alloc((parts, M, _pad8(Co)), dtype=torch.bfloat16, device=x.y.device)
+    seg = (C.c_int32 * (3 * len(x.segs)))(*[v for s_ in x.segs for v in s_])
+    res = residual.y if residual is not None else None
+    if res is not None and tuple(res.shape) != (M, Co):
+        raise ValueError("residual does not match the convolution output")
+    e0 = _prof_begin()
+    _lib.check(_lib.lib().sln_conv2d_fwd_ms_f32(
+        ops._ptr(xp), len(x.segs), seg, xp.shape[2], ops._ptr(wp), parts, Co, KH, KW, sh, sw, dh, dw,
+        pt, pl, pb, pr, ops._ptr(scale), ops._ptr(shift), ops._ptr(res), 1 if relu else 0,
+        ops._ptr(y), ops._ptr(yp), ops._stream()), "sln_conv2d_fwd_ms_f32")
+    _prof_end(e0, flops, "conv_fwd_kernel<%d>" % parts,
+              "fwd ms%s C%d->%d k%d s%d d%d" % ("+".join("%dx%d" % (h, w) for _, h, w in x.segs), Ci, Co, KH, sh, dh))
+    return MultiScale(osegs, y, yp)
+
+
 def _grad_prep(gy, y, scale, want_gu, want_bias, parts):
     gy = _nhwc(gy)
     N, C, H, W = gy.shape

@@ -200,6 +200,7 @@ __global__ __launch_bounds__(256) void split_weights_kernel(const float *__restr
 }
 
 // ------------------------------------------------------------------- forward
+#define SLN_MAX_SEG 4
 struct ConvParams {
     const __bf16 *x;      // [P][Min][Cin] parts (Min = N*H*W)
     const __bf16 *w;      // [P][Cout][Ktot]
@@ -210,8 +211,14 @@ struct ConvParams {
     __bf16 *yparts;       // [P][M][Cop] or null: the output's own bf16 parts (fused act_split)
     long x_part_stride, w_part_stride, y_part_stride;
     int Cop;
-    int N, H, W, Cin, Cout, KH, KW, sh, sw, dh, dw, pt, pl, OH, OW, relu;
+    int Cin, Cout, KH, KW, sh, sw, dh, dw, pt, pl, relu;
     int M, Ktot, cin_chunks, gm, gn;
+    // Up to SLN_MAX_SEG image groups of different sizes share one launch (the GLM's three
+    // scales): group s holds segN[s] images of segH x segW, its output rows start at
+    // seg_m0[s] and its input pixels at seg_x0[s] of the flat [pixels][C] buffers.
+    int nseg;
+    int segH[SLN_MAX_SEG], segW[SLN_MAX_SEG], segOH[SLN_MAX_SEG], segOW[SLN_MAX_SEG];
+    int seg_m0[SLN_MAX_SEG], seg_x0[SLN_MAX_SEG];
 };
 
 template <int P>
@@ -256,20 +263,26 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvParams p) {
     // each thread stages two 16-B chunks per part for A and for B:
     // row = (t>>2) + 64*i (i = 0,1), chunk = t&3 (8 bf16 each)
     const int chunk = (t & 3) * 8;
-    int a_ih0[2], a_iw0[2];
+    int a_ih0[2], a_iw0[2], a_H[2], a_W[2];
     long a_nbase[2];
     bool a_ok[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int m = m0 + (t >> 2) + 64 * i;
         a_ok[i] = m < p.M;
-        const int mm = a_ok[i] ? m : 0;
-        const int n = mm / (p.OH * p.OW);
-        const int rem = mm - n * (p.OH * p.OW);
-        const int oh = rem / p.OW, ow = rem - oh * p.OW;
+        int mm = a_ok[i] ? m : 0;
+        int sg = 0;
+        for (int q = 1; q < p.nseg; ++q)
+            if (mm >= p.seg_m0[q]) sg = q;
+        mm -= p.seg_m0[sg];
+        const int OHs = p.segOH[sg], OWs = p.segOW[sg];
+        a_H[i] = p.segH[sg]; a_W[i] = p.segW[sg];
+        const int n = mm / (OHs * OWs);
+        const int rem = mm - n * (OHs * OWs);
+        const int oh = rem / OWs, ow = rem - oh * OWs;
         a_ih0[i] = oh * p.sh - p.pt;
         a_iw0[i] = ow * p.sw - p.pl;
-        a_nbase[i] = (long)n * p.H * p.W;
+        a_nbase[i] = (long)p.seg_x0[sg] + (long)n * a_H[i] * a_W[i];
     }
     bool b_ok[2];
     const __bf16 *bptr[2];
@@ -304,8 +317,8 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvParams p) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int ih = a_ih0[i] + kh * p.dh, iw = a_iw0[i] + kw * p.dw;
-            const bool ok = a_ok[i] && cok && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
-            const long off = (a_nbase[i] + (long)ih * p.W + iw) * p.Cin + ci;
+            const bool ok = a_ok[i] && cok && ih >= 0 && ih < a_H[i] && iw >= 0 && iw < a_W[i];
+            const long off = (a_nbase[i] + (long)ih * a_W[i] + iw) * p.Cin + ci;
 #pragma unroll
             for (int pp = 0; pp < P; ++pp)
                 ra[pp][i] = ok ? *(const bf16x8 *)(p.x + pp * p.x_part_stride + off) : zero8;
@@ -657,34 +670,51 @@ extern "C" int sln_conv_grad_prep_f32(const float *gy, const float *y, const flo
     return sln_launch_status();
 }
 
-extern "C" int sln_conv2d_fwd_f32(const uint16_t *x_parts, int N, int H, int W, int Cin,
-                                  const uint16_t *w_parts, int parts, int Cout, int KH, int KW,
-                                  int stride_h, int stride_w, int dil_h, int dil_w, int pad_top,
-                                  int pad_left, int OH, int OW, const float *scale, const float *shift,
-                                  const float *residual, int relu, float *y, uint16_t *y_parts,
-                                  sln_stream_t stream) {
+extern "C" int sln_conv2d_fwd_ms_f32(const uint16_t *x_parts, int nseg, const int32_t *seg_nhw, int Cin,
+                                     const uint16_t *w_parts, int parts, int Cout, int KH, int KW,
+                                     int stride_h, int stride_w, int dil_h, int dil_w, int pad_top,
+                                     int pad_left, int pad_bottom, int pad_right, const float *scale,
+                                     const float *shift, const float *residual, int relu, float *y,
+                                     uint16_t *y_parts, sln_stream_t stream) {
     sln_enter();
-    if (!x_parts || !w_parts || !y || N < 0 || H < 1 || W < 1 || Cin < 1 || Cout < 1 || KH < 1 || KW < 1 ||
-        stride_h < 1 || stride_w < 1 || dil_h < 1 || dil_w < 1 || OH < 1 || OW < 1)
+    if (!x_parts || !w_parts || !y || !seg_nhw || nseg < 1 || nseg > SLN_MAX_SEG || Cin < 1 || Cout < 1 ||
+        KH < 1 || KW < 1 || stride_h < 1 || stride_w < 1 || dil_h < 1 || dil_w < 1)
         return SLN_ERR_INVALID_ARG;
     if (parts != 2 && parts != 3) return SLN_ERR_INVALID_ARG;
     if (Cin % 8 != 0) return SLN_ERR_UNSUPPORTED;  // 16-B vector loads along (padded) channels
-    if (N == 0) return SLN_OK;
     ConvParams p;
+    long M = 0, Min = 0;
+    for (int q = 0; q < nseg; ++q) {
+        const int N = seg_nhw[3 * q], H = seg_nhw[3 * q + 1], W = seg_nhw[3 * q + 2];
+        if (N < 0 || H < 1 || W < 1) return SLN_ERR_INVALID_ARG;
+        const int OH = (H + pad_top + pad_bottom - dil_h * (KH - 1) - 1) / stride_h + 1;
+        const int OW = (W + pad_left + pad_right - dil_w * (KW - 1) - 1) / stride_w + 1;
+        if (OH < 1 || OW < 1) return SLN_ERR_INVALID_ARG;
+        if (M > 2147483647L - BM || Min > 2147483647L) return SLN_ERR_UNSUPPORTED;
+        p.segH[q] = H; p.segW[q] = W; p.segOH[q] = OH; p.segOW[q] = OW;
+        p.seg_m0[q] = (int)M; p.seg_x0[q] = (int)Min;
+        M += (long)N * OH * OW;
+        Min += (long)N * H * W;
+    }
+    for (int q = nseg; q < SLN_MAX_SEG; ++q) {
+        p.segH[q] = p.segW[q] = p.segOH[q] = p.segOW[q] = 1;
+        p.seg_m0[q] = 2147483647; p.seg_x0[q] = 0;
+    }
+    if (M == 0) return SLN_OK;
+    if (M > 2147483647L - BM || Min > 2147483647L) return SLN_ERR_UNSUPPORTED;
+    p.nseg = nseg;
     p.x = (const __bf16 *)x_parts; p.w = (const __bf16 *)w_parts;
     p.scale = scale; p.shift = shift; p.residual = residual; p.y = y;
     p.yparts = (__bf16 *)y_parts;
     p.Cop = (Cout + 7) / 8 * 8;
-    p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW;
+    p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW;
     p.sh = stride_h; p.sw = stride_w; p.dh = dil_h; p.dw = dil_w; p.pt = pad_top; p.pl = pad_left;
-    p.OH = OH; p.OW = OW; p.relu = relu;
-    const long M = (long)N * OH * OW;
-    if (M > 2147483647L - BM) return SLN_ERR_UNSUPPORTED;
+    p.relu = relu;
     p.M = (int)M;
     p.Ktot = KH * KW * Cin;
-    p.x_part_stride = (long)N * H * W * Cin;
+    p.x_part_stride = Min * Cin;
     p.w_part_stride = (long)Cout * p.Ktot;
-    p.y_part_stride = (long)N * OH * OW * p.Cop;
+    p.y_part_stride = M * p.Cop;
     p.cin_chunks = sln_div_up(Cin, BK);
     p.gm = sln_div_up(M, BM);
     p.gn = sln_div_up(Cout, BN);
@@ -695,6 +725,26 @@ extern "C" int sln_conv2d_fwd_f32(const uint16_t *x_parts, int N, int H, int W, 
     else
         hipLaunchKernelGGL(conv_fwd_kernel<3>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, p);
     return sln_launch_status();
+}
+
+extern "C" int sln_conv2d_fwd_f32(const uint16_t *x_parts, int N, int H, int W, int Cin,
+                                  const uint16_t *w_parts, int parts, int Cout, int KH, int KW,
+                                  int stride_h, int stride_w, int dil_h, int dil_w, int pad_top,
+                                  int pad_left, int OH, int OW, const float *scale, const float *shift,
+                                  const float *residual, int relu, float *y, uint16_t *y_parts,
+                                  sln_stream_t stream) {
+    // one image group; the caller's OH/OW fix the bottom/right padding
+    if (N < 0 || H < 1 || W < 1 || OH < 1 || OW < 1 || KH < 1 || KW < 1 || stride_h < 1 || stride_w < 1 ||
+        dil_h < 1 || dil_w < 1) {
+        sln_enter();
+        return SLN_ERR_INVALID_ARG;
+    }
+    const int32_t seg[3] = {N, H, W};
+    const int pad_bottom = (OH - 1) * stride_h + dil_h * (KH - 1) + 1 - H - pad_top;
+    const int pad_right = (OW - 1) * stride_w + dil_w * (KW - 1) + 1 - W - pad_left;
+    return sln_conv2d_fwd_ms_f32(x_parts, 1, seg, Cin, w_parts, parts, Cout, KH, KW, stride_h, stride_w,
+                                 dil_h, dil_w, pad_top, pad_left, pad_bottom, pad_right, scale, shift,
+                                 residual, relu, y, y_parts, stream);
 }
 
 extern "C" int sln_conv2d_wgrad_f32(const uint16_t *gz_parts, int Cout, int Cout_pad,

@@ -71,13 +71,15 @@ def conv_bn_act(x, conv, bn=None, relu=False, residual=None, same=False):
     bn:   frozen nn.BatchNorm2d or None.  same: apply SamePad2d first."""
     stride, dilation = conv.stride, conv.dilation
     kh, kw = conv.kernel_size
-    if same:
+    if same:   # (never with a MultiScale: the GLM uses symmetric padding)
         pt, pb = same_pad(x.shape[2], kh, stride[0])
         pl, pr = same_pad(x.shape[3], kw, stride[1])
     else:
         pt = pb = conv.padding[0]
         pl = pr = conv.padding[1]
     hip = _hip_conv() if BACKEND in ("auto", "hip") else None
+    if hip is not None and isinstance(x, hip.MultiScale):   # all GLM scales in one launch
+        return hip.conv_bn_act_ms(x, conv, bn, relu, residual, (pt, pb, pl, pr))
     if hip is not None and x.is_cuda and hip.supports(conv, x):
         return hip.conv_bn_act(x, conv, bn, relu, residual, (pt, pb, pl, pr))
     if BACKEND == "hip" and conv.in_channels >= 8:   # (3-channel stems are aten by design)

@@ -126,3 +126,82 @@ def test_module_dispatch_uses_hip_backend():
     nn_ops.BACKEND = "auto"
     for a, b in zip(outs["hip"], outs["torch"]):
         assert torch.allclose(a, b, rtol=1e-4, atol=1e-5 * b.abs().max().item())
+
+
+# ------------------------------------------------- multi-scale (one launch for all GLM scales)
+@pytest.mark.parametrize("case", [
+    # Cin, Cout, k, stride, dil, pad, relu, with_bn, with_res
+    (64, 256, 1, 1, 1, 0, False, True, True),
+    (72, 182, 3, 1, 6, 6, False, False, True),    # ASPP-like: bias, Cout not a multiple of 8, running sum
+    (64, 64, 3, 1, 2, 2, True, True, False),
+    (128, 96, 1, 2, 1, 0, True, True, False),     # strided 1x1 (layer3 block1)
+])
+def test_multiscale_conv_is_bit_identical_to_per_scale_launches(case):
+    """sln_conv2d_fwd_ms_f32 over three image groups == three sln_conv2d_fwd_f32 launches,
+    bit for bit (same products, same k order per output element)."""
+    from sln_amodal_amd import conv_hip, nn_ops
+    Cin, Cout, k, stride, dil, pad, relu, with_bn, with_res = case
+    g = torch.Generator().manual_seed(Cin * 1000 + Cout)
+    conv = nn.Conv2d(Cin, Cout, k, stride, pad, dil, bias=not with_bn).cuda()
+    bn = nn.BatchNorm2d(Cout).cuda().eval() if with_bn else None
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) * 0.05)
+        if conv.bias is not None:
+            conv.bias.copy_(torch.randn(Cout, generator=g) * 0.1)
+        if bn is not None:
+            bn.weight.copy_(torch.rand(Cout, generator=g) + 0.5)
+            bn.bias.copy_(torch.randn(Cout, generator=g) * 0.1)
+            bn.running_mean.copy_(torch.randn(Cout, generator=g) * 0.1)
+            bn.running_var.copy_(torch.rand(Cout, generator=g) + 0.5)
+    sizes = [(2, 33, 33), (2, 17, 17), (2, 25, 25)]     # 2 images per scale; tiles straddle the groups
+    xs = [torch.randn(n, Cin, h, w, generator=g).cuda().contiguous(memory_format=torch.channels_last)
+          for n, h, w in sizes]
+    with torch.no_grad():
+        outs_seq, res_seq = [], []
+        for x in xs:
+            r = None
+            if with_res:
+                oh = (x.shape[2] + 2 * pad - dil * (k - 1) - 1) // stride + 1
+                r = torch.randn(x.shape[0], Cout, oh, oh, generator=g).cuda().contiguous(
+                    memory_format=torch.channels_last)
+            res_seq.append(r)
+            outs_seq.append(nn_ops.conv_bn_act(x, conv, bn, relu=relu, residual=r))
+        ms = conv_hip.MultiScale.pack(xs)
+        res = conv_hip.MultiScale.pack(res_seq) if with_res else None
+        out = nn_ops.conv_bn_act(ms, conv, bn, relu=relu, residual=res)
+    assert isinstance(out, conv_hip.MultiScale)
+    for a, b in zip(out.tensors(), outs_seq):
+        assert a.shape == b.shape
+        assert torch.equal(a, b)
+    # the fused output parts feed the next layer: they must equal a fresh split of y
+    fresh = conv_hip.MultiScale(out.segs, out.y).get_parts(out.parts.shape[0])
+    assert torch.equal(out.parts[:, :, :Cout], fresh[:, :, :Cout])
+    assert not out.parts[:, :, Cout:].any()
+
+
+def test_msc_packed_forward_equals_sequential_scales():
+    """The GLM wrapper with all scales packed per layer returns exactly what the
+    reference-order loop over the scales returns (modal/msc_deeplab.py:29-45)."""
+    from sln_amodal_amd.modal import msc_deeplab
+    from sln_amodal_amd.modal.deeplabv2 import DeepLabV2
+    from tests._util import key_init_
+    net = msc_deeplab.MSC(DeepLabV2(n_classes=21, n_blocks=[1, 2, 2, 1], atrous_rates=[2, 4, 6, 8]),
+                          scales=[0.5, 0.75]).cuda()
+    key_init_(net)
+    net.train()                      # returns every scale's logits as well as the max
+    for m in net.modules():
+        if isinstance(m, nn.BatchNorm2d):
+            m.eval()
+    x = torch.randn(2, 3, 129, 129, generator=torch.Generator().manual_seed(3)).cuda()
+    x = x.contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        msc_deeplab.PACK_SCALES = True
+        try:
+            packed = net(x)
+            msc_deeplab.PACK_SCALES = False
+            seq = net(x)
+        finally:
+            msc_deeplab.PACK_SCALES = True
+    assert len(packed) == len(seq) == 4
+    for a, b in zip(packed, seq):
+        assert a.shape == b.shape and torch.equal(a, b)

@@ -33,17 +33,14 @@ def main(batch=16, dim=1024):
     for _ in range(2):
         model.train_step(b, opt, None)
     torch.cuda.synchronize()
-    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=False, record_shapes=True) as prof:
         model.train_step(b, opt, None)
         torch.cuda.synchronize()
-    rows = sorted(prof.key_averages(group_by_stack_n=8), key=lambda e: -e.self_device_time_total)
-    for e in rows[:60]:
-        if e.self_device_time_total < 250:   # us
-            break
-        print("%9.2f ms  n=%5d  %s" % (e.self_device_time_total / 1e3, e.count, e.key[:90]))
-        for fr in e.stack[:8]:
-            if "sln_amodal_amd" in fr or "bench.py" in fr:
-                print("              ", fr[-120:])
+    rows = sorted(prof.key_averages(group_by_input_shape=True), key=lambda e: -e.self_device_time_total)
+    want = ("aten::add", "aten::copy_", "aten::add_", "aten::mul", "aten::fill_", "aten::sum", "aten::cat",
+            "aten::clone", "aten::contiguous")
+    for e in [r for r in rows if r.key in want and r.self_device_time_total >= 100][:40]:
+        print("%9.2f ms  n=%5d  %-14s %s" % (e.self_device_time_total / 1e3, e.count, e.key, str(e.input_shapes)[:150]))
 
 
 if __name__ == "__main__":
