@@ -21,6 +21,8 @@ class _NoCache(dict):
     pass
 
 
+LINK_SHORTCUT_GRAD = os.environ.get("SLN_LINK_SHORTCUT_GRAD", "1") != "0"   # A/B switch
+LINK_STATS = [0, 0]   # shortcut gradients handed over by tails / consumed by heads
 FUSE_OUTPUT_SPLIT = True   # conv epilogue writes the output's parts (skips the next act_split)
 _cache = _NoCache()   # kept for tools that call _cache.clear(); caches live on the tensors
 
@@ -239,7 +241,7 @@ def _grad_prep(gy, y, scale, want_gu, want_bias, parts):
 
 class _ConvFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, bn_scale, bn_shift, residual, relu, stride, dil, pads):
+    def forward(ctx, x, weight, bias, bn_scale, bn_shift, residual, relu, stride, dil, pads, link=None):
         parts = PARTS
         if PARTS_NOGRAD and not any(ctx.needs_input_grad):
             parts = PARTS_NOGRAD
@@ -260,6 +262,18 @@ class _ConvFn(torch.autograd.Function):
         y = _fwd(xp, N, H, W, _split_weights(weight, parts=parts), Co, KH, KW, stride, dil, pt, pl,
                  OH, OW, scale, shift, res, relu, cin=Ci, out_parts=FUSE_OUTPUT_SPLIT)
         need_w = ctx.needs_input_grad[1]
+        # identity-shortcut link (Bottleneck.forward): the conv that consumes x (head) and the
+        # conv that adds the same x as its residual (tail) share a dict, so that the tail's
+        # gradient for x is added inside the head's data-gradient epilogue instead of by a
+        # separate autograd accumulation pass over the whole activation.
+        ctx.link_head = ctx.link_tail = None
+        if link is not None:
+            if residual is None:
+                if stride == (1, 1):
+                    link["head_wants_dx"] = bool(ctx.needs_input_grad[0])
+                    ctx.link_head = link
+            elif link.get("head_wants_dx") and ctx.needs_input_grad[5]:
+                ctx.link_tail = link
         ctx.save_for_backward(xp if need_w else None, weight, scale, y if relu else None)
         ctx.cfg = (stride, dil, pads, relu, bias is not None, residual is not None, (N, Ci, H, W),
                    parts)
@@ -277,12 +291,22 @@ class _ConvFn(torch.autograd.Function):
         want_res = has_res and ctx.needs_input_grad[5]
         want_bias = has_bias and ctx.needs_input_grad[2]
         gz, g_res, g_bias = _grad_prep(gy, y, scale, want_res, want_bias, parts)
+        if ctx.link_tail is not None and g_res is not None:
+            ctx.link_tail["idgrad"] = g_res     # consumed by the head's data gradient below
+            g_res = None
+            LINK_STATS[0] += 1
+        id_grad = ctx.link_head.pop("idgrad", None) if ctx.link_head is not None else None
         gx = gw = None
+        if id_grad is not None:
+            LINK_STATS[1] += 1
+        if id_grad is not None and not need_x:
+            raise RuntimeError("identity-shortcut gradient was handed over but dx is not computed")
         if need_x:
             wt = _split_weights(weight, flip_swap=True, parts=parts)
             if stride == (1, 1):
                 gx = _fwd(gz, N, OH, OW, wt, Ci, KH, KW, (1, 1), dil, dil[0] * (KH - 1) - pt,
-                          dil[1] * (KW - 1) - pl, H, W, None, None, None, False, cin=Co)
+                          dil[1] * (KW - 1) - pl, H, W, None, None,
+                          _nhwc(id_grad) if id_grad is not None else None, False, cin=Co)
             elif KH == 1 and KW == 1 and pads == (0, 0, 0, 0):
                 # strided 1x1: the gradient lives on the stride lattice, zero elsewhere
                 small = _fwd(gz, N, OH, OW, wt, Ci, 1, 1, (1, 1), (1, 1), 0, 0, OH, OW, None, None,
@@ -301,13 +325,14 @@ class _ConvFn(torch.autograd.Function):
             _prof_end(e0, 2.0 * N * OH * OW * Co * KH * KW * Ci, "conv_wgrad_kernel<%d>" % parts,
                       "wgrad N%d %dx%d C%d->%d k%d s%d d%d" % (N, H, W, Ci, Co, KH, stride[0], dil[0]))
             gw = gw_t.permute(0, 3, 1, 2)  # logical [Co,Ci,KH,KW]
-        return gx, gw, g_bias, None, None, g_res, None, None, None, None
+        return gx, gw, g_bias, None, None, g_res, None, None, None, None, None
 
 
-def conv_bn_act(x, conv, bn, relu, residual, pads, weight=None):
+def conv_bn_act(x, conv, bn, relu, residual, pads, weight=None, link=None):
     from .nn_ops import bn_affine
     scale = shift = None
     if bn is not None:
         scale, shift = bn_affine(bn)
     return _ConvFn.apply(x, conv.weight if weight is None else weight, conv.bias, scale, shift,
-                         residual, bool(relu), tuple(conv.stride), tuple(conv.dilation), tuple(pads))
+                         residual, bool(relu), tuple(conv.stride), tuple(conv.dilation), tuple(pads),
+                         link if LINK_SHORTCUT_GRAD else None)

@@ -219,12 +219,12 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         conv = nn_ops.conv_bn_act
-        residual = x
+        residual, link = x, {}
         if self.downsample is not None:
-            residual = conv(x, self.downsample[0], self.downsample[1])
-        out = conv(x, self.conv1, self.bn1, relu=True)
+            residual, link = conv(x, self.downsample[0], self.downsample[1]), None
+        out = conv(x, self.conv1, self.bn1, relu=True, link=link)
         out = conv(out, self.conv2, self.bn2, relu=True, same=True)
-        return conv(out, self.conv3, self.bn3, relu=True, residual=residual)
+        return conv(out, self.conv3, self.bn3, relu=True, residual=residual, link=link)
 
 
 class _Stem(nn.Sequential):

@@ -205,3 +205,45 @@ def test_msc_packed_forward_equals_sequential_scales():
     assert len(packed) == len(seq) == 4
     for a, b in zip(packed, seq):
         assert a.shape == b.shape and torch.equal(a, b)
+
+
+def test_identity_shortcut_gradient_link_matches_autograd_accumulation():
+    """Bottleneck blocks with identity shortcuts hand the shortcut's gradient to conv1's
+    data-gradient epilogue (conv_hip link) instead of letting autograd add two full-size
+    tensors.  One fp32 addition per element either way: dx must be bit-identical; weight
+    gradients differ only by the atomics' summation order."""
+    from sln_amodal_amd import conv_hip
+    from sln_amodal_amd.modal.modals import Bottleneck
+    from tests._util import key_init_
+    down = nn.Sequential(nn.Conv2d(64, 128, kernel_size=1, stride=1), nn.BatchNorm2d(128, eps=0.001))
+    net = nn.Sequential(Bottleneck(64, 32, 1, down), Bottleneck(128, 32), Bottleneck(128, 32)).cuda()
+    key_init_(net)
+    for m in net.modules():
+        if isinstance(m, nn.BatchNorm2d):
+            m.eval()
+            m.weight.requires_grad = m.bias.requires_grad = False
+    g = torch.Generator().manual_seed(11)
+    x0 = torch.randn(2, 64, 24, 24, generator=g).cuda().contiguous(memory_format=torch.channels_last)
+    up = torch.randn(2, 128, 24, 24, generator=g).cuda().contiguous(memory_format=torch.channels_last)
+    res = {}
+    saved = conv_hip.LINK_SHORTCUT_GRAD
+    try:
+        for mode in (True, False):
+            conv_hip.LINK_SHORTCUT_GRAD = mode
+            conv_hip.LINK_STATS[:] = [0, 0]
+            x = x0.clone().requires_grad_(True)
+            net.zero_grad(set_to_none=True)
+            y = net(x)
+            y.backward(up)
+            # two identity blocks: both hand-overs happen and are consumed -- or none when off
+            assert conv_hip.LINK_STATS == ([2, 2] if mode else [0, 0])
+            res[mode] = (y.detach().clone(), x.grad.clone(),
+                         {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None})
+    finally:
+        conv_hip.LINK_SHORTCUT_GRAD = saved
+    assert torch.equal(res[True][0], res[False][0])
+    assert torch.equal(res[True][1], res[False][1])
+    assert res[True][2].keys() == res[False][2].keys() and len(res[True][2]) >= 20
+    for k in res[True][2]:
+        a, b = res[True][2][k], res[False][2][k]
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-5 * float(b.abs().max()) + 1e-7), k
