@@ -187,6 +187,13 @@ int sln_pyramid_crop_bwd_f32(const float *grads, int g_cstride, int g_coffset, c
  *     network at scales 1, 0.5, 0.75 one after the other): 65^2 / 49^2 / 33^2 maps
  *     alone fill 1.4 / 0.8 / 0.4 rounds of the chip's resident tiles, together 2.5.
  *     Results are bit-identical to per-group sln_conv2d_fwd_f32 calls.
+ *     Epilogue extras used by the backward pass, where this kernel computes a data
+ *     gradient whose only reader is the previous layer's gradient preparation
+ *     (sln_conv_grad_prep_f32): mask [M][Cout] (optional) zeroes every output element
+ *     whose mask value is not > 0 (the previous layer's ReLU, after scale/shift/
+ *     residual/relu); y may be NULL when only y_parts are wanted; colsum [Cout]
+ *     (optional, zeroed by the callee) receives the per-channel sums of the output
+ *     (the previous layer's bias gradient; fp32 atomics).
  * sln_conv2d_wgrad_f32        gw [Cout][KH][KW][Cin] fp32 (zeroed by the callee) =
  *     sum over output pixels of gz[pix][co] * x[pix @ tap][ci]; split-K over pixel
  *     ranges with fp32 atomics (summation order not deterministic).
@@ -208,7 +215,8 @@ int sln_conv2d_fwd_ms_f32(const uint16_t *x_parts, int nseg, const int32_t *seg_
                           const uint16_t *w_parts, int parts, int Cout, int KH, int KW, int stride_h,
                           int stride_w, int dil_h, int dil_w, int pad_top, int pad_left, int pad_bottom,
                           int pad_right, const float *scale, const float *shift, const float *residual,
-                          int relu, float *y, uint16_t *y_parts, sln_stream_t stream);
+                          int relu, const float *mask, float *y, uint16_t *y_parts, float *colsum,
+                          sln_stream_t stream);
 int sln_conv2d_wgrad_f32(const uint16_t *gz_parts, int Cout, int Cout_pad, const uint16_t *x_parts,
                          int N, int H, int W, int Cin, int Cin_pad, int parts, int KH, int KW,
                          int stride_h, int stride_w, int dil_h, int dil_w, int pad_top, int pad_left,

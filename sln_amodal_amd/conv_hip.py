@@ -22,6 +22,8 @@ class _NoCache(dict):
 
 
 LINK_SHORTCUT_GRAD = os.environ.get("SLN_LINK_SHORTCUT_GRAD", "1") != "0"   # A/B switch
+CHAIN_GRAD_PREP = os.environ.get("SLN_CHAIN_GRAD_PREP", "1") != "0"            # A/B switch
+CHAIN_STATS = [0, 0]  # prepared gradients handed over by consumers / used by producers
 LINK_STATS = [0, 0]   # shortcut gradients handed over by tails / consumed by heads
 FUSE_OUTPUT_SPLIT = True   # conv epilogue writes the output's parts (skips the next act_split)
 _cache = _NoCache()   # kept for tools that call _cache.clear(); caches live on the tensors
@@ -121,22 +123,33 @@ def _prof_end(e0, flops, name, shape=""):
 
 
 def _fwd(xparts, N, H, W, wparts, Cout, KH, KW, stride, dil, pt, pl, OH, OW, scale, shift, residual,
-         relu, cin=None, out_parts=False):
-    y = torch.empty((N, OH, OW, Cout), dtype=torch.float32, device=xparts.device).permute(0, 3, 1, 2)
+         relu, cin=None, out_parts=False, mask=None, want_y=True, want_colsum=False):
+    """One launch of conv_fwd_kernel.  mask / want_y=False / want_colsum: the epilogue extras of
+    sln_conv2d_fwd_ms_f32 (a data gradient that is consumed only as the previous layer's
+    prepared gradient).  Returns y, or (y_or_None, parts, colsum) when any extra is used."""
+    import ctypes as C
+    dev = xparts.device
+    y = torch.empty((N, OH, OW, Cout), dtype=torch.float32, device=dev).permute(0, 3, 1, 2) if want_y else None
     yp = None
     if out_parts:   # the epilogue also emits the output's bf16 parts (next layer's operand)
         alloc = torch.empty if Cout % 8 == 0 else torch.zeros   # pad channels must be zero
-        yp = alloc((wparts.shape[0], N * OH * OW, _pad8(Cout)), dtype=torch.bfloat16, device=xparts.device)
+        yp = alloc((wparts.shape[0], N * OH * OW, _pad8(Cout)), dtype=torch.bfloat16, device=dev)
+    cs = torch.empty((Cout,), dtype=torch.float32, device=dev) if want_colsum else None
+    pb = (OH - 1) * stride[0] + dil[0] * (KH - 1) + 1 - H - pt
+    pr = (OW - 1) * stride[1] + dil[1] * (KW - 1) + 1 - W - pl
+    seg = (C.c_int32 * 3)(N, H, W)
     e0 = _prof_begin()
-    _lib.check(_lib.lib().sln_conv2d_fwd_f32(
-        ops._ptr(xparts), N, H, W, xparts.shape[2], ops._ptr(wparts), wparts.shape[0], Cout, KH, KW,
-        stride[0], stride[1], dil[0], dil[1], pt, pl, OH, OW, ops._ptr(scale), ops._ptr(shift),
-        ops._ptr(residual), 1 if relu else 0, ops._ptr(y), ops._ptr(yp), ops._stream()),
-        "sln_conv2d_fwd_f32")
-    if yp is not None:
+    _lib.check(_lib.lib().sln_conv2d_fwd_ms_f32(
+        ops._ptr(xparts), 1, seg, xparts.shape[2], ops._ptr(wparts), wparts.shape[0], Cout, KH, KW,
+        stride[0], stride[1], dil[0], dil[1], pt, pl, pb, pr, ops._ptr(scale), ops._ptr(shift),
+        ops._ptr(residual), 1 if relu else 0, ops._ptr(mask), ops._ptr(y), ops._ptr(yp), ops._ptr(cs),
+        ops._stream()), "sln_conv2d_fwd_ms_f32")
+    if yp is not None and y is not None:
         y._sln_parts = ((y._version, wparts.shape[0]), yp)
     _prof_end(e0, 2.0 * N * OH * OW * Cout * KH * KW * (cin or wparts.shape[4]), "conv_fwd_kernel<%d>" % wparts.shape[0],
               "fwd N%d %dx%d C%d->%d k%d s%d d%d" % (N, H, W, cin or wparts.shape[4], Cout, KH, stride[0], dil[0]))
+    if mask is not None or not want_y or want_colsum:
+        return y, yp, cs
     return y
 
 
@@ -215,8 +228,8 @@ def conv_bn_act_ms(x, conv, bn, relu, residual, pads):
     e0 = _prof_begin()
     _lib.check(_lib.lib().sln_conv2d_fwd_ms_f32(
         ops._ptr(xp), len(x.segs), seg, xp.shape[2], ops._ptr(wp), parts, Co, KH, KW, sh, sw, dh, dw,
-        pt, pl, pb, pr, ops._ptr(scale), ops._ptr(shift), ops._ptr(res), 1 if relu else 0,
-        ops._ptr(y), ops._ptr(yp), ops._stream()), "sln_conv2d_fwd_ms_f32")
+        pt, pl, pb, pr, ops._ptr(scale), ops._ptr(shift), ops._ptr(res), 1 if relu else 0, None,
+        ops._ptr(y), ops._ptr(yp), None, ops._stream()), "sln_conv2d_fwd_ms_f32")
     _prof_end(e0, flops, "conv_fwd_kernel<%d>" % parts,
               "fwd ms%s C%d->%d k%d s%d d%d" % ("+".join("%dx%d" % (h, w) for _, h, w in x.segs), Ci, Co, KH, sh, dh))
     return MultiScale(osegs, y, yp)
@@ -241,7 +254,8 @@ def _grad_prep(gy, y, scale, want_gu, want_bias, parts):
 
 class _ConvFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, bn_scale, bn_shift, residual, relu, stride, dil, pads, link=None):
+    def forward(ctx, x, weight, bias, bn_scale, bn_shift, residual, relu, stride, dil, pads, link=None,
+                chain_in=None, chain_out=None):
         parts = PARTS
         if PARTS_NOGRAD and not any(ctx.needs_input_grad):
             parts = PARTS_NOGRAD
@@ -274,14 +288,33 @@ class _ConvFn(torch.autograd.Function):
                     ctx.link_head = link
             elif link.get("head_wants_dx") and ctx.needs_input_grad[5]:
                 ctx.link_tail = link
-        ctx.save_for_backward(xp if need_w else None, weight, scale, y if relu else None)
+        # producer -> sole-consumer chain (conv1 -> conv2 -> conv3 of a bottleneck): the
+        # consumer's data gradient is read by nothing but this layer's gradient preparation
+        # (ReLU mask x BN scale -> bf16 parts, bias sums), so the consumer's dgrad epilogue
+        # does that preparation itself and hands over the parts; the fp32 gradient is never
+        # written and sln_conv_grad_prep_f32 is not launched for this layer.
+        ctx.chain_in = ctx.chain_out = None
+        if CHAIN_GRAD_PREP and chain_out is not None and residual is None and \
+                (ctx.needs_input_grad[0] or need_w):
+            chain_out.update(active=True, scale=scale, relu=bool(relu), parts=parts,
+                             want_bias=bool(bias is not None and ctx.needs_input_grad[2]))
+            ctx.chain_out = chain_out
+        if CHAIN_GRAD_PREP and chain_in is not None and chain_in.get("active") and stride == (1, 1) and \
+                ctx.needs_input_grad[0] and chain_in["parts"] == parts:
+            chain_in["consumer"] = True
+            ctx.chain_in = chain_in
+        # the producer's ReLU mask is this layer's own input: saved here as an input tensor
+        # (the shared dict must not hold activations: a dict -> output -> grad_fn -> ctx -> dict
+        # cycle through the C++ graph would never be collected)
+        mask_x = x if (ctx.chain_in is not None and chain_in["relu"]) else None
+        ctx.save_for_backward(xp if need_w else None, weight, scale, y if relu else None, mask_x)
         ctx.cfg = (stride, dil, pads, relu, bias is not None, residual is not None, (N, Ci, H, W),
                    parts)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        xp, weight, scale, y = ctx.saved_tensors
+        xp, weight, scale, y, mask_x = ctx.saved_tensors
         stride, dil, pads, relu, has_bias, has_res, xshape, parts = ctx.cfg
         pt, pb, pl, pr = pads
         Co, Ci, KH, KW = weight.shape
@@ -290,7 +323,16 @@ class _ConvFn(torch.autograd.Function):
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         want_res = has_res and ctx.needs_input_grad[5]
         want_bias = has_bias and ctx.needs_input_grad[2]
-        gz, g_res, g_bias = _grad_prep(gy, y, scale, want_res, want_bias, parts)
+        ch = ctx.chain_out
+        if ch is not None and ch.get("consumer"):
+            if "gz" not in ch or gy.stride() != (0, 0, 0, 0):
+                raise RuntimeError("chained gradient: the consumer's dgrad did not run, or the "
+                                   "activation has a second consumer")
+            gz, g_res = ch.pop("gz"), None
+            g_bias = ch.pop("gbias") if want_bias else None
+            CHAIN_STATS[1] += 1
+        else:
+            gz, g_res, g_bias = _grad_prep(gy, y, scale, want_res, want_bias, parts)
         if ctx.link_tail is not None and g_res is not None:
             ctx.link_tail["idgrad"] = g_res     # consumed by the head's data gradient below
             g_res = None
@@ -303,7 +345,16 @@ class _ConvFn(torch.autograd.Function):
             raise RuntimeError("identity-shortcut gradient was handed over but dx is not computed")
         if need_x:
             wt = _split_weights(weight, flip_swap=True, parts=parts)
-            if stride == (1, 1):
+            if ctx.chain_in is not None:
+                ci = ctx.chain_in
+                _, gz_up, gb_up = _fwd(gz, N, OH, OW, wt, Ci, KH, KW, (1, 1), dil, dil[0] * (KH - 1) - pt,
+                                       dil[1] * (KW - 1) - pl, H, W, ci["scale"], None, None, False, cin=Co,
+                                       out_parts=True, mask=_nhwc(mask_x) if mask_x is not None else None,
+                                       want_y=False, want_colsum=ci["want_bias"])
+                ci["gz"], ci["gbias"] = gz_up, gb_up
+                gx = _dummy_grad(gy.device).expand(N, Ci, H, W)   # never read: see chain_out above
+                CHAIN_STATS[0] += 1
+            elif stride == (1, 1):
                 gx = _fwd(gz, N, OH, OW, wt, Ci, KH, KW, (1, 1), dil, dil[0] * (KH - 1) - pt,
                           dil[1] * (KW - 1) - pl, H, W, None, None,
                           _nhwc(id_grad) if id_grad is not None else None, False, cin=Co)
@@ -325,14 +376,24 @@ class _ConvFn(torch.autograd.Function):
             _prof_end(e0, 2.0 * N * OH * OW * Co * KH * KW * Ci, "conv_wgrad_kernel<%d>" % parts,
                       "wgrad N%d %dx%d C%d->%d k%d s%d d%d" % (N, H, W, Ci, Co, KH, stride[0], dil[0]))
             gw = gw_t.permute(0, 3, 1, 2)  # logical [Co,Ci,KH,KW]
-        return gx, gw, g_bias, None, None, g_res, None, None, None, None, None
+        return gx, gw, g_bias, None, None, g_res, None, None, None, None, None, None, None
 
 
-def conv_bn_act(x, conv, bn, relu, residual, pads, weight=None, link=None):
+_DUMMY = {}
+
+
+def _dummy_grad(device):
+    d = _DUMMY.get(device)
+    if d is None:
+        d = _DUMMY[device] = torch.zeros(1, dtype=torch.float32, device=device)
+    return d
+
+
+def conv_bn_act(x, conv, bn, relu, residual, pads, weight=None, link=None, chain_in=None, chain_out=None):
     from .nn_ops import bn_affine
     scale = shift = None
     if bn is not None:
         scale, shift = bn_affine(bn)
     return _ConvFn.apply(x, conv.weight if weight is None else weight, conv.bias, scale, shift,
                          residual, bool(relu), tuple(conv.stride), tuple(conv.dilation), tuple(pads),
-                         link if LINK_SHORTCUT_GRAD else None)
+                         link if LINK_SHORTCUT_GRAD else None, chain_in, chain_out)

@@ -117,7 +117,16 @@ __device__ __forceinline__ void grad_prep_emit(float g[4], long m, int c, int C,
             for (int j = 0; j < 4; ++j)
                 if (c + j < C) gu[m * C + c + j] = g[j];
     }
-    for (int j = 0; j < 4; ++j) { g[j] *= sc[j]; acc[j] += g[j]; }
+    // The product must be rounded to fp32 BEFORE it is split.  With contraction allowed the
+    // compiler fuses it into split4's first residual subtraction (v_pk_fma_f32 g, sc, -h0 in
+    // the ISA; __fmul_rn is a plain multiply on this toolchain and does not prevent it), and the
+    // parts then encode the unrounded product -- 1 ulp away from what the conv epilogue's fused
+    // preparation (mask/colsum mode) produces for the same gradient.
+    {
+#pragma clang fp contract(off)
+        for (int j = 0; j < 4; ++j) g[j] = g[j] * sc[j];
+    }
+    for (int j = 0; j < 4; ++j) acc[j] += g[j];
     bf16x4 ps[P];
     split4<P>(make_float4(g[0], g[1], g[2], g[3]), ps);
 #pragma unroll
@@ -207,8 +216,10 @@ struct ConvParams {
     const float *scale;   // [Cout] or null (=1)
     const float *shift;   // [Cout] or null (=0)
     const float *residual;  // [M][Cout] or null
-    float *y;             // [M][Cout]
+    float *y;             // [M][Cout], or null when only the parts are wanted
     __bf16 *yparts;       // [P][M][Cop] or null: the output's own bf16 parts (fused act_split)
+    const float *mask;    // [M][Cout] or null: output elements whose mask value is not > 0 become 0
+    float *colsum;        // [Cout] or null: += per-channel sums of the output (bias gradient)
     long x_part_stride, w_part_stride, y_part_stride;
     int Cop;
     int Cin, Cout, KH, KW, sh, sw, dh, dw, pt, pl, relu;
@@ -252,6 +263,8 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvParams p) {
     typedef __bf16 (*tile_t)[BM][BK];
     tile_t sA = (tile_t)smem;
     tile_t sB = (tile_t)(smem + P * BM * BK * 2);
+    __shared__ float s_colsum[BN];   // per-block column sums of the output (colsum mode)
+    if (threadIdx.x < BN) s_colsum[threadIdx.x] = 0.f;   // ordered by the k-loop's barriers
 
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
@@ -412,7 +425,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvParams p) {
                 }
             // all residual rows of this half are requested before the first store: the
             // loads cannot be moved across the y stores by the compiler (may alias)
-            float4 res4[8];
+            float4 res4[8], msk4[8];
             if (vec_ok && p.residual) {
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
@@ -421,6 +434,15 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvParams p) {
                                       : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
             }
+            if (vec_ok && p.mask) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int m = m0 + h * 64 + (t >> 5) + 8 * q;
+                    msk4[q] = m < p.M ? *(const float4 *)(p.mask + (long)m * p.Cout + c)
+                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+            float csum[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const int row = (t >> 5) + 8 * q;
@@ -439,17 +461,27 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvParams p) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
                     }
-                    *(float4 *)(p.y + o) = make_float4(v[0], v[1], v[2], v[3]);
+                    if (p.mask) {
+                        const float4 k4 = msk4[q];
+                        if (!(k4.x > 0.f)) v[0] = 0.f;
+                        if (!(k4.y > 0.f)) v[1] = 0.f;
+                        if (!(k4.z > 0.f)) v[2] = 0.f;
+                        if (!(k4.w > 0.f)) v[3] = 0.f;
+                    }
+                    if (p.y) *(float4 *)(p.y + o) = make_float4(v[0], v[1], v[2], v[3]);
                 } else {
                     for (int e = 0; e < 4; ++e)
                         if (c + e < p.Cout) {
                             if (p.residual) v[e] += p.residual[o + e];
                             if (p.relu) v[e] = fmaxf(v[e], 0.f);
-                            p.y[o + e] = v[e];
+                            if (p.mask && !(p.mask[o + e] > 0.f)) v[e] = 0.f;
+                            if (p.y) p.y[o + e] = v[e];
                         } else {
                             v[e] = 0.f;
                         }
                 }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) csum[e] += v[e];
                 if (p.yparts) {   // fused act_split of the output (Cop % 8 == 0, c % 4 == 0)
                     bf16x4 ps[3];
                     split4<P>(make_float4(v[0], v[1], v[2], v[3]), ps);
@@ -458,9 +490,16 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvParams p) {
                         *(bf16x4 *)(p.yparts + pp * p.y_part_stride + (long)m * p.Cop + c) = ps[pp];
                 }
             }
+            if (p.colsum) {   // 8 row groups x 2 halves share a column: combine in LDS first
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (csum[e] != 0.f) atomicAdd(&s_colsum[4 * (t & 31) + e], csum[e]);
+            }
         }
         __syncthreads();
     }
+    if (p.colsum && t < BN && n0 + t < p.Cout && s_colsum[t] != 0.f)   // one global atomic per column
+        atomicAdd(p.colsum + n0 + t, s_colsum[t]);
 }
 
 // ------------------------------------------------------------ weight gradient
@@ -674,10 +713,11 @@ extern "C" int sln_conv2d_fwd_ms_f32(const uint16_t *x_parts, int nseg, const in
                                      const uint16_t *w_parts, int parts, int Cout, int KH, int KW,
                                      int stride_h, int stride_w, int dil_h, int dil_w, int pad_top,
                                      int pad_left, int pad_bottom, int pad_right, const float *scale,
-                                     const float *shift, const float *residual, int relu, float *y,
-                                     uint16_t *y_parts, sln_stream_t stream) {
+                                     const float *shift, const float *residual, int relu,
+                                     const float *mask, float *y, uint16_t *y_parts, float *colsum,
+                                     sln_stream_t stream) {
     sln_enter();
-    if (!x_parts || !w_parts || !y || !seg_nhw || nseg < 1 || nseg > SLN_MAX_SEG || Cin < 1 || Cout < 1 ||
+    if (!x_parts || !w_parts || (!y && !y_parts) || !seg_nhw || nseg < 1 || nseg > SLN_MAX_SEG || Cin < 1 || Cout < 1 ||
         KH < 1 || KW < 1 || stride_h < 1 || stride_w < 1 || dil_h < 1 || dil_w < 1)
         return SLN_ERR_INVALID_ARG;
     if (parts != 2 && parts != 3) return SLN_ERR_INVALID_ARG;
@@ -700,12 +740,14 @@ extern "C" int sln_conv2d_fwd_ms_f32(const uint16_t *x_parts, int nseg, const in
         p.segH[q] = p.segW[q] = p.segOH[q] = p.segOW[q] = 1;
         p.seg_m0[q] = 2147483647; p.seg_x0[q] = 0;
     }
+    if (colsum && hipMemsetAsync(colsum, 0, sizeof(float) * Cout, (hipStream_t)stream) != hipSuccess)
+        return SLN_ERR_LAUNCH;
     if (M == 0) return SLN_OK;
     if (M > 2147483647L - BM || Min > 2147483647L) return SLN_ERR_UNSUPPORTED;
     p.nseg = nseg;
     p.x = (const __bf16 *)x_parts; p.w = (const __bf16 *)w_parts;
     p.scale = scale; p.shift = shift; p.residual = residual; p.y = y;
-    p.yparts = (__bf16 *)y_parts;
+    p.yparts = (__bf16 *)y_parts; p.mask = mask; p.colsum = colsum;
     p.Cop = (Cout + 7) / 8 * 8;
     p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW;
     p.sh = stride_h; p.sw = stride_w; p.dh = dil_h; p.dw = dil_w; p.pt = pad_top; p.pl = pad_left;
@@ -744,7 +786,7 @@ extern "C" int sln_conv2d_fwd_f32(const uint16_t *x_parts, int N, int H, int W, 
     const int pad_right = (OW - 1) * stride_w + dil_w * (KW - 1) + 1 - W - pad_left;
     return sln_conv2d_fwd_ms_f32(x_parts, 1, seg, Cin, w_parts, parts, Cout, KH, KW, stride_h, stride_w,
                                  dil_h, dil_w, pad_top, pad_left, pad_bottom, pad_right, scale, shift,
-                                 residual, relu, y, y_parts, stream);
+                                 residual, relu, nullptr, y, y_parts, nullptr, stream);
 }
 
 extern "C" int sln_conv2d_wgrad_f32(const uint16_t *gz_parts, int Cout, int Cout_pad,

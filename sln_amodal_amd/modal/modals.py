@@ -222,9 +222,10 @@ class Bottleneck(nn.Module):
         residual, link = x, {}
         if self.downsample is not None:
             residual, link = conv(x, self.downsample[0], self.downsample[1]), None
-        out = conv(x, self.conv1, self.bn1, relu=True, link=link)
-        out = conv(out, self.conv2, self.bn2, relu=True, same=True)
-        return conv(out, self.conv3, self.bn3, relu=True, residual=residual, link=link)
+        c12, c23 = {}, {}   # conv1 -> conv2 -> conv3: each output has exactly one reader
+        out = conv(x, self.conv1, self.bn1, relu=True, link=link, chain_out=c12)
+        out = conv(out, self.conv2, self.bn2, relu=True, same=True, chain_in=c12, chain_out=c23)
+        return conv(out, self.conv3, self.bn3, relu=True, residual=residual, link=link, chain_in=c23)
 
 
 class _Stem(nn.Sequential):

@@ -65,12 +65,15 @@ def bn_affine(bn):
     return scale, shift
 
 
-def conv_bn_act(x, conv, bn=None, relu=False, residual=None, same=False, link=None):
+def conv_bn_act(x, conv, bn=None, relu=False, residual=None, same=False, link=None, chain_in=None,
+                chain_out=None):
     """x [B,C,H,W] (any memory format; channels-last preferred).
     conv: nn.Conv2d parameter holder (weight, bias, stride, padding, dilation).
     bn:   frozen nn.BatchNorm2d or None.  same: apply SamePad2d first.
     link: dict shared by the two convs of an identity-shortcut block that see the same x
-          (one as input, one as residual); HIP backend only, see conv_hip._ConvFn."""
+          (one as input, one as residual); HIP backend only, see conv_hip._ConvFn.
+    chain_out / chain_in: dict shared by a conv (chain_out) and the ONLY conv that reads its
+          output (chain_in): lets the reader's backward prepare this layer's gradient."""
     stride, dilation = conv.stride, conv.dilation
     kh, kw = conv.kernel_size
     if same:   # (never with a MultiScale: the GLM uses symmetric padding)
@@ -83,7 +86,8 @@ def conv_bn_act(x, conv, bn=None, relu=False, residual=None, same=False, link=No
     if hip is not None and isinstance(x, hip.MultiScale):   # all GLM scales in one launch
         return hip.conv_bn_act_ms(x, conv, bn, relu, residual, (pt, pb, pl, pr))
     if hip is not None and x.is_cuda and hip.supports(conv, x):
-        return hip.conv_bn_act(x, conv, bn, relu, residual, (pt, pb, pl, pr), link=link)
+        return hip.conv_bn_act(x, conv, bn, relu, residual, (pt, pb, pl, pr), link=link,
+                               chain_in=chain_in, chain_out=chain_out)
     if BACKEND == "hip" and conv.in_channels >= 8:   # (3-channel stems are aten by design)
         raise RuntimeError("HIP conv backend requested but unavailable for this layer")
     if pt == pb and pl == pr:
@@ -125,7 +129,7 @@ def deconv2x2_relu(x, deconv):
     Ci, Co = deconv.weight.shape[0], deconv.weight.shape[1]
     w2 = deconv.weight.permute(2, 3, 1, 0).reshape(4 * Co, Ci, 1, 1)
     b2 = deconv.bias.repeat(4) if deconv.bias is not None else None
-    y = hip._ConvFn.apply(x, w2, b2, None, None, None, True, (1, 1), (1, 1), (0, 0, 0, 0), None)
+    y = hip._ConvFn.apply(x, w2, b2, None, None, None, True, (1, 1), (1, 1), (0, 0, 0, 0), None, None, None)
     N, _, H, W = y.shape
     y = y.permute(0, 2, 3, 1).reshape(N, H, W, 2, 2, Co).permute(0, 1, 3, 2, 4, 5)
     return y.reshape(N, 2 * H, 2 * W, Co).permute(0, 3, 1, 2)      # logical NCHW, NHWC in memory
@@ -138,5 +142,5 @@ def linear(x, lin):
         return F.linear(x, lin.weight, lin.bias)
     R, C = x.shape
     y = hip._ConvFn.apply(x.reshape(R, C, 1, 1), lin.weight.reshape(lin.out_features, C, 1, 1), lin.bias,
-                          None, None, None, False, (1, 1), (1, 1), (0, 0, 0, 0), None)
+                          None, None, None, False, (1, 1), (1, 1), (0, 0, 0, 0), None, None, None)
     return y.reshape(R, lin.out_features)
