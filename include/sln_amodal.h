@@ -193,7 +193,10 @@ int sln_pyramid_crop_bwd_f32(const float *grads, int g_cstride, int g_coffset, c
  *     whose mask value is not > 0 (the previous layer's ReLU, after scale/shift/
  *     residual/relu); y may be NULL when only y_parts are wanted; colsum [Cout]
  *     (optional, zeroed by the callee) receives the per-channel sums of the output
- *     (the previous layer's bias gradient; fp32 atomics).
+ *     (the previous layer's bias gradient; fp32 atomics).  post_scale [Cout]
+ *     (optional): y is written as computed, but y_parts and colsum hold y*post_scale[c]
+ *     (product rounded to fp32 first) -- the previous layer's frozen-BN scale when the
+ *     fp32 gradient itself is still needed (it is that layer's shortcut gradient).
  * sln_conv2d_wgrad_f32        gw [Cout][KH][KW][Cin] fp32 (zeroed by the callee) =
  *     sum over output pixels of gz[pix][co] * x[pix @ tap][ci]; split-K over pixel
  *     ranges with fp32 atomics (summation order not deterministic).
@@ -215,8 +218,8 @@ int sln_conv2d_fwd_ms_f32(const uint16_t *x_parts, int nseg, const int32_t *seg_
                           const uint16_t *w_parts, int parts, int Cout, int KH, int KW, int stride_h,
                           int stride_w, int dil_h, int dil_w, int pad_top, int pad_left, int pad_bottom,
                           int pad_right, const float *scale, const float *shift, const float *residual,
-                          int relu, const float *mask, float *y, uint16_t *y_parts, float *colsum,
-                          sln_stream_t stream);
+                          int relu, const float *mask, const float *post_scale, float *y,
+                          uint16_t *y_parts, float *colsum, sln_stream_t stream);
 int sln_conv2d_wgrad_f32(const uint16_t *gz_parts, int Cout, int Cout_pad, const uint16_t *x_parts,
                          int N, int H, int W, int Cin, int Cin_pad, int parts, int KH, int KW,
                          int stride_h, int stride_w, int dil_h, int dil_w, int pad_top, int pad_left,

@@ -38,7 +38,7 @@ SIGNATURES = {
     "sln_conv2d_fwd_f32": (_i, [_p, _i, _i, _i, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
                                 _i, _p, _p, _p, _i, _p, _p, _p]),
     "sln_conv2d_fwd_ms_f32": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
-                                   _p, _p, _p, _i, _p, _p, _p, _p, _p]),
+                                   _p, _p, _p, _i, _p, _p, _p, _p, _p, _p]),
     "sln_conv2d_wgrad_f32": (_i, [_p, _i, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
                                   _i, _i, _i, _i, _p, _p]),
 }

@@ -23,6 +23,7 @@ class _NoCache(dict):
 
 LINK_SHORTCUT_GRAD = os.environ.get("SLN_LINK_SHORTCUT_GRAD", "1") != "0"   # A/B switch
 CHAIN_GRAD_PREP = os.environ.get("SLN_CHAIN_GRAD_PREP", "1") != "0"            # A/B switch
+CHAIN_BLOCK_OUTPUT = os.environ.get("SLN_CHAIN_BLOCK_OUTPUT", "1") != "0"      # A/B switch
 CHAIN_STATS = [0, 0]  # prepared gradients handed over by consumers / used by producers
 LINK_STATS = [0, 0]   # shortcut gradients handed over by tails / consumed by heads
 FUSE_OUTPUT_SPLIT = True   # conv epilogue writes the output's parts (skips the next act_split)
@@ -123,7 +124,7 @@ def _prof_end(e0, flops, name, shape=""):
 
 
 def _fwd(xparts, N, H, W, wparts, Cout, KH, KW, stride, dil, pt, pl, OH, OW, scale, shift, residual,
-         relu, cin=None, out_parts=False, mask=None, want_y=True, want_colsum=False):
+         relu, cin=None, out_parts=False, mask=None, want_y=True, want_colsum=False, post_scale=None):
     """One launch of conv_fwd_kernel.  mask / want_y=False / want_colsum: the epilogue extras of
     sln_conv2d_fwd_ms_f32 (a data gradient that is consumed only as the previous layer's
     prepared gradient).  Returns y, or (y_or_None, parts, colsum) when any extra is used."""
@@ -142,9 +143,9 @@ def _fwd(xparts, N, H, W, wparts, Cout, KH, KW, stride, dil, pt, pl, OH, OW, sca
     _lib.check(_lib.lib().sln_conv2d_fwd_ms_f32(
         ops._ptr(xparts), 1, seg, xparts.shape[2], ops._ptr(wparts), wparts.shape[0], Cout, KH, KW,
         stride[0], stride[1], dil[0], dil[1], pt, pl, pb, pr, ops._ptr(scale), ops._ptr(shift),
-        ops._ptr(residual), 1 if relu else 0, ops._ptr(mask), ops._ptr(y), ops._ptr(yp), ops._ptr(cs),
-        ops._stream()), "sln_conv2d_fwd_ms_f32")
-    if yp is not None and y is not None:
+        ops._ptr(residual), 1 if relu else 0, ops._ptr(mask), ops._ptr(post_scale), ops._ptr(y),
+        ops._ptr(yp), ops._ptr(cs), ops._stream()), "sln_conv2d_fwd_ms_f32")
+    if yp is not None and y is not None and post_scale is None:
         y._sln_parts = ((y._version, wparts.shape[0]), yp)
     _prof_end(e0, 2.0 * N * OH * OW * Cout * KH * KW * (cin or wparts.shape[4]), "conv_fwd_kernel<%d>" % wparts.shape[0],
               "fwd N%d %dx%d C%d->%d k%d s%d d%d" % (N, H, W, cin or wparts.shape[4], Cout, KH, stride[0], dil[0]))
@@ -228,7 +229,7 @@ def conv_bn_act_ms(x, conv, bn, relu, residual, pads):
     e0 = _prof_begin()
     _lib.check(_lib.lib().sln_conv2d_fwd_ms_f32(
         ops._ptr(xp), len(x.segs), seg, xp.shape[2], ops._ptr(wp), parts, Co, KH, KW, sh, sw, dh, dw,
-        pt, pl, pb, pr, ops._ptr(scale), ops._ptr(shift), ops._ptr(res), 1 if relu else 0, None,
+        pt, pl, pb, pr, ops._ptr(scale), ops._ptr(shift), ops._ptr(res), 1 if relu else 0, None, None,
         ops._ptr(y), ops._ptr(yp), None, ops._stream()), "sln_conv2d_fwd_ms_f32")
     _prof_end(e0, flops, "conv_fwd_kernel<%d>" % parts,
               "fwd ms%s C%d->%d k%d s%d d%d" % ("+".join("%dx%d" % (h, w) for _, h, w in x.segs), Ci, Co, KH, sh, dh))
@@ -294,13 +295,19 @@ class _ConvFn(torch.autograd.Function):
         # does that preparation itself and hands over the parts; the fp32 gradient is never
         # written and sln_conv_grad_prep_f32 is not launched for this layer.
         ctx.chain_in = ctx.chain_out = None
-        if CHAIN_GRAD_PREP and chain_out is not None and residual is None and \
-                (ctx.needs_input_grad[0] or need_w):
-            chain_out.update(active=True, scale=scale, relu=bool(relu), parts=parts,
+        # A producer WITH a residual (conv3: block output = relu(bn(conv) + shortcut)) still needs
+        # the masked fp32 gradient -- it is its shortcut's gradient -- so its reader writes that as
+        # its dx and applies the BN scale to the parts only (post_scale); CHAIN_BLOCK_OUTPUT.
+        with_res = residual is not None
+        if CHAIN_GRAD_PREP and chain_out is not None and (ctx.needs_input_grad[0] or need_w) and \
+                (not with_res or (CHAIN_BLOCK_OUTPUT and relu)):
+            chain_out.update(active=True, scale=scale, relu=bool(relu), parts=parts, with_res=with_res,
                              want_bias=bool(bias is not None and ctx.needs_input_grad[2]))
             ctx.chain_out = chain_out
+        # (a block output's reader must also carry the shortcut's gradient: only as a link head)
         if CHAIN_GRAD_PREP and chain_in is not None and chain_in.get("active") and stride == (1, 1) and \
-                ctx.needs_input_grad[0] and chain_in["parts"] == parts:
+                ctx.needs_input_grad[0] and chain_in["parts"] == parts and \
+                (not chain_in["with_res"] or ctx.link_head is not None):
             chain_in["consumer"] = True
             ctx.chain_in = chain_in
         # the producer's ReLU mask is this layer's own input: saved here as an input tensor
@@ -325,10 +332,16 @@ class _ConvFn(torch.autograd.Function):
         want_bias = has_bias and ctx.needs_input_grad[2]
         ch = ctx.chain_out
         if ch is not None and ch.get("consumer"):
-            if "gz" not in ch or gy.stride() != (0, 0, 0, 0):
+            # what arrives must be exactly what the reader produced: the zero-stride placeholder,
+            # or (block outputs) the reader's own masked dx -- anything else means autograd added a
+            # second reader's gradient, which the handed-over parts do not contain
+            ok = "gz" in ch and (gy.data_ptr() == ch.pop("gu_ptr", None) if ch["with_res"]
+                                 else gy.stride() == (0, 0, 0, 0))
+            if not ok:
                 raise RuntimeError("chained gradient: the consumer's dgrad did not run, or the "
                                    "activation has a second consumer")
-            gz, g_res = ch.pop("gz"), None
+            gz = ch.pop("gz")
+            g_res = gy if (ch["with_res"] and want_res) else None   # already masked by the reader
             g_bias = ch.pop("gbias") if want_bias else None
             CHAIN_STATS[1] += 1
         else:
@@ -345,7 +358,16 @@ class _ConvFn(torch.autograd.Function):
             raise RuntimeError("identity-shortcut gradient was handed over but dx is not computed")
         if need_x:
             wt = _split_weights(weight, flip_swap=True, parts=parts)
-            if ctx.chain_in is not None:
+            if ctx.chain_in is not None and ctx.chain_in["with_res"]:
+                ci = ctx.chain_in
+                gx, gz_up, gb_up = _fwd(gz, N, OH, OW, wt, Ci, KH, KW, (1, 1), dil, dil[0] * (KH - 1) - pt,
+                                        dil[1] * (KW - 1) - pl, H, W, None, None,
+                                        _nhwc(id_grad) if id_grad is not None else None, False, cin=Co,
+                                        out_parts=True, mask=_nhwc(mask_x), want_y=True,
+                                        want_colsum=ci["want_bias"], post_scale=ci["scale"])
+                ci["gz"], ci["gbias"], ci["gu_ptr"] = gz_up, gb_up, gx.data_ptr()
+                CHAIN_STATS[0] += 1
+            elif ctx.chain_in is not None:
                 ci = ctx.chain_in
                 _, gz_up, gb_up = _fwd(gz, N, OH, OW, wt, Ci, KH, KW, (1, 1), dil, dil[0] * (KH - 1) - pt,
                                        dil[1] * (KW - 1) - pl, H, W, ci["scale"], None, None, False, cin=Co,

@@ -218,6 +218,7 @@ struct ConvParams {
     const float *residual;  // [M][Cout] or null
     float *y;             // [M][Cout], or null when only the parts are wanted
     __bf16 *yparts;       // [P][M][Cop] or null: the output's own bf16 parts (fused act_split)
+    const float *post_scale;  // [Cout] or null: the PARTS (and colsum) hold output * post_scale[c]
     const float *mask;    // [M][Cout] or null: output elements whose mask value is not > 0 become 0
     float *colsum;        // [Cout] or null: += per-channel sums of the output (bias gradient)
     long x_part_stride, w_part_stride, y_part_stride;
@@ -416,12 +417,13 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvParams p) {
         __syncthreads();
         const int c = n0 + 4 * (t & 31);
         if (c < p.Cout) {
-            float sc[4] = {1.f, 1.f, 1.f, 1.f}, sf[4] = {0.f, 0.f, 0.f, 0.f};
+            float sc[4] = {1.f, 1.f, 1.f, 1.f}, sf[4] = {0.f, 0.f, 0.f, 0.f}, ps_[4] = {1.f, 1.f, 1.f, 1.f};
 #pragma unroll
             for (int e = 0; e < 4; ++e)
                 if (c + e < p.Cout) {
                     if (p.scale) sc[e] = p.scale[c + e];
                     if (p.shift) sf[e] = p.shift[c + e];
+                    if (p.post_scale) ps_[e] = p.post_scale[c + e];
                 }
             // all residual rows of this half are requested before the first store: the
             // loads cannot be moved across the y stores by the compiler (may alias)
@@ -479,6 +481,13 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvParams p) {
                         } else {
                             v[e] = 0.f;
                         }
+                }
+                if (p.post_scale) {
+                    // rounded to fp32 before the split (no contraction into split4's subtraction):
+                    // the same value sln_conv_grad_prep_f32 would split
+#pragma clang fp contract(off)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] * ps_[e];
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) csum[e] += v[e];
@@ -714,8 +723,8 @@ extern "C" int sln_conv2d_fwd_ms_f32(const uint16_t *x_parts, int nseg, const in
                                      int stride_h, int stride_w, int dil_h, int dil_w, int pad_top,
                                      int pad_left, int pad_bottom, int pad_right, const float *scale,
                                      const float *shift, const float *residual, int relu,
-                                     const float *mask, float *y, uint16_t *y_parts, float *colsum,
-                                     sln_stream_t stream) {
+                                     const float *mask, const float *post_scale, float *y,
+                                     uint16_t *y_parts, float *colsum, sln_stream_t stream) {
     sln_enter();
     if (!x_parts || !w_parts || (!y && !y_parts) || !seg_nhw || nseg < 1 || nseg > SLN_MAX_SEG || Cin < 1 || Cout < 1 ||
         KH < 1 || KW < 1 || stride_h < 1 || stride_w < 1 || dil_h < 1 || dil_w < 1)
@@ -747,7 +756,7 @@ extern "C" int sln_conv2d_fwd_ms_f32(const uint16_t *x_parts, int nseg, const in
     p.nseg = nseg;
     p.x = (const __bf16 *)x_parts; p.w = (const __bf16 *)w_parts;
     p.scale = scale; p.shift = shift; p.residual = residual; p.y = y;
-    p.yparts = (__bf16 *)y_parts; p.mask = mask; p.colsum = colsum;
+    p.yparts = (__bf16 *)y_parts; p.mask = mask; p.colsum = colsum; p.post_scale = post_scale;
     p.Cop = (Cout + 7) / 8 * 8;
     p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW;
     p.sh = stride_h; p.sw = stride_w; p.dh = dil_h; p.dw = dil_w; p.pt = pad_top; p.pl = pad_left;
@@ -786,7 +795,7 @@ extern "C" int sln_conv2d_fwd_f32(const uint16_t *x_parts, int N, int H, int W, 
     const int pad_right = (OW - 1) * stride_w + dil_w * (KW - 1) + 1 - W - pad_left;
     return sln_conv2d_fwd_ms_f32(x_parts, 1, seg, Cin, w_parts, parts, Cout, KH, KW, stride_h, stride_w,
                                  dil_h, dil_w, pad_top, pad_left, pad_bottom, pad_right, scale, shift,
-                                 residual, relu, nullptr, y, y_parts, nullptr, stream);
+                                 residual, relu, nullptr, nullptr, y, y_parts, nullptr, stream);
 }
 
 extern "C" int sln_conv2d_wgrad_f32(const uint16_t *gz_parts, int Cout, int Cout_pad,

@@ -249,20 +249,23 @@ def test_identity_shortcut_gradient_link_matches_autograd_accumulation():
         assert torch.allclose(a, b, rtol=1e-4, atol=1e-5 * float(b.abs().max()) + 1e-7), k
 
 
-def test_chained_gradient_preparation_matches_separate_grad_prep():
-    """conv1 -> conv2 -> conv3 of a bottleneck: the reader's data-gradient epilogue applies the
-    producer's ReLU mask and BN scale and emits the bf16 parts (and bias sums) directly
-    (sln_conv2d_fwd_ms_f32 with mask / colsum / y == NULL) instead of writing the fp32
-    gradient and launching sln_conv_grad_prep_f32.  Same products in the same order: the
-    prepared parts, hence dx, are bit-identical; bias sums and weight gradients differ by
-    summation order only.  Third block: 34 mid channels (pad channels in the parts, scalar
-    epilogue path)."""
+@pytest.mark.parametrize("knob", ["CHAIN_GRAD_PREP", "CHAIN_BLOCK_OUTPUT"])
+def test_chained_gradient_preparation_matches_separate_grad_prep(knob):
+    """The reader's data-gradient epilogue applies the producer's ReLU mask and BN scale and emits
+    the bf16 parts (and bias sums) directly (sln_conv2d_fwd_ms_f32 with mask / post_scale /
+    colsum / y == NULL) instead of writing the fp32 gradient and launching
+    sln_conv_grad_prep_f32.  CHAIN_GRAD_PREP: all chaining (conv1 -> conv2 -> conv3 inside a
+    block, and block output -> next identity block); CHAIN_BLOCK_OUTPUT: only the latter.
+    Same products in the same order: the prepared parts, hence dx, are bit-identical; bias sums
+    and weight gradients differ by summation order only.  Last block: 34 mid channels (pad
+    channels in the parts, scalar epilogue path)."""
     from sln_amodal_amd import conv_hip
     from sln_amodal_amd.modal.modals import Bottleneck
     from tests._util import key_init_
     down1 = nn.Sequential(nn.Conv2d(64, 128, kernel_size=1, stride=1), nn.BatchNorm2d(128, eps=0.001))
-    down3 = nn.Sequential(nn.Conv2d(128, 136, kernel_size=1, stride=1), nn.BatchNorm2d(136, eps=0.001))
-    net = nn.Sequential(Bottleneck(64, 32, 1, down1), Bottleneck(128, 32), Bottleneck(128, 34, 1, down3)).cuda()
+    down4 = nn.Sequential(nn.Conv2d(128, 136, kernel_size=1, stride=1), nn.BatchNorm2d(136, eps=0.001))
+    net = nn.Sequential(Bottleneck(64, 32, 1, down1), Bottleneck(128, 32), Bottleneck(128, 32),
+                        Bottleneck(128, 34, 1, down4)).cuda()
     key_init_(net)
     for m in net.modules():
         if isinstance(m, nn.BatchNorm2d):
@@ -271,25 +274,45 @@ def test_chained_gradient_preparation_matches_separate_grad_prep():
     g = torch.Generator().manual_seed(12)
     x0 = torch.randn(2, 64, 21, 27, generator=g).cuda().contiguous(memory_format=torch.channels_last)
     up = torch.randn(2, 136, 21, 27, generator=g).cuda().contiguous(memory_format=torch.channels_last)
+    # 4 blocks x (conv1->conv2, conv2->conv3) = 8 inner chains; block1->2 and block2->3 = 2 outer ones
+    expect = {("CHAIN_GRAD_PREP", True): 10, ("CHAIN_GRAD_PREP", False): 0,
+              ("CHAIN_BLOCK_OUTPUT", True): 10, ("CHAIN_BLOCK_OUTPUT", False): 8}
     res = {}
-    saved = conv_hip.CHAIN_GRAD_PREP
+    saved = getattr(conv_hip, knob)
     try:
         for mode in (True, False):
-            conv_hip.CHAIN_GRAD_PREP = mode
+            setattr(conv_hip, knob, mode)
             conv_hip.CHAIN_STATS[:] = [0, 0]
             x = x0.clone().requires_grad_(True)
             net.zero_grad(set_to_none=True)
             y = net(x)
             y.backward(up)
-            # 3 blocks x (conv1->conv2, conv2->conv3): handed over and used -- or none when off
-            assert conv_hip.CHAIN_STATS == ([6, 6] if mode else [0, 0])
+            assert conv_hip.CHAIN_STATS == [expect[(knob, mode)]] * 2     # handed over == used
             res[mode] = (y.detach().clone(), x.grad.clone(),
                          {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None})
     finally:
-        conv_hip.CHAIN_GRAD_PREP = saved
+        setattr(conv_hip, knob, saved)
     assert torch.equal(res[True][0], res[False][0])
     assert torch.equal(res[True][1], res[False][1])
-    assert res[True][2].keys() == res[False][2].keys() and len(res[True][2]) >= 22
+    assert res[True][2].keys() == res[False][2].keys() and len(res[True][2]) >= 28
     for k in res[True][2]:
         a, b = res[True][2][k], res[False][2][k]
         assert torch.allclose(a, b, rtol=1e-4, atol=1e-5 * float(b.abs().max()) + 1e-7), k
+
+
+def test_chained_block_output_with_a_second_reader_fails_loudly():
+    """The hand-over is only valid while the next block is the only reader of a block output; a
+    second reader makes autograd add its gradient, which the backward detects (no silent error)."""
+    from sln_amodal_amd.modal.modals import Bottleneck
+    from tests._util import key_init_
+    net = nn.Sequential(Bottleneck(128, 32), Bottleneck(128, 32)).cuda()
+    key_init_(net)
+    for m in net.modules():
+        if isinstance(m, nn.BatchNorm2d):
+            m.eval()
+            m.weight.requires_grad = m.bias.requires_grad = False
+    x = torch.randn(1, 128, 9, 9).cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    mid = net[0](x)
+    out = net[1](mid)
+    with pytest.raises(RuntimeError, match="second consumer"):
+        (out.sum() + (mid * 2.0).sum()).backward()
