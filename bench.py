@@ -51,22 +51,27 @@ def dominant_kernel_roofline(prof, elapsed, parts):
         return {"bound": "mfma", "achieved": None, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": None, "traffic": None}
     by = {}
-    for e0, e1, fl, name, _shape in prof:
-        d = by.setdefault(name, [0.0, 0.0, 0])
+    for e0, e1, fl, name, _shape, rd, wr in prof:
+        d = by.setdefault(name, [0.0, 0.0, 0, 0.0, 0.0])
         d[0] += e0.elapsed_time(e1) * 1e-3
         d[1] += fl
         d[2] += 1
+        d[3] += rd
+        d[4] += wr
     name = max(by, key=lambda k: by[k][0])
-    secs, flops, n = by[name]
+    secs, flops, n, rd_b, wr_b = by[name]
     ach = flops / secs / 1e12
     mult = 6 if parts == 3 else 3
     traffic = None
     try:   # HBM bytes per launch from the committed rocprofv3 PMC passes (not collectable live)
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_v5_pmc_traffic.json")))[name]
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_v7_pmc_traffic.json")))[name]["last_step"]
         traffic = {"hbm_read_bytes_per_launch_raw": pmc["read_bytes_per_launch_raw"],
                    "hbm_read_bytes_per_launch_x2_corrected": pmc["read_bytes_per_launch_x2_gfx950_wide_load_correction"],
                    "hbm_write_bytes_per_launch": pmc["write_bytes_per_launch"],
-                   "source": "profiles/r1_v5_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"}
+                   "algorithmic_read_bytes_per_launch": int(rd_b / n),      # live: this run's launches
+                   "algorithmic_write_bytes_per_launch": int(wr_b / n),
+                   "source": "profiles/r1_v7_pmc_traffic.json, last steady-state step (rocprofv3 --pmc FETCH_SIZE / "
+                             "WRITE_SIZE, separate passes); algorithmic bytes counted live over the timed launches"}
     except Exception:
         pass
     return {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
@@ -195,7 +200,7 @@ def main():
         out["roofline"] = dominant_kernel_roofline(prof, elapsed, conv_hip.PARTS)
         if os.environ.get("SLN_PROFILE_SHAPES"):
             agg = {}
-            for e0, e1, fl, name, shape in prof:
+            for e0, e1, fl, name, shape, _rd, _wr in prof:
                 d = agg.setdefault(shape, [0.0, 0.0, 0])
                 d[0] += e0.elapsed_time(e1); d[1] += fl; d[2] += 1
             tot = sum(v[0] for v in agg.values())

@@ -116,11 +116,17 @@ def _prof_begin():
     return e
 
 
-def _prof_end(e0, flops, name, shape=""):
+def _prof_end(e0, flops, name, shape="", rd_bytes=0, wr_bytes=0):
+    """rd/wr_bytes: the launch's algorithmic HBM traffic (every operand read once, every output
+    written once) -- what the PMC figures in profiles/ are compared against."""
     if e0 is not None:
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
-        PROFILE.append((e0, e1, flops, name, shape))
+        PROFILE.append((e0, e1, flops, name, shape, rd_bytes, wr_bytes))
+
+
+def _nbytes(*tensors):
+    return sum(t.numel() * t.element_size() for t in tensors if t is not None)
 
 
 def _fwd(xparts, N, H, W, wparts, Cout, KH, KW, stride, dil, pt, pl, OH, OW, scale, shift, residual,
@@ -148,7 +154,8 @@ def _fwd(xparts, N, H, W, wparts, Cout, KH, KW, stride, dil, pt, pl, OH, OW, sca
     if yp is not None and y is not None and post_scale is None:
         y._sln_parts = ((y._version, wparts.shape[0]), yp)
     _prof_end(e0, 2.0 * N * OH * OW * Cout * KH * KW * (cin or wparts.shape[4]), "conv_fwd_kernel<%d>" % wparts.shape[0],
-              "fwd N%d %dx%d C%d->%d k%d s%d d%d" % (N, H, W, cin or wparts.shape[4], Cout, KH, stride[0], dil[0]))
+              "fwd N%d %dx%d C%d->%d k%d s%d d%d" % (N, H, W, cin or wparts.shape[4], Cout, KH, stride[0], dil[0]),
+              _nbytes(xparts, wparts, residual, mask), _nbytes(y, yp))
     if mask is not None or not want_y or want_colsum:
         return y, yp, cs
     return y
@@ -232,7 +239,8 @@ def conv_bn_act_ms(x, conv, bn, relu, residual, pads):
         pt, pl, pb, pr, ops._ptr(scale), ops._ptr(shift), ops._ptr(res), 1 if relu else 0, None, None,
         ops._ptr(y), ops._ptr(yp), None, ops._stream()), "sln_conv2d_fwd_ms_f32")
     _prof_end(e0, flops, "conv_fwd_kernel<%d>" % parts,
-              "fwd ms%s C%d->%d k%d s%d d%d" % ("+".join("%dx%d" % (h, w) for _, h, w in x.segs), Ci, Co, KH, sh, dh))
+              "fwd ms%s C%d->%d k%d s%d d%d" % ("+".join("%dx%d" % (h, w) for _, h, w in x.segs), Ci, Co, KH, sh, dh),
+              _nbytes(xp, wp, res), _nbytes(y, yp))
     return MultiScale(osegs, y, yp)
 
 
@@ -396,7 +404,8 @@ class _ConvFn(torch.autograd.Function):
                 stride[0], stride[1], dil[0], dil[1], pt, pl, OH, OW, ops._ptr(gw_t), ops._stream()),
                 "sln_conv2d_wgrad_f32")
             _prof_end(e0, 2.0 * N * OH * OW * Co * KH * KW * Ci, "conv_wgrad_kernel<%d>" % parts,
-                      "wgrad N%d %dx%d C%d->%d k%d s%d d%d" % (N, H, W, Ci, Co, KH, stride[0], dil[0]))
+                      "wgrad N%d %dx%d C%d->%d k%d s%d d%d" % (N, H, W, Ci, Co, KH, stride[0], dil[0]),
+                      _nbytes(gz, xp), _nbytes(gw_t))
             gw = gw_t.permute(0, 3, 1, 2)  # logical [Co,Ci,KH,KW]
         return gx, gw, g_bias, None, None, g_res, None, None, None, None, None, None, None
 
