@@ -191,6 +191,7 @@ def main():
                        "stage": args.stage, "parallelism": "dp%d" % world,
                        "conv_backend": nn_ops.BACKEND, "conv_split_parts": conv_hip.PARTS,
                        "final_loss": round(final_loss, 5),
+                       "loss_trace": [round(float(l), 4) for l in losses[:: max(1, len(losses) // 8)]],
                        "max_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)},
             "step_roofline": {"bound": "mfma", "kernel": "whole train step (all kernels)",
                               "achieved": round(achieved, 3), "peak": PEAK_F32_MFMA_TFLOPS,
