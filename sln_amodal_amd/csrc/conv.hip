@@ -253,6 +253,105 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
 }
 
+// One 64-row slab of an output tile, already staged as fp32 in LDS (row stride LD floats):
+// thread t owns columns 4*(t % NCOLQ)..+3 of rows t/NCOLQ + 8q (q = 0..7).  Per element:
+// v = acc*scale[c] + shift[c] (+ residual) (ReLU) (mask) -> y; parts / colsum of v (* post_scale).
+template <int P, int NCOLQ, int LD>
+__device__ __forceinline__ void epilogue_slab(const ConvParams &p, const float *stage, int m_base, int n0,
+                                              int t, float *s_colsum) {
+    const bool vec_ok = (p.Cout & 3) == 0;
+    const int c = n0 + 4 * (t & (NCOLQ - 1));
+    if (c < p.Cout) {
+        float sc[4] = {1.f, 1.f, 1.f, 1.f}, sf[4] = {0.f, 0.f, 0.f, 0.f}, ps_[4] = {1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (c + e < p.Cout) {
+                if (p.scale) sc[e] = p.scale[c + e];
+                if (p.shift) sf[e] = p.shift[c + e];
+                if (p.post_scale) ps_[e] = p.post_scale[c + e];
+            }
+        // all residual rows of this half are requested before the first store: the
+        // loads cannot be moved across the y stores by the compiler (may alias)
+        float4 res4[8], msk4[8];
+        if (vec_ok && p.residual) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int m = m_base + (t / NCOLQ) + 8 * q;
+                res4[q] = m < p.M ? *(const float4 *)(p.residual + (long)m * p.Cout + c)
+                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        if (vec_ok && p.mask) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int m = m_base + (t / NCOLQ) + 8 * q;
+                msk4[q] = m < p.M ? *(const float4 *)(p.mask + (long)m * p.Cout + c)
+                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        float csum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int row = (t / NCOLQ) + 8 * q;
+            const int m = m_base + row;
+            if (m >= p.M) continue;
+            const float4 a4 = *(const float4 *)&stage[row * LD + 4 * (t & (NCOLQ - 1))];
+            float v[4] = {a4.x * sc[0] + sf[0], a4.y * sc[1] + sf[1], a4.z * sc[2] + sf[2],
+                          a4.w * sc[3] + sf[3]};
+            const long o = (long)m * p.Cout + c;
+            if (vec_ok) {
+                if (p.residual) {
+                    const float4 r4 = res4[q];
+                    v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+                }
+                if (p.relu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                if (p.mask) {
+                    const float4 k4 = msk4[q];
+                    if (!(k4.x > 0.f)) v[0] = 0.f;
+                    if (!(k4.y > 0.f)) v[1] = 0.f;
+                    if (!(k4.z > 0.f)) v[2] = 0.f;
+                    if (!(k4.w > 0.f)) v[3] = 0.f;
+                }
+                if (p.y) *(float4 *)(p.y + o) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+                for (int e = 0; e < 4; ++e)
+                    if (c + e < p.Cout) {
+                        if (p.residual) v[e] += p.residual[o + e];
+                        if (p.relu) v[e] = fmaxf(v[e], 0.f);
+                        if (p.mask && !(p.mask[o + e] > 0.f)) v[e] = 0.f;
+                        if (p.y) p.y[o + e] = v[e];
+                    } else {
+                        v[e] = 0.f;
+                    }
+            }
+            if (p.post_scale) {
+                // rounded to fp32 before the split (no contraction into split4's subtraction):
+                // the same value sln_conv_grad_prep_f32 would split
+#pragma clang fp contract(off)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = v[e] * ps_[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) csum[e] += v[e];
+            if (p.yparts) {   // fused act_split of the output (Cop % 8 == 0, c % 4 == 0)
+                bf16x4 ps[3];
+                split4<P>(make_float4(v[0], v[1], v[2], v[3]), ps);
+#pragma unroll
+                for (int pp = 0; pp < P; ++pp)
+                    *(bf16x4 *)(p.yparts + pp * p.y_part_stride + (long)m * p.Cop + c) = ps[pp];
+            }
+        }
+        if (p.colsum) {   // 8 row groups x 2 halves share a column: combine in LDS first
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (csum[e] != 0.f) atomicAdd(&s_colsum[4 * (t & (NCOLQ - 1)) + e], csum[e]);
+        }
+    }
+}
+
 template <int P>
 __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvParams p) {
     // one LDS region: operand tiles during the k-loop, fp32 staging tile in the epilogue
@@ -401,7 +500,6 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvParams p) {
     // tiles), read back row-major: thread t owns columns 4*(t&31)..+3 of rows
     // (t>>5) + 8q.  Per element: v = acc*scale[c] + shift[c] (+ residual) (ReLU).
     float(*stage)[132] = (float(*)[132])smem;
-    const bool vec_ok = (p.Cout & 3) == 0;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         if (wr == h) {
@@ -415,96 +513,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvParams p) {
                             acc[i][j][r];
         }
         __syncthreads();
-        const int c = n0 + 4 * (t & 31);
-        if (c < p.Cout) {
-            float sc[4] = {1.f, 1.f, 1.f, 1.f}, sf[4] = {0.f, 0.f, 0.f, 0.f}, ps_[4] = {1.f, 1.f, 1.f, 1.f};
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (c + e < p.Cout) {
-                    if (p.scale) sc[e] = p.scale[c + e];
-                    if (p.shift) sf[e] = p.shift[c + e];
-                    if (p.post_scale) ps_[e] = p.post_scale[c + e];
-                }
-            // all residual rows of this half are requested before the first store: the
-            // loads cannot be moved across the y stores by the compiler (may alias)
-            float4 res4[8], msk4[8];
-            if (vec_ok && p.residual) {
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int m = m0 + h * 64 + (t >> 5) + 8 * q;
-                    res4[q] = m < p.M ? *(const float4 *)(p.residual + (long)m * p.Cout + c)
-                                      : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-            }
-            if (vec_ok && p.mask) {
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int m = m0 + h * 64 + (t >> 5) + 8 * q;
-                    msk4[q] = m < p.M ? *(const float4 *)(p.mask + (long)m * p.Cout + c)
-                                      : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-            }
-            float csum[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int row = (t >> 5) + 8 * q;
-                const int m = m0 + h * 64 + row;
-                if (m >= p.M) continue;
-                const float4 a4 = *(const float4 *)&stage[row][4 * (t & 31)];
-                float v[4] = {a4.x * sc[0] + sf[0], a4.y * sc[1] + sf[1], a4.z * sc[2] + sf[2],
-                              a4.w * sc[3] + sf[3]};
-                const long o = (long)m * p.Cout + c;
-                if (vec_ok) {
-                    if (p.residual) {
-                        const float4 r4 = res4[q];
-                        v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
-                    }
-                    if (p.relu) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-                    }
-                    if (p.mask) {
-                        const float4 k4 = msk4[q];
-                        if (!(k4.x > 0.f)) v[0] = 0.f;
-                        if (!(k4.y > 0.f)) v[1] = 0.f;
-                        if (!(k4.z > 0.f)) v[2] = 0.f;
-                        if (!(k4.w > 0.f)) v[3] = 0.f;
-                    }
-                    if (p.y) *(float4 *)(p.y + o) = make_float4(v[0], v[1], v[2], v[3]);
-                } else {
-                    for (int e = 0; e < 4; ++e)
-                        if (c + e < p.Cout) {
-                            if (p.residual) v[e] += p.residual[o + e];
-                            if (p.relu) v[e] = fmaxf(v[e], 0.f);
-                            if (p.mask && !(p.mask[o + e] > 0.f)) v[e] = 0.f;
-                            if (p.y) p.y[o + e] = v[e];
-                        } else {
-                            v[e] = 0.f;
-                        }
-                }
-                if (p.post_scale) {
-                    // rounded to fp32 before the split (no contraction into split4's subtraction):
-                    // the same value sln_conv_grad_prep_f32 would split
-#pragma clang fp contract(off)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = v[e] * ps_[e];
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) csum[e] += v[e];
-                if (p.yparts) {   // fused act_split of the output (Cop % 8 == 0, c % 4 == 0)
-                    bf16x4 ps[3];
-                    split4<P>(make_float4(v[0], v[1], v[2], v[3]), ps);
-#pragma unroll
-                    for (int pp = 0; pp < P; ++pp)
-                        *(bf16x4 *)(p.yparts + pp * p.y_part_stride + (long)m * p.Cop + c) = ps[pp];
-                }
-            }
-            if (p.colsum) {   // 8 row groups x 2 halves share a column: combine in LDS first
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (csum[e] != 0.f) atomicAdd(&s_colsum[4 * (t & 31) + e], csum[e]);
-            }
-        }
+        epilogue_slab<P, 32, 132>(p, &stage[0][0], m0 + h * 64, n0, t, s_colsum);
         __syncthreads();
     }
     if (p.colsum && t < BN && n0 + t < p.Cout && s_colsum[t] != 0.f)   // one global atomic per column
