@@ -125,6 +125,14 @@ def _prof_end(e0, flops, name, shape="", rd_bytes=0, wr_bytes=0):
         PROFILE.append((e0, e1, flops, name, shape, rd_bytes, wr_bytes))
 
 
+def _fwd_kernel_name(M, Cout, K, parts):
+    """Name of the kernel sln_conv2d_fwd_ms_f32 launches for this problem (sln_conv_fwd_tile)."""
+    if PROFILE is None:
+        return ""
+    tile = _lib.lib().sln_conv_fwd_tile(M, Cout, K, parts)
+    return ("conv_fwd256_kernel<%d>" if tile == 256 else "conv_fwd_kernel<%d>") % parts
+
+
 def _nbytes(*tensors):
     return sum(t.numel() * t.element_size() for t in tensors if t is not None)
 
@@ -153,7 +161,8 @@ def _fwd(xparts, N, H, W, wparts, Cout, KH, KW, stride, dil, pt, pl, OH, OW, sca
         ops._ptr(yp), ops._ptr(cs), ops._stream()), "sln_conv2d_fwd_ms_f32")
     if yp is not None and y is not None and post_scale is None:
         y._sln_parts = ((y._version, wparts.shape[0]), yp)
-    _prof_end(e0, 2.0 * N * OH * OW * Cout * KH * KW * (cin or wparts.shape[4]), "conv_fwd_kernel<%d>" % wparts.shape[0],
+    _prof_end(e0, 2.0 * N * OH * OW * Cout * KH * KW * (cin or wparts.shape[4]),
+              _fwd_kernel_name(N * OH * OW, Cout, KH * KW * xparts.shape[2], wparts.shape[0]),
               "fwd N%d %dx%d C%d->%d k%d s%d d%d" % (N, H, W, cin or wparts.shape[4], Cout, KH, stride[0], dil[0]),
               _nbytes(xparts, wparts, residual, mask), _nbytes(y, yp))
     if mask is not None or not want_y or want_colsum:
@@ -238,7 +247,7 @@ def conv_bn_act_ms(x, conv, bn, relu, residual, pads):
         ops._ptr(xp), len(x.segs), seg, xp.shape[2], ops._ptr(wp), parts, Co, KH, KW, sh, sw, dh, dw,
         pt, pl, pb, pr, ops._ptr(scale), ops._ptr(shift), ops._ptr(res), 1 if relu else 0, None, None,
         ops._ptr(y), ops._ptr(yp), None, ops._stream()), "sln_conv2d_fwd_ms_f32")
-    _prof_end(e0, flops, "conv_fwd_kernel<%d>" % parts,
+    _prof_end(e0, flops, _fwd_kernel_name(M, Co, KH * KW * xp.shape[2], parts),
               "fwd ms%s C%d->%d k%d s%d d%d" % ("+".join("%dx%d" % (h, w) for _, h, w in x.segs), Ci, Co, KH, sh, dh),
               _nbytes(xp, wp, res), _nbytes(y, yp))
     return MultiScale(osegs, y, yp)

@@ -21,6 +21,8 @@
 //                  ("TN" GEMM: both operands are pixel-major, fragments are
 //                  fetched with the ds_read_b64_tr_b16 transposing LDS read)
 //
+// (conv_fwd256_kernel further down is the same GEMM on 256x256 tiles with an LDS-DMA pipeline;
+// sln_conv_fwd_tile picks one of the two per launch.)
 // conv_fwd GEMM view: M = N*OH*OW output pixels, N = Cout, K = KH*KW*Cin walked
 // tap by tap in 32-channel chunks; taps outside the image read zero (the
 // reference's SamePad2d / conv padding).  Tile 128x128x32, 256 threads = 4 waves
@@ -28,6 +30,7 @@
 // (64 B) with the 16-B chunk index XOR-swizzled by row bits 2..3 (48 KB per block, 3
 // blocks per CU): the ds_read_b128 fragment reads of a 16-lane group hit 16 distinct
 // 4-bank groups (conflict-free).  Register prefetch of the next k-step.
+#include <cstdlib>
 #include "common.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -520,6 +523,181 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvParams p) {
         atomicAdd(p.colsum + n0 + t, s_colsum[t]);
 }
 
+// ---------------------------------------------------------------- 256x256 forward tile
+// The same GEMM on a 256x256 output tile: 8 waves (2 x 4), each 128x64 = 4x2 MFMA tiles, so a
+// 16-deep k-step needs 18 fragment reads for 48 MFMAs (the 128^2 kernel: 12 for 24).  Operand
+// tiles go global -> LDS by DMA (global_load_lds_dwordx4: lane l's 16 B land at base + 16 l, the
+// SOURCE address is per lane), three 48-KB stages deep, one barrier per stage, the DMA of stage
+// s+2 in flight across it (counted s_waitcnt vmcnt, raw s_barrier).  LDS rows are 16 bf16 = 32 B;
+// the 16-B half is XOR-swizzled with bit 3 of the row, applied on the source side, so that the
+// 16 lanes of a ds_read_b128 group hit 16 distinct 4-bank groups.  Taps outside the image and
+// channel / row tails read a 16-B page of zeros.  One block per CU (144 KB LDS).
+#define T2 256
+#define T2K 16
+__device__ __attribute__((aligned(16))) const unsigned char sln_zero_page[16] = {0};
+
+template <int P>
+__global__ __launch_bounds__(512) void conv_fwd256_kernel(const ConvParams p) {
+    constexpr int REGION = T2 * T2K * 2;      // one part of one operand: 256 rows x 32 B = 8 KB
+    constexpr int STAGE = 2 * P * REGION;     // A parts then B parts
+    // ONE LDS object: with a second __shared__ array beside the DMA staging buffer hipcc (ROCm 7.2)
+    // emits s_waitcnt vmcnt(0) before the first ds_read of every k-step, draining the DMA pipeline
+    __shared__ __attribute__((aligned(16))) unsigned char smem[3 * STAGE + T2 * 4];
+    float *s_colsum = (float *)(smem + 3 * STAGE);
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef __attribute__((address_space(1))) const void glb_void;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int wr = wave >> 2, wc = wave & 3;
+    if (t < T2) s_colsum[t] = 0.f;
+    const int bid = xcd_remap(blockIdx.x, p.gm * p.gn);
+    const int m0 = (bid / p.gn) * T2;
+    const int n0 = (bid % p.gn) * T2;
+
+    // ---- DMA slot of this lane: row 32*wave + lane/2 of every region, 16-B half lane&1 ----
+    const int drow = 32 * wave + (lane >> 1);
+    const int dlog = ((lane & 1) ^ ((drow >> 3) & 1)) * 8;   // logical channel offset it fetches
+    int a_ih0, a_iw0, a_H, a_W;
+    long a_nbase;
+    bool a_ok;
+    {
+        const int m = m0 + drow;
+        a_ok = m < p.M;
+        int mm = a_ok ? m : 0;
+        int sg = 0;
+        for (int q = 1; q < p.nseg; ++q)
+            if (mm >= p.seg_m0[q]) sg = q;
+        mm -= p.seg_m0[sg];
+        const int OHs = p.segOH[sg], OWs = p.segOW[sg];
+        a_H = p.segH[sg]; a_W = p.segW[sg];
+        const int n = mm / (OHs * OWs);
+        const int rem = mm - n * (OHs * OWs);
+        const int oh = rem / OWs, ow = rem - oh * OWs;
+        a_ih0 = oh * p.sh - p.pt;
+        a_iw0 = ow * p.sw - p.pl;
+        a_nbase = (long)p.seg_x0[sg] + (long)n * a_H * a_W;
+    }
+    const bool b_ok = (n0 + drow) < p.Cout;
+    const __bf16 *bptr = p.w + (long)(n0 + (b_ok ? drow : 0)) * p.Ktot;
+    const int ncc = (p.Cin + T2K - 1) / T2K;
+    const int nk = p.KH * p.KW * ncc;
+
+    // K order: 64-channel group major, tap, then the group's 16-channel chunks -- the four
+    // stages of a (group, tap) walk one 128-B line of every pixel, and the KH*KW shifted windows
+    // of a group are read within 4*KH*KW consecutive stages, while their lines are still in L2
+    // (tap-major order re-fetched them from beyond L2: 4.7x the algorithmic reads, PMC)
+    const int ntap = p.KH * p.KW;
+    const int gfull = ncc / 4, nsub_tail = ncc - 4 * gfull;
+    auto issue = [&](int s) {
+        int tap, cc;
+        if (s < gfull * ntap * 4) {
+            const int g = s / (ntap * 4), r = s - g * (ntap * 4);
+            tap = r >> 2; cc = 4 * g + (r & 3);
+        } else {
+            const int r = s - gfull * ntap * 4;
+            tap = r / nsub_tail; cc = 4 * gfull + (r - tap * nsub_tail);
+        }
+        const int kh = tap / p.KW, kw = tap - kh * p.KW;
+        const int ci = cc * T2K + dlog;
+        const bool cok = ci < p.Cin;
+        const int ih = a_ih0 + kh * p.dh, iw = a_iw0 + kw * p.dw;
+        const bool aok = a_ok && cok && ih >= 0 && ih < a_H && iw >= 0 && iw < a_W;
+        const long aoff = (a_nbase + (long)ih * a_W + iw) * p.Cin + ci;
+        const long boff = (long)tap * p.Cin + ci;
+        unsigned char *base = smem + (s % 3) * STAGE + wave * 1024;
+#pragma unroll
+        for (int pp = 0; pp < P; ++pp) {
+            const void *ga = aok ? (const void *)(p.x + pp * p.x_part_stride + aoff) : (const void *)sln_zero_page;
+            __builtin_amdgcn_global_load_lds((glb_void *)ga, (lds_void *)(base + pp * REGION), 16, 0, 0);
+        }
+#pragma unroll
+        for (int pp = 0; pp < P; ++pp) {
+            const void *gb = (b_ok && cok) ? (const void *)(bptr + pp * p.w_part_stride + boff)
+                                           : (const void *)sln_zero_page;
+            __builtin_amdgcn_global_load_lds((glb_void *)gb, (lds_void *)(base + (P + pp) * REGION), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragment addresses (bytes inside a region): row*32 + swizzled half*16
+    const int frow = lane & 31, fhalf = lane >> 5;
+    int a_off[4], b_off[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = 128 * wr + 32 * i + frow;
+        a_off[i] = row * 32 + ((fhalf ^ ((row >> 3) & 1)) * 16);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = 64 * wc + 32 * j + frow;
+        b_off[j] = row * 32 + ((fhalf ^ ((row >> 3) & 1)) * 16);
+    }
+
+    issue(0);
+    if (nk > 1) issue(1);
+    for (int s = 0; s < nk; ++s) {
+        // this wave's DMAs of stage s have landed (those of stage s+1 may still be in flight) ...
+        if (s + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // ... and so have everyone's; everyone has also finished reading stage s-1's buffer,
+        // which the DMA of stage s+2 overwrites
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const unsigned char *st = smem + (s % 3) * STAGE;
+        bf16x8 a[4][P], b[2][P];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int pp = 0; pp < P; ++pp) b[j][pp] = *(const bf16x8 *)(st + (P + pp) * REGION + b_off[j]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int pp = 0; pp < P; ++pp) a[i][pp] = *(const bf16x8 *)(st + pp * REGION + a_off[i]);
+        // fragment reads first, then the first quarter of the MFMAs, and only then the DMA of
+        // stage s+2 (its buffer is free since the barrier): the DMA issue no longer delays the
+        // reads this stage's MFMAs wait for
+#pragma unroll
+        for (int j = 0; j < 2; ++j) mfma_products<P>(a[0], b[j], acc[0][j]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 2 < nk) issue(s + 2);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 1; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) mfma_products<P>(a[i], b[j], acc[i][j]);
+    }
+    __syncthreads();
+
+    // ---- epilogue: four 64-row slabs through LDS ([64][260] floats), as in the 128^2 kernel ----
+    float *stage = (float *)smem;
+    static_assert(64 * 260 * 4 <= 3 * STAGE, "staging slab must fit");
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        if (wr == (h >> 1)) {
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        stage[(ii * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 260 + wc * 64 + j * 32 +
+                              (lane & 31)] = acc[2 * (h & 1) + ii][j][r];
+        }
+        __syncthreads();
+        epilogue_slab<P, 64, 260>(p, stage, m0 + h * 64, n0, t, s_colsum);
+        __syncthreads();
+    }
+    if (p.colsum && t < T2 && n0 + t < p.Cout && s_colsum[t] != 0.f) atomicAdd(p.colsum + n0 + t, s_colsum[t]);
+}
+
 // ------------------------------------------------------------ weight gradient
 // gw[co][tap][ci] += sum over a pixel range of gz[pix][co] * x[pix@tap][ci].
 // "TN" GEMM: M = Cout, N = one tap's Cin slice, K = output pixels.  Both operand
@@ -727,6 +905,23 @@ extern "C" int sln_conv_grad_prep_f32(const float *gy, const float *y, const flo
     return sln_launch_status();
 }
 
+// Which forward kernel sln_conv2d_fwd(_ms)_f32 uses for M output pixels, Cout channels and a
+// reduction of K = KH*KW*Cin: 256 = conv_fwd256_kernel (one 256x256 tile per CU, LDS-DMA pipeline)
+// when Cout fills most of 256 columns, the tiles come in (nearly) whole rounds of the 256 CUs
+// and K is long enough to amortise the pipeline; else 128.  SLN_CONV_TILE256 = 0 never,
+// 1 (default) by this rule, 2 always (tests); read on every call.
+extern "C" int sln_conv_fwd_tile(int64_t M, int Cout, int64_t K, int parts) {
+    const char *e = getenv("SLN_CONV_TILE256");
+    const int mode = e ? atoi(e) : 1;
+    if (M < 1 || Cout < 1 || M > 2147483647L - T2) return BM;
+    if (mode == 2) return T2;
+    if (mode != 1 || parts != 3) return BM;
+    const long nb2 = sln_div_up(M, T2) * (long)sln_div_up(Cout, T2);
+    const double fill = (double)nb2 / (double)(sln_div_up(nb2, 256) * 256L);
+    const bool cols = Cout >= 192 && (Cout % T2 == 0 || Cout % T2 >= 160);
+    return (cols && fill >= 0.85 && K >= 512) ? T2 : BM;
+}
+
 extern "C" int sln_conv2d_fwd_ms_f32(const uint16_t *x_parts, int nseg, const int32_t *seg_nhw, int Cin,
                                      const uint16_t *w_parts, int parts, int Cout, int KH, int KW,
                                      int stride_h, int stride_w, int dil_h, int dil_w, int pad_top,
@@ -776,6 +971,17 @@ extern "C" int sln_conv2d_fwd_ms_f32(const uint16_t *x_parts, int nseg, const in
     p.w_part_stride = (long)Cout * p.Ktot;
     p.y_part_stride = M * p.Cop;
     p.cin_chunks = sln_div_up(Cin, BK);
+    const bool use256 = sln_conv_fwd_tile(M, Cout, KH * KW * Cin, parts) == T2;
+    const long gm2 = sln_div_up(M, T2), gn2 = sln_div_up(Cout, T2);
+    const long nb2 = gm2 * gn2;
+    if (use256) {
+        p.gm = (int)gm2; p.gn = (int)gn2;
+        if (parts == 2)
+            hipLaunchKernelGGL(conv_fwd256_kernel<2>, dim3((unsigned)nb2), dim3(512), 0, (hipStream_t)stream, p);
+        else
+            hipLaunchKernelGGL(conv_fwd256_kernel<3>, dim3((unsigned)nb2), dim3(512), 0, (hipStream_t)stream, p);
+        return sln_launch_status();
+    }
     p.gm = sln_div_up(M, BM);
     p.gn = sln_div_up(Cout, BN);
     const long nblk = (long)p.gm * p.gn;

@@ -74,3 +74,23 @@ def test_product_package_never_imports_the_oracle():
                 text = open(os.path.join(dirpath, fn)).read()
                 assert "import oracle" not in text and "from oracle" not in text, fn
                 assert "libsln_oracle" not in text, fn
+
+
+def test_forward_tile_rule_is_a_pure_host_function(monkeypatch):
+    """sln_conv_fwd_tile: 256x256 tiles only for wide outputs in whole rounds of 256 CUs with a
+    long reduction; SLN_CONV_TILE256 = 0 / 2 override it (read on every call)."""
+    from sln_amodal_amd import _lib
+    L = _lib.lib()
+    monkeypatch.delenv("SLN_CONV_TILE256", raising=False)
+    assert L.sln_conv_fwd_tile(65536, 256, 2304, 3) == 256       # C4 3x3: 256 tiles, one per CU
+    assert L.sln_conv_fwd_tile(65536, 64, 2304, 3) == 128        # narrow output
+    assert L.sln_conv_fwd_tile(65536, 256, 256, 3) == 128        # short reduction
+    assert L.sln_conv_fwd_tile(67600, 256, 2304, 3) == 128       # 265 tiles: 52 % of two rounds
+    assert L.sln_conv_fwd_tile(123440, 256, 2304, 3) == 256      # packed GLM scales: 483 tiles, 94 %
+    assert L.sln_conv_fwd_tile(65536, 256, 2304, 2) == 128       # 2-part path stays on 128
+    assert L.sln_conv_fwd_tile(65536, 182, 18432, 3) == 128      # ASPP: 182 < 192 columns stay on 128
+    assert L.sln_conv_fwd_tile(65536, 200, 18432, 3) == 256      # 200 of 256 columns is enough
+    monkeypatch.setenv("SLN_CONV_TILE256", "0")
+    assert L.sln_conv_fwd_tile(65536, 256, 2304, 3) == 128
+    monkeypatch.setenv("SLN_CONV_TILE256", "2")
+    assert L.sln_conv_fwd_tile(100, 8, 8, 2) == 256

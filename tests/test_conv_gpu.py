@@ -38,10 +38,28 @@ def _ref(x, w, b, scale, shift, res, relu, stride, dil, pads):
     return F.relu(y) if relu else y
 
 
+@pytest.fixture
+def tile_mode():
+    """SLN_CONV_TILE256 is read by the C launcher on every call: 0 = 128x128 tiles only,
+    2 = the 256x256 LDS-DMA kernel for every forward / data-gradient launch."""
+    import os
+    saved = os.environ.get("SLN_CONV_TILE256")
+
+    def set_mode(v):
+        os.environ["SLN_CONV_TILE256"] = str(v)
+    yield set_mode
+    if saved is None:
+        os.environ.pop("SLN_CONV_TILE256", None)
+    else:
+        os.environ["SLN_CONV_TILE256"] = saved
+
+
 @pytest.mark.parametrize("case", CASES)
 @pytest.mark.parametrize("parts", [3, 2])
-def test_conv_forward_matches_fp64_reference(case, parts):
+@pytest.mark.parametrize("tile", [128, 256])
+def test_conv_forward_matches_fp64_reference(case, parts, tile, tile_mode):
     from sln_amodal_amd import conv_hip
+    tile_mode(2 if tile == 256 else 0)
     Cin, Cout, k, stride, dil, pads, H, W, N = case
     g = torch.Generator(device="cuda").manual_seed(Cin * 7 + Cout)
     x = torch.randn(N, Cin, H, W, device="cuda", generator=g).contiguous(memory_format=torch.channels_last)
@@ -316,3 +334,36 @@ def test_chained_block_output_with_a_second_reader_fails_loudly():
     out = net[1](mid)
     with pytest.raises(RuntimeError, match="second consumer"):
         (out.sum() + (mid * 2.0).sum()).backward()
+
+
+@pytest.mark.parametrize("shape", [
+    # N, H, W, Cin, Cout, k, dil : M and Cout not multiples of 256, K from 8 to 144 stages
+    (3, 37, 41, 64, 256, 3, 1), (2, 65, 65, 1024, 200, 1, 1), (1, 49, 49, 136, 439, 3, 2), (5, 16, 16, 8, 256, 1, 1)])
+def test_tile256_kernel_is_deterministic_and_agrees_with_tile128(shape, tile_mode):
+    """Race screen for the hand-synchronised DMA pipeline of conv_fwd256_kernel (counted vmcnt +
+    raw barrier, three stages): 40 launches of the same problem must give bit-identical
+    outputs (a race shows up as run-to-run differences), and they agree with the 128x128
+    kernel to fp32 accumulation-order noise (the two walk K in different orders)."""
+    from sln_amodal_amd import conv_hip
+    N, H, W, Cin, Cout, k, dil = shape
+    g = torch.Generator(device="cuda").manual_seed(H * 131 + Cin)
+    x = torch.randn(N, Cin, H, W, device="cuda", generator=g).contiguous(memory_format=torch.channels_last)
+    w = torch.randn(Cout, Cin, k, k, device="cuda", generator=g) / (Cin * k * k) ** 0.5
+    pad = dil * (k - 1) // 2
+    xp = conv_hip.act_parts(x, 3)
+    wp = conv_hip._split_weights(w, parts=3)
+
+    def run():
+        return conv_hip._fwd(xp, N, H, W, wp, Cout, k, k, (1, 1), (dil, dil), pad, pad, H, W, None, None,
+                             None, False, cin=Cin, out_parts=True)
+
+    tile_mode(0)
+    y128 = run().clone()
+    tile_mode(2)
+    first = run()
+    y0, p0 = first.clone(), first._sln_parts[1].clone()
+    for _ in range(40):
+        y = run()
+        assert torch.equal(y, y0) and torch.equal(y._sln_parts[1], p0)
+    err = (y0 - y128).abs().max().item() / y128.abs().max().item()
+    assert err < 2e-6, err
