@@ -907,7 +907,7 @@ extern "C" int sln_conv_grad_prep_f32(const float *gy, const float *y, const flo
 
 // Which forward kernel sln_conv2d_fwd(_ms)_f32 uses for M output pixels, Cout channels and a
 // reduction of K = KH*KW*Cin: 256 = conv_fwd256_kernel (one 256x256 tile per CU, LDS-DMA pipeline)
-// when Cout fills most of 256 columns, the tiles come in (nearly) whole rounds of the 256 CUs
+// when Cout fills >= 176 of the last 256 columns, the tiles come in (nearly) whole rounds of the 256 CUs
 // and K is long enough to amortise the pipeline; else 128.  SLN_CONV_TILE256 = 0 never,
 // 1 (default) by this rule, 2 always (tests); read on every call.
 extern "C" int sln_conv_fwd_tile(int64_t M, int Cout, int64_t K, int parts) {
@@ -918,7 +918,9 @@ extern "C" int sln_conv_fwd_tile(int64_t M, int Cout, int64_t K, int parts) {
     if (mode != 1 || parts != 3) return BM;
     const long nb2 = sln_div_up(M, T2) * (long)sln_div_up(Cout, T2);
     const double fill = (double)nb2 / (double)(sln_div_up(nb2, 256) * 256L);
-    const bool cols = Cout >= 192 && (Cout % T2 == 0 || Cout % T2 >= 160);
+    // at least 176 of the last 256 columns in use (ASPP's Cout = 182: +6...11 % per launch over
+    // the 128x128 kernel, which wastes the same share of its second 128-column tile)
+    const bool cols = Cout >= 176 && (Cout % T2 == 0 || Cout % T2 >= 160);
     return (cols && fill >= 0.85 && K >= 512) ? T2 : BM;
 }
 

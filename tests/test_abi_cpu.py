@@ -88,8 +88,9 @@ def test_forward_tile_rule_is_a_pure_host_function(monkeypatch):
     assert L.sln_conv_fwd_tile(67600, 256, 2304, 3) == 128       # 265 tiles: 52 % of two rounds
     assert L.sln_conv_fwd_tile(123440, 256, 2304, 3) == 256      # packed GLM scales: 483 tiles, 94 %
     assert L.sln_conv_fwd_tile(65536, 256, 2304, 2) == 128       # 2-part path stays on 128
-    assert L.sln_conv_fwd_tile(65536, 182, 18432, 3) == 128      # ASPP: 182 < 192 columns stay on 128
-    assert L.sln_conv_fwd_tile(65536, 200, 18432, 3) == 256      # 200 of 256 columns is enough
+    assert L.sln_conv_fwd_tile(65536, 182, 18432, 3) == 256      # ASPP: 182 of 256 columns is enough
+    assert L.sln_conv_fwd_tile(65536, 150, 18432, 3) == 128      # 150 is not
+    assert L.sln_conv_fwd_tile(65536, 256 + 100, 18432, 3) == 128  # nor a 100-column second tile
     monkeypatch.setenv("SLN_CONV_TILE256", "0")
     assert L.sln_conv_fwd_tile(65536, 256, 2304, 3) == 128
     monkeypatch.setenv("SLN_CONV_TILE256", "2")
