@@ -849,6 +849,138 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     }
 }
 
+// ---------------------------------------------------------------- 256x256 weight-gradient tile
+// The weight gradient on the structure of conv_fwd256_kernel: one (tap, 256 Cout x 256 Cin) tile per
+// block, 8 waves of 128x64, K = output pixels in 16-pixel stages, both operands pixel-major in LDS
+// (rows of 256 bf16 = 512 B) filled by LDS-DMA three stages deep; the fragments (8 consecutive
+// pixels per lane) come from ds_read_b64_tr_b16 as in conv_wgrad_kernel.  Rows are unpadded: the
+// 64-B quarter of a row is XOR-swizzled with k&3 on the DMA's source side so that the four k-rows
+// of a transposing read sit 16 banks apart.  Split-K over pixel ranges, fp32 atomics.
+__device__ __forceinline__ bf16x8 tr_frag256(const unsigned char *region, int k0, int m0, int lane) {
+    const int li = lane & 15, q = li >> 2, pq = li & 3;
+    typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+    const int col = (m0 + 4 * pq) ^ (q << 5);      // k0 is a multiple of 8: rows k0+q, k0+4+q share key q
+    const __bf16 *p0 = (const __bf16 *)region + (k0 + q) * T2 + col;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)p0);
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(p0 + 4 * T2));
+    bf16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+}
+
+template <int P>
+__global__ __launch_bounds__(512) void conv_wgrad256_kernel(const WgradParams p) {
+    constexpr int REGION = T2K * T2 * 2;      // one part of one operand: 16 pixel rows x 512 B = 8 KB
+    constexpr int STAGE = 2 * P * REGION;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[3 * STAGE];   // ONE LDS object (see fwd256)
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef __attribute__((address_space(1))) const void glb_void;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int wr = wave >> 2, wc = wave & 3;
+    const int ntile = p.gm * p.gn_per_tap * p.KH * p.KW;
+    int bid = blockIdx.x;
+    const int split = bid / ntile;
+    bid -= split * ntile;
+    const int mt = bid % p.gm;
+    int rest = bid / p.gm;
+    const int nt = rest % p.gn_per_tap;
+    const int tap = rest / p.gn_per_tap;
+    const int kh = tap / p.KW, kw = tap - kh * p.KW;
+    const int m0 = mt * T2, n0 = nt * T2;
+    const int pix_begin = split * p.pix_per_split;
+    const int pix_end = min(p.M, pix_begin + p.pix_per_split);
+    const int nk = (pix_end - pix_begin + T2K - 1) / T2K;
+
+    // DMA slot: pixel row 2*wave + lane/32 of every region, 16-B chunk lane%32 (8 channels)
+    const int drow = 2 * wave + (lane >> 5);
+    const int dch = (((lane & 31) ^ ((drow & 3) << 2))) * 8;     // logical channel offset fetched
+    const bool a_cok = (m0 + dch) < p.Cop;
+    const bool b_cok = (n0 + dch) < p.Cip;
+
+    auto issue = [&](int s) {
+        const int pix = pix_begin + s * T2K + drow;
+        const bool pok = pix < pix_end;
+        const int pp_ = pok ? pix : 0;
+        const int n = pp_ / (p.OH * p.OW);
+        const int rem = pp_ - n * (p.OH * p.OW);
+        const int oh = rem / p.OW, ow = rem - oh * p.OW;
+        const int ih = oh * p.sh - p.pt + kh * p.dh, iw = ow * p.sw - p.pl + kw * p.dw;
+        const bool xok = pok && b_cok && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+        const long aoff = (long)pix * p.Cop + m0 + dch;
+        const long boff = (((long)n * p.H + ih) * p.W + iw) * p.Cip + n0 + dch;
+        unsigned char *base = smem + (s % 3) * STAGE + wave * 1024;
+#pragma unroll
+        for (int pp = 0; pp < P; ++pp) {
+            const void *ga = (pok && a_cok) ? (const void *)(p.gz + pp * p.gz_part_stride + aoff)
+                                            : (const void *)sln_zero_page;
+            __builtin_amdgcn_global_load_lds((glb_void *)ga, (lds_void *)(base + pp * REGION), 16, 0, 0);
+        }
+#pragma unroll
+        for (int pp = 0; pp < P; ++pp) {
+            const void *gb = xok ? (const void *)(p.x + pp * p.x_part_stride + boff) : (const void *)sln_zero_page;
+            __builtin_amdgcn_global_load_lds((glb_void *)gb, (lds_void *)(base + (P + pp) * REGION), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int g = lane >> 4;
+    const int k0 = 8 * (g >> 1);
+    if (nk > 0) issue(0);
+    if (nk > 1) issue(1);
+    for (int s = 0; s < nk; ++s) {
+        if (s + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const unsigned char *st = smem + (s % 3) * STAGE;
+        bf16x8 a[4][P], b[2][P];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int pp = 0; pp < P; ++pp)
+                b[j][pp] = tr_frag256(st + (P + pp) * REGION, k0, 64 * wc + 32 * j + 16 * (g & 1), lane);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int pp = 0; pp < P; ++pp)
+                a[i][pp] = tr_frag256(st + pp * REGION, k0, 128 * wr + 32 * i + 16 * (g & 1), lane);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) mfma_products<P>(a[0], b[j], acc[0][j]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 2 < nk) issue(s + 2);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 1; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) mfma_products<P>(a[i], b[j], acc[i][j]);
+    }
+    // epilogue: row = co, col = ci; atomics (split-K partial sums)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int ci = n0 + wc * 64 + j * 32 + (lane & 31);
+        if (ci >= p.Cin) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = m0 + wr * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (co >= p.Cout) continue;
+                const float v = acc[i][j][r];
+                if (v != 0.f) atomicAdd(p.gw + ((long)co * p.KH * p.KW + tap) * p.Cin + ci, v);
+            }
+    }
+}
+
 // ---------------------------------------------------------------- C ABI
 static inline int ew_grid(long total) {
     long g = (total + 255) / 256;
@@ -1039,6 +1171,32 @@ extern "C" int sln_conv2d_wgrad_f32(const uint16_t *gz_parts, int Cout, int Cout
     p.M = (int)M;
     p.gz_part_stride = M * Cout_pad;
     p.x_part_stride = (long)N * H * W * Cin_pad;
+    // 256x256 tiles, one block per CU, when both channel counts fill most of a tile and the pixel
+    // range gives every block enough stages; SLN_WGRAD_TILE256 = 0 never, 1 (default) rule, 2 always
+    {
+        const char *e = getenv("SLN_WGRAD_TILE256");
+        const int mode = e ? atoi(e) : 1;
+        const long gm2 = sln_div_up(Cout, T2), gn2 = sln_div_up(Cin, T2);
+        const long nt2 = gm2 * gn2 * KH * KW;
+        const bool wide = Cout >= 176 && (Cout % T2 == 0 || Cout % T2 >= 160) && Cin >= 176 &&
+                          (Cin % T2 == 0 || Cin % T2 >= 160);
+        if (mode == 2 || (mode == 1 && parts == 3 && wide && nt2 <= 256 && M >= 256L * 64)) {
+            long ks2 = 256 / nt2;                         // one round of the 256 CUs
+            const long cap = (M + 255) / 256;             // >= 16 stages per block
+            if (ks2 > cap) ks2 = cap;
+            if (ks2 < 1) ks2 = 1;
+            long pps2 = (M + ks2 - 1) / ks2;
+            pps2 = ((pps2 + T2K - 1) / T2K) * T2K;
+            ks2 = (M + pps2 - 1) / pps2;
+            p.gm = (int)gm2; p.gn_per_tap = (int)gn2; p.ksplit = (int)ks2; p.pix_per_split = (int)pps2;
+            const long nb2 = nt2 * ks2;
+            if (parts == 2)
+                hipLaunchKernelGGL(conv_wgrad256_kernel<2>, dim3((unsigned)nb2), dim3(512), 0, st, p);
+            else
+                hipLaunchKernelGGL(conv_wgrad256_kernel<3>, dim3((unsigned)nb2), dim3(512), 0, st, p);
+            return sln_launch_status();
+        }
+    }
     p.gm = sln_div_up(Cout, BM);
     p.gn_per_tap = sln_div_up(Cin, BN);
     const long ntile = (long)p.gm * p.gn_per_tap * KH * KW;

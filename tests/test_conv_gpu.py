@@ -89,8 +89,11 @@ def test_conv_forward_matches_fp64_reference(case, parts, tile, tile_mode):
 
 
 @pytest.mark.parametrize("case", [CASES[1], CASES[2], CASES[3], CASES[5], CASES[8], CASES[11], CASES[12]])
-def test_conv_backward_matches_autograd_of_unfused_ops(case):
+@pytest.mark.parametrize("tile", [128, 256])
+def test_conv_backward_matches_autograd_of_unfused_ops(case, tile, tile_mode, monkeypatch):
     from sln_amodal_amd import conv_hip
+    tile_mode(2 if tile == 256 else 0)                                   # data gradient (forward kernel)
+    monkeypatch.setenv("SLN_WGRAD_TILE256", "2" if tile == 256 else "0")   # weight gradient
     Cin, Cout, k, stride, dil, pads, H, W, N = case
     g = torch.Generator(device="cuda").manual_seed(11)
     x = torch.randn(N, Cin, H, W, device="cuda", generator=g).contiguous(memory_format=torch.channels_last)
