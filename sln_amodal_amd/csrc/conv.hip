@@ -869,6 +869,25 @@ __device__ __forceinline__ bf16x8 tr_frag256(const unsigned char *region, int k0
     return r;
 }
 
+// The same fragment through inline asm: hipcc drains the LDS-DMA queue (s_waitcnt vmcnt(0)) in front
+// of the tr-read INTRINSIC even when all LDS is one object; it cannot see into the asm, so the
+// reads are ordered by hand -- DMA landed: counted vmcnt + barrier before; data returned:
+// tr_wait() (s_waitcnt lgkmcnt(0), tied to the fragment registers) before the first MFMA use.
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+struct TrFrag { u32x2 lo, hi; };
+__device__ __forceinline__ void tr_issue(TrFrag &f, unsigned region_lds, int k0, int m0, int lane) {
+    const int li = lane & 15, q = li >> 2, pq = li & 3;
+    const int col = (m0 + 4 * pq) ^ (q << 5);
+    const unsigned a = region_lds + 2u * (unsigned)((k0 + q) * T2 + col);
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.lo) : "v"(a));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.hi) : "v"(a), "n"(4 * T2 * 2));
+}
+__device__ __forceinline__ bf16x8 tr_value(const TrFrag &f) {
+    union { u32x2 u[2]; bf16x8 v; } c;
+    c.u[0] = f.lo; c.u[1] = f.hi;
+    return c.v;
+}
+
 template <int P>
 __global__ __launch_bounds__(512) void conv_wgrad256_kernel(const WgradParams p) {
     constexpr int REGION = T2K * T2 * 2;      // one part of one operand: 16 pixel rows x 512 B = 8 KB
@@ -942,25 +961,53 @@ __global__ __launch_bounds__(512) void conv_wgrad256_kernel(const WgradParams p)
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        const unsigned char *st = smem + (s % 3) * STAGE;
+        typedef __attribute__((address_space(3))) unsigned char lds_u8;
+        const unsigned st = (unsigned)(size_t)(lds_u8 *)(smem + (s % 3) * STAGE);
+        TrFrag fa[4][P], fb[2][P];
+        const int cb = 64 * wc + 16 * (g & 1), ca = 128 * wr + 16 * (g & 1);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int pp = 0; pp < P; ++pp) tr_issue(fb[j][pp], st + (P + pp) * REGION, k0, cb + 32 * j, lane);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int pp = 0; pp < P; ++pp) tr_issue(fa[i][pp], st + pp * REGION, k0, ca + 32 * i, lane);
+        // B and A rows 0..63 have returned; A rows 64..127 are requested before the MFMAs start.
+        // sched_barrier(0): nothing (in particular no MFMA that consumes the asm's outputs) may be
+        // moved across the hand-placed wait
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 2; i < 4; ++i)
+#pragma unroll
+            for (int pp = 0; pp < P; ++pp) tr_issue(fa[i][pp], st + pp * REGION, k0, ca + 32 * i, lane);
         bf16x8 a[4][P], b[2][P];
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int pp = 0; pp < P; ++pp)
-                b[j][pp] = tr_frag256(st + (P + pp) * REGION, k0, 64 * wc + 32 * j + 16 * (g & 1), lane);
+            for (int pp = 0; pp < P; ++pp) b[j][pp] = tr_value(fb[j][pp]);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int pp = 0; pp < P; ++pp)
-                a[i][pp] = tr_frag256(st + pp * REGION, k0, 128 * wr + 32 * i + 16 * (g & 1), lane);
+            for (int pp = 0; pp < P; ++pp) a[i][pp] = tr_value(fa[i][pp]);
 #pragma unroll
         for (int j = 0; j < 2; ++j) mfma_products<P>(a[0], b[j], acc[0][j]);
         __builtin_amdgcn_sched_barrier(0);
         if (s + 2 < nk) issue(s + 2);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 1; i < 4; ++i)
+        for (int j = 0; j < 2; ++j) mfma_products<P>(a[1], b[j], acc[1][j]);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 2; i < 4; ++i)
+#pragma unroll
+            for (int pp = 0; pp < P; ++pp) a[i][pp] = tr_value(fa[i][pp]);
+#pragma unroll
+        for (int i = 2; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) mfma_products<P>(a[i], b[j], acc[i][j]);
     }
