@@ -223,6 +223,8 @@ int sln_conv2d_fwd_ms_f32(const uint16_t *x_parts, int nseg, const int32_t *seg_
 /* Tile edge (128 or 256) of the forward kernel the two functions above use for M output pixels,
  * Cout channels, K = KH*KW*Cin and `parts`: host-side rule, no GPU work (csrc/conv.hip). */
 int sln_conv_fwd_tile(int64_t M, int Cout, int64_t K, int parts);
+/* Tile edge (128 or 256) of the weight-gradient kernel sln_conv2d_wgrad_f32 uses (host-side rule). */
+int sln_conv_wgrad_tile(int64_t M, int Cout, int Cin, int taps, int parts);
 int sln_conv2d_wgrad_f32(const uint16_t *gz_parts, int Cout, int Cout_pad, const uint16_t *x_parts,
                          int N, int H, int W, int Cin, int Cin_pad, int parts, int KH, int KW,
                          int stride_h, int stride_w, int dil_h, int dil_w, int pad_top, int pad_left,

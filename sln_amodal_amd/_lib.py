@@ -40,6 +40,7 @@ SIGNATURES = {
     "sln_conv2d_fwd_ms_f32": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
                                    _p, _p, _p, _i, _p, _p, _p, _p, _p, _p]),
     "sln_conv_fwd_tile": (_i, [C.c_int64, _i, C.c_int64, _i]),
+    "sln_conv_wgrad_tile": (_i, [C.c_int64, _i, _i, _i, _i]),
     "sln_conv2d_wgrad_f32": (_i, [_p, _i, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
                                   _i, _i, _i, _i, _p, _p]),
 }

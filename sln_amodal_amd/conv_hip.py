@@ -412,7 +412,9 @@ class _ConvFn(torch.autograd.Function):
                 ops._ptr(gz), Co, gz.shape[2], ops._ptr(xp), N, H, W, Ci, xp.shape[2], parts, KH, KW,
                 stride[0], stride[1], dil[0], dil[1], pt, pl, OH, OW, ops._ptr(gw_t), ops._stream()),
                 "sln_conv2d_wgrad_f32")
-            _prof_end(e0, 2.0 * N * OH * OW * Co * KH * KW * Ci, "conv_wgrad_kernel<%d>" % parts,
+            wt_ = _lib.lib().sln_conv_wgrad_tile(N * OH * OW, Co, Ci, KH * KW, parts) if e0 is not None else 128
+            _prof_end(e0, 2.0 * N * OH * OW * Co * KH * KW * Ci,
+                      ("conv_wgrad256_kernel<%d>" if wt_ == 256 else "conv_wgrad_kernel<%d>") % parts,
                       "wgrad N%d %dx%d C%d->%d k%d s%d d%d" % (N, H, W, Ci, Co, KH, stride[0], dil[0]),
                       _nbytes(gz, xp), _nbytes(gw_t))
             gw = gw_t.permute(0, 3, 1, 2)  # logical [Co,Ci,KH,KW]

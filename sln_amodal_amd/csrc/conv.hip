@@ -1194,6 +1194,22 @@ extern "C" int sln_conv2d_fwd_f32(const uint16_t *x_parts, int N, int H, int W, 
                                  residual, relu, nullptr, nullptr, y, y_parts, nullptr, stream);
 }
 
+// Which weight-gradient kernel sln_conv2d_wgrad_f32 uses: 256 = conv_wgrad256_kernel (one (tap, 256 Cout
+// x 256 Cin) tile per block, LDS-DMA pipeline, split-K sized to one round of the 256 CUs) when both
+// channel counts fill >= 176 (>= 160 of the last 256) columns, the tap tiles fit one round and there
+// are enough pixels; else 128.  SLN_WGRAD_TILE256 = 0 never, 1 (default) by this rule, 2 always.
+extern "C" int sln_conv_wgrad_tile(int64_t M, int Cout, int Cin, int taps, int parts) {
+    const char *e = getenv("SLN_WGRAD_TILE256");
+    const int mode = e ? atoi(e) : 1;
+    if (M < 1 || Cout < 1 || Cin < 1 || taps < 1) return BM;
+    if (mode == 2) return T2;
+    if (mode != 1 || parts != 3) return BM;
+    const long nt2 = (long)sln_div_up(Cout, T2) * sln_div_up(Cin, T2) * taps;
+    const bool wide = Cout >= 176 && (Cout % T2 == 0 || Cout % T2 >= 160) && Cin >= 176 &&
+                      (Cin % T2 == 0 || Cin % T2 >= 160);
+    return (wide && nt2 <= 256 && M >= 256L * 64) ? T2 : BM;
+}
+
 extern "C" int sln_conv2d_wgrad_f32(const uint16_t *gz_parts, int Cout, int Cout_pad,
                                     const uint16_t *x_parts, int N, int H, int W, int Cin, int Cin_pad,
                                     int parts, int KH, int KW, int stride_h, int stride_w, int dil_h,
@@ -1218,16 +1234,10 @@ extern "C" int sln_conv2d_wgrad_f32(const uint16_t *gz_parts, int Cout, int Cout
     p.M = (int)M;
     p.gz_part_stride = M * Cout_pad;
     p.x_part_stride = (long)N * H * W * Cin_pad;
-    // 256x256 tiles, one block per CU, when both channel counts fill most of a tile and the pixel
-    // range gives every block enough stages; SLN_WGRAD_TILE256 = 0 never, 1 (default) rule, 2 always
     {
-        const char *e = getenv("SLN_WGRAD_TILE256");
-        const int mode = e ? atoi(e) : 1;
         const long gm2 = sln_div_up(Cout, T2), gn2 = sln_div_up(Cin, T2);
         const long nt2 = gm2 * gn2 * KH * KW;
-        const bool wide = Cout >= 176 && (Cout % T2 == 0 || Cout % T2 >= 160) && Cin >= 176 &&
-                          (Cin % T2 == 0 || Cin % T2 >= 160);
-        if (mode == 2 || (mode == 1 && parts == 3 && wide && nt2 <= 256 && M >= 256L * 64)) {
+        if (sln_conv_wgrad_tile(M, Cout, Cin, KH * KW, parts) == T2) {
             long ks2 = 256 / nt2;                         // one round of the 256 CUs
             const long cap = (M + 255) / 256;             // >= 16 stages per block
             if (ks2 > cap) ks2 = cap;

@@ -95,3 +95,21 @@ def test_forward_tile_rule_is_a_pure_host_function(monkeypatch):
     assert L.sln_conv_fwd_tile(65536, 256, 2304, 3) == 128
     monkeypatch.setenv("SLN_CONV_TILE256", "2")
     assert L.sln_conv_fwd_tile(100, 8, 8, 2) == 256
+
+
+def test_wgrad_tile_rule_is_a_pure_host_function(monkeypatch):
+    """sln_conv_wgrad_tile: 256x256 (tap, Cout, Cin) tiles only when both channel counts are wide,
+    the tap tiles fit one round of the 256 CUs and there are enough pixels."""
+    from sln_amodal_amd import _lib
+    L = _lib.lib()
+    monkeypatch.delenv("SLN_WGRAD_TILE256", raising=False)
+    assert L.sln_conv_wgrad_tile(65536, 256, 256, 9, 3) == 256      # C4 3x3
+    assert L.sln_conv_wgrad_tile(65536, 1024, 256, 1, 3) == 256     # C4 1x1 expand
+    assert L.sln_conv_wgrad_tile(1048576, 64, 64, 9, 3) == 128      # narrow channels
+    assert L.sln_conv_wgrad_tile(4096, 256, 256, 9, 3) == 128       # too few pixels
+    assert L.sln_conv_wgrad_tile(65536, 2048, 2048, 9, 3) == 128    # 576 tap tiles: more than one round
+    assert L.sln_conv_wgrad_tile(65536, 256, 256, 9, 2) == 128      # 2-part path stays on 128
+    monkeypatch.setenv("SLN_WGRAD_TILE256", "0")
+    assert L.sln_conv_wgrad_tile(65536, 256, 256, 9, 3) == 128
+    monkeypatch.setenv("SLN_WGRAD_TILE256", "2")
+    assert L.sln_conv_wgrad_tile(100, 8, 8, 1, 2) == 256
