@@ -48,6 +48,17 @@ def step_gflop_per_image(stage, dim, arch):
     return fwd + bwd
 
 
+def _pmc_for(kernel):
+    """Measured HBM bytes per launch of `kernel` over one steady-state step (committed PMC passes)."""
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_v9_pmc_traffic.json")))[kernel]["last_step"]
+        return {"hbm_read_bytes_per_launch_raw": pmc["read_bytes_per_launch_raw"],
+                "hbm_read_bytes_per_launch_x2_corrected": pmc["read_bytes_per_launch_x2_gfx950_wide_load_correction"],
+                "hbm_write_bytes_per_launch": pmc["write_bytes_per_launch"]}
+    except Exception:
+        return {}
+
+
 def dominant_kernel_roofline(prof, elapsed, parts):
     """Roofline of the dominant kernel (the split-bf16 implicit-GEMM conv), from HIP
     events recorded around every launch inside the timed region, on the launch
@@ -72,13 +83,13 @@ def dominant_kernel_roofline(prof, elapsed, parts):
     mult = 6 if parts == 3 else 3
     traffic = None
     try:   # HBM bytes per launch from the committed rocprofv3 PMC passes (not collectable live)
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_v8_pmc_traffic.json")))[name]["last_step"]
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_v9_pmc_traffic.json")))[name]["last_step"]
         traffic = {"hbm_read_bytes_per_launch_raw": pmc["read_bytes_per_launch_raw"],
                    "hbm_read_bytes_per_launch_x2_corrected": pmc["read_bytes_per_launch_x2_gfx950_wide_load_correction"],
                    "hbm_write_bytes_per_launch": pmc["write_bytes_per_launch"],
                    "algorithmic_read_bytes_per_launch": int(rd_b / n),      # live: this run's launches
                    "algorithmic_write_bytes_per_launch": int(wr_b / n),
-                   "source": "profiles/r1_v8_pmc_traffic.json, last steady-state step (rocprofv3 --pmc FETCH_SIZE / "
+                   "source": "profiles/r1_v9_pmc_traffic.json, last steady-state step (rocprofv3 --pmc FETCH_SIZE / "
                              "WRITE_SIZE, separate passes); algorithmic bytes counted live over the timed launches"}
     except Exception:
         pass
@@ -95,8 +106,12 @@ def dominant_kernel_roofline(prof, elapsed, parts):
             "share_of_step_time": round(secs / elapsed, 4),
             "bf16_mfma_tflops": round(ach * mult, 1), "bf16_mfma_peak": 2500.0,
             "bf16_mfma_frac": round(ach * mult / 2500.0, 4),
-            "other_kernels": {k: {"tflops": round(v[1] / v[0] / 1e12, 2), "launches": v[2],
-                                  "share_of_step_time": round(v[0] / elapsed, 4)}
+            "other_kernels": {k: dict({"tflops": round(v[1] / v[0] / 1e12, 2), "launches": v[2],
+                                       "share_of_step_time": round(v[0] / elapsed, 4),
+                                       "frac": round(v[1] / v[0] / 1e12 / peak, 4),
+                                       "algorithmic_read_bytes_per_launch": int(v[3] / v[2]),
+                                       "algorithmic_write_bytes_per_launch": int(v[4] / v[2])},
+                                      **_pmc_for(k))
                               for k, v in by.items() if k != name}}
 
 
