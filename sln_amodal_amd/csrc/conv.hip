@@ -714,7 +714,7 @@ struct WgradParams {
     float *gw;          // [Cout][KH][KW][Cin]
     long gz_part_stride, x_part_stride;
     int N, H, W, Cin, Cip, Cout, Cop, KH, KW, sh, sw, dh, dw, pt, pl, OH, OW;
-    int M, gm, gn_per_tap, ksplit, pix_per_split;
+    int M, gm, gn_per_tap, ksplit, pix_per_split, xcd_wgrad;
 };
 
 __device__ __forceinline__ bf16x8 tr_frag(const __bf16 *tile, int k0, int m0, int lane) {
@@ -900,7 +900,9 @@ __global__ __launch_bounds__(512) void conv_wgrad256_kernel(const WgradParams p)
     const int lane = t & 63, wave = t >> 6;
     const int wr = wave >> 2, wc = wave & 3;
     const int ntile = p.gm * p.gn_per_tap * p.KH * p.KW;
-    int bid = blockIdx.x;
+    // the tap tiles of one pixel range are consecutive block ids: keep them on one XCD (one L2), so
+    // that the range's gz rows are fetched from HBM once and not once per tap (xcd_wgrad)
+    int bid = p.xcd_wgrad ? xcd_remap(blockIdx.x, ntile * p.ksplit) : (int)blockIdx.x;
     const int split = bid / ntile;
     bid -= split * ntile;
     const int mt = bid % p.gm;
@@ -1246,6 +1248,7 @@ extern "C" int sln_conv2d_wgrad_f32(const uint16_t *gz_parts, int Cout, int Cout
             pps2 = ((pps2 + T2K - 1) / T2K) * T2K;
             ks2 = (M + pps2 - 1) / pps2;
             p.gm = (int)gm2; p.gn_per_tap = (int)gn2; p.ksplit = (int)ks2; p.pix_per_split = (int)pps2;
+            { const char *x = getenv("SLN_WGRAD_XCD"); p.xcd_wgrad = x ? atoi(x) : 1; }
             const long nb2 = nt2 * ks2;
             if (parts == 2)
                 hipLaunchKernelGGL(conv_wgrad256_kernel<2>, dim3((unsigned)nb2), dim3(512), 0, st, p);
