@@ -1102,7 +1102,7 @@ extern "C" int sln_conv_fwd_tile(int64_t M, int Cout, int64_t K, int parts) {
     // at least 176 of the last 256 columns in use (ASPP's Cout = 182: +6...11 % per launch over
     // the 128x128 kernel, which wastes the same share of its second 128-column tile)
     const bool cols = Cout >= 176 && (Cout % T2 == 0 || Cout % T2 >= 160);
-    return (cols && fill >= 0.85 && K >= 512) ? T2 : BM;
+    return (cols && fill >= 0.85 && K >= 256) ? T2 : BM;   // K >= 256: 16 stages (1x1 256 -> 1024: +3 %)
 }
 
 extern "C" int sln_conv2d_fwd_ms_f32(const uint16_t *x_parts, int nseg, const int32_t *seg_nhw, int Cin,

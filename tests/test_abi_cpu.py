@@ -84,7 +84,8 @@ def test_forward_tile_rule_is_a_pure_host_function(monkeypatch):
     monkeypatch.delenv("SLN_CONV_TILE256", raising=False)
     assert L.sln_conv_fwd_tile(65536, 256, 2304, 3) == 256       # C4 3x3: 256 tiles, one per CU
     assert L.sln_conv_fwd_tile(65536, 64, 2304, 3) == 128        # narrow output
-    assert L.sln_conv_fwd_tile(65536, 256, 256, 3) == 128        # short reduction
+    assert L.sln_conv_fwd_tile(65536, 1024, 256, 3) == 256       # 1x1 expand: 16 stages are enough
+    assert L.sln_conv_fwd_tile(65536, 256, 128, 3) == 128        # short reduction
     assert L.sln_conv_fwd_tile(67600, 256, 2304, 3) == 128       # 265 tiles: 52 % of two rounds
     assert L.sln_conv_fwd_tile(123440, 256, 2304, 3) == 256      # packed GLM scales: 483 tiles, 94 %
     assert L.sln_conv_fwd_tile(65536, 256, 2304, 2) == 128       # 2-part path stays on 128
