@@ -190,6 +190,33 @@ def test_train_step_runs_updates_and_stays_finite():
     assert set(parts) == {"layer", "rpn_bbox", "mrcnn_bbox", "mrcnn_class", "amodal", "rpn_class"}
 
 
+def test_train_step_learns_one_fixed_batch():
+    """The whole step (HIP conv stack with every backward fusion, losses, clip, SGD) reduces
+    the loss on one batch with fixed sampling priorities: 80 steps at lr 0.01 took the total from
+    3.03 to 2.06 and the two mask losses from 0.688 to 0.54 when this test was written (the
+    aten-convolution path: 3.08 -> 2.50, 0.688 -> 0.59).  Thresholds are loose: weight-gradient
+    atomics make the trajectory non-reproducible."""
+    from sln_amodal_amd import synthetic
+    m, cfg = _small_model()
+    batch = synthetic.make_batch(cfg, 2, 256, 256, seed=3, anchors_f64=m.anchors_f64)
+    synthetic.calibrate_batchnorm(m, batch["images"])
+    synthetic.calibrate_glm(m, batch["images"])
+    synthetic.warm_start_rpn(m, [batch], iters=40)
+    opt = m.make_optimizer(0.01)
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    pr = {"pos": torch.rand(2, 1000, device="cuda", generator=gen),
+          "neg": torch.rand(2, 1000, device="cuda", generator=gen)}
+    first = last = None
+    for it in range(80):
+        loss, parts = m.train_step(batch, opt, priorities=pr)
+        if it == 0:
+            first = (float(loss), float(parts["layer"]))
+    last = (float(loss), float(parts["layer"]))
+    assert np.isfinite(last[0])
+    assert last[0] < first[0] - 0.3, (first, last)
+    assert last[1] < first[1] - 0.03, (first, last)
+
+
 def test_loss_parity_hip_conv_vs_aten_conv_same_proposals():
     """Six losses with the HIP split-bf16 conv stack vs aten fp32 convs, same weights,
     batch, proposals and sampling priorities: within 1e-4 (north-star tolerance)."""
