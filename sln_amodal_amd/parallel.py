@@ -65,6 +65,7 @@ class GradientAllReducer(object):
         self._pending = [len(b) for b in self.buckets]
         self._flat = [None] * len(self.buckets)
         self._work = [None] * len(self.buckets)
+        self._next = 0          # collectives are issued strictly in bucket order on every rank
         self._hooks = []
 
     def attach(self):
@@ -77,8 +78,12 @@ class GradientAllReducer(object):
     def _on_grad(self, p):
         bi = self._owner[id(p)]
         self._pending[bi] -= 1
-        if self._pending[bi] == 0:
-            self._launch(bi)
+        # A bucket is launched only once every earlier bucket has been: ranks whose gradients
+        # arrive in a different order (or not at all: a rank without positive rois) would otherwise
+        # issue the RCCL collectives in different orders and hang.
+        while self._next < len(self.buckets) and self._pending[self._next] <= 0:
+            self._launch(self._next)
+            self._next += 1
 
     def _launch(self, bi):
         grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.buckets[bi]]
@@ -89,9 +94,10 @@ class GradientAllReducer(object):
     def finish(self):
         if self.world == 1:
             return
+        while self._next < len(self.buckets):   # grads that never arrived (unused params): reduce now, in order
+            self._launch(self._next)
+            self._next += 1
         for bi, bucket in enumerate(self.buckets):
-            if self._work[bi] is None:  # some grads never arrived (unused params): reduce now
-                self._launch(bi)
             self._work[bi].wait()
             flat = self._flat[bi]
             flat.div_(self.world)
@@ -106,6 +112,7 @@ class GradientAllReducer(object):
             self._flat[bi] = None
             self._work[bi] = None
         self._pending = [len(b) for b in self.buckets]
+        self._next = 0
 
     def __call__(self, params=None):
         self.finish()

@@ -30,8 +30,12 @@ def _worker(rank, world, port, hooks, out):
     for p in model[3].parameters():                     # an unused, trainable layer (no grad arrives)
         p.requires_grad_(True)
     parallel.broadcast_parameters(model)
-    params = [p for p in model.parameters() if p.requires_grad]
-    red = parallel.GradientAllReducer(params, bucket_bytes=256)   # several buckets
+    # parameter order chosen so that the buckets are {model[2]}, {model[0]}, {unused model[3]}: on the step
+    # where rank 1 has no gradient for model[2], its {model[0]} bucket is ready first -- the reducer must
+    # still issue the collectives in bucket order, like rank 0 (a different order mismatches / hangs)
+    params = list(model[3].parameters()) + list(model[0].parameters()) + list(model[2].parameters())
+    red = parallel.GradientAllReducer(params, bucket_bytes=128)
+    assert [len(b) for b in red.buckets] == [2, 2, 2]
     if hooks:
         red.attach()
     opt = torch.optim.SGD(params, lr=0.1)
@@ -39,7 +43,12 @@ def _worker(rank, world, port, hooks, out):
     for step in range(3):
         x = torch.randn(4, 7, generator=g)
         opt.zero_grad(set_to_none=True)
-        model[2](model[1](model[0](x))).square().mean().backward()
+        if step == 1 and rank == 1:
+            # this rank's loss does not reach model[2]: its gradients never arrive HERE but do on rank 0
+            # (a rank without positive rois); the collectives must still be issued in the same order
+            model[1](model[0](x)).square().mean().backward()
+        else:
+            model[2](model[1](model[0](x))).square().mean().backward()
         local = [p.grad.clone() if p.grad is not None else torch.zeros_like(p) for p in params]
         red.finish() if hooks else red(params)
         gathered = [torch.zeros_like(torch.cat([l.reshape(-1) for l in local])) for _ in range(world)]
@@ -66,5 +75,9 @@ def test_gradient_allreduce_world2_gloo(hooks):
         p.start()
     for p in procs:
         p.join(120)
-        assert p.exitcode == 0
+    for p in procs:
+        if p.is_alive():          # a hang (mismatched collectives) must fail the test, not the suite
+            p.terminate()
+            p.join(10)
+    assert [p.exitcode for p in procs] == [0, 0]
     assert sorted(q.get(timeout=5) for _ in range(2)) == [0, 1]
