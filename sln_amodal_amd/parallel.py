@@ -36,8 +36,13 @@ def broadcast_parameters(module, src=0):
     """Replicas start from identical weights."""
     if not (dist.is_available() and dist.is_initialized()):
         return
-    for t in list(module.parameters()) + list(module.buffers()):
-        dist.broadcast(t.data, src)
+    with torch.no_grad():
+        for t in list(module.parameters()) + list(module.buffers()):
+            dist.broadcast(t.data, src)
+            # Caches derived from these tensors (bf16 weight parts, frozen-BN scale/shift) are keyed
+            # by the tensors' version counters, which writing through `.data` does not advance: bump
+            # them, or a rank would keep computing with what it held before the broadcast.
+            t.mul_(1)
 
 
 class GradientAllReducer(object):

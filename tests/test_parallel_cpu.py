@@ -29,7 +29,19 @@ def _worker(rank, world, port, hooks, out):
                                 torch.nn.Linear(3, 5))
     for p in model[3].parameters():                     # an unused, trainable layer (no grad arrives)
         p.requires_grad_(True)
+    # caches keyed by version counters (conv weight parts, frozen-BN affine) must see the broadcast
+    from sln_amodal_amd import nn_ops
+    bn = torch.nn.BatchNorm2d(4).eval()
+    bn.weight.requires_grad = bn.bias.requires_grad = False
+    with torch.no_grad():
+        bn.running_mean.fill_(float(rank + 1)); bn.running_var.fill_(float(rank + 2))
+    scale_before, _ = nn_ops.bn_affine(bn)                # cached with THIS rank's statistics
+    v0 = [p._version for p in model.parameters()]
     parallel.broadcast_parameters(model)
+    parallel.broadcast_parameters(bn)
+    assert all(p._version > a for p, a in zip(model.parameters(), v0))
+    scale_after, _ = nn_ops.bn_affine(bn)
+    assert torch.allclose(scale_after, torch.full((4,), (2.0 + bn.eps) ** -0.5)), (rank, scale_after)   # rank 0's var = 2
     # parameter order chosen so that the buckets are {model[2]}, {model[0]}, {unused model[3]}: on the step
     # where rank 1 has no gradient for model[2], its {model[0]} bucket is ready first -- the reducer must
     # still issue the collectives in bucket order, like rank 0 (a different order mismatches / hangs)
