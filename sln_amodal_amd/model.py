@@ -296,9 +296,11 @@ class MaskRCNN(nn.Module):
         loss, parts = self.compute_losses(out, batch["rpn_match"], batch["rpn_bbox"])
         optimizer.zero_grad(set_to_none=True)
         loss.backward()
-        params = [p for p in self.parameters() if p.requires_grad and p.grad is not None]
         if grad_sync is not None:
-            grad_sync(params)
+            grad_sync([p for p in self.parameters() if p.requires_grad])
+        # after the all-reduce: a parameter without a local gradient may have received one from a peer,
+        # and every rank must clip over the same set
+        params = [p for p in self.parameters() if p.requires_grad and p.grad is not None]
         torch.nn.utils.clip_grad_norm_(params, self.config.GRADIENT_CLIP_NORM)
         optimizer.step()
         return loss.detach(), parts
