@@ -1096,7 +1096,7 @@ extern "C" int sln_conv_fwd_tile(int64_t M, int Cout, int64_t K, int parts) {
     const int mode = e ? atoi(e) : 1;
     if (M < 1 || Cout < 1 || M > 2147483647L - T2) return BM;
     if (mode == 2) return T2;
-    if (mode != 1 || parts != 3) return BM;
+    if (mode != 1 || (parts != 3 && !getenv("SLN_TILE256_P2"))) return BM;   // P2 knob: preview runs only
     const long nb2 = sln_div_up(M, T2) * (long)sln_div_up(Cout, T2);
     const double fill = (double)nb2 / (double)(sln_div_up(nb2, 256) * 256L);
     // at least 176 of the last 256 columns in use (ASPP's Cout = 182: +6...11 % per launch over
@@ -1205,7 +1205,7 @@ extern "C" int sln_conv_wgrad_tile(int64_t M, int Cout, int Cin, int taps, int p
     const int mode = e ? atoi(e) : 1;
     if (M < 1 || Cout < 1 || Cin < 1 || taps < 1) return BM;
     if (mode == 2) return T2;
-    if (mode != 1 || parts != 3) return BM;
+    if (mode != 1 || (parts != 3 && !getenv("SLN_TILE256_P2"))) return BM;   // P2 knob: preview runs only
     const long nt2 = (long)sln_div_up(Cout, T2) * sln_div_up(Cin, T2) * taps;
     const bool wide = Cout >= 176 && (Cout % T2 == 0 || Cout % T2 >= 160) && Cin >= 176 &&
                       (Cin % T2 == 0 || Cin % T2 >= 160);
