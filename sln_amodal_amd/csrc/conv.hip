@@ -257,11 +257,13 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 }
 
 // One 64-row slab of an output tile, already staged as fp32 in LDS (row stride LD floats):
-// thread t owns columns 4*(t % NCOLQ)..+3 of rows t/NCOLQ + 8q (q = 0..7).  Per element:
+// thread t owns columns 4*(t % NCOLQ)..+3 of rows t/NCOLQ + RG*q (RG = NTHREADS/NCOLQ row groups).  Per element:
 // v = acc*scale[c] + shift[c] (+ residual) (ReLU) (mask) -> y; parts / colsum of v (* post_scale).
-template <int P, int NCOLQ, int LD>
+template <int P, int NCOLQ, int LD, int NTHREADS>
 __device__ __forceinline__ void epilogue_slab(const ConvParams &p, const float *stage, int m_base, int n0,
                                               int t, float *s_colsum) {
+    constexpr int RG = NTHREADS / NCOLQ;      // row groups: thread t owns rows t/NCOLQ + RG*q
+    constexpr int NQ = 64 / RG;
     const bool vec_ok = (p.Cout & 3) == 0;
     const int c = n0 + 4 * (t & (NCOLQ - 1));
     if (c < p.Cout) {
@@ -275,27 +277,27 @@ __device__ __forceinline__ void epilogue_slab(const ConvParams &p, const float *
             }
         // all residual rows of this half are requested before the first store: the
         // loads cannot be moved across the y stores by the compiler (may alias)
-        float4 res4[8], msk4[8];
+        float4 res4[NQ], msk4[NQ];
         if (vec_ok && p.residual) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int m = m_base + (t / NCOLQ) + 8 * q;
+            for (int q = 0; q < NQ; ++q) {
+                const int m = m_base + (t / NCOLQ) + RG * q;
                 res4[q] = m < p.M ? *(const float4 *)(p.residual + (long)m * p.Cout + c)
                                   : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
         if (vec_ok && p.mask) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int m = m_base + (t / NCOLQ) + 8 * q;
+            for (int q = 0; q < NQ; ++q) {
+                const int m = m_base + (t / NCOLQ) + RG * q;
                 msk4[q] = m < p.M ? *(const float4 *)(p.mask + (long)m * p.Cout + c)
                                   : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
         float csum[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int row = (t / NCOLQ) + 8 * q;
+        for (int q = 0; q < NQ; ++q) {
+            const int row = (t / NCOLQ) + RG * q;
             const int m = m_base + row;
             if (m >= p.M) continue;
             const float4 a4 = *(const float4 *)&stage[row * LD + 4 * (t & (NCOLQ - 1))];
@@ -355,26 +357,32 @@ __device__ __forceinline__ void epilogue_slab(const ConvParams &p, const float *
     }
 }
 
-template <int P>
+// BNT = 128: waves 2x2, each 64x64 (2x2 MFMA tiles).  BNT = 64 (Cout <= 64: the C2 stage): waves 4x1,
+// each 32x64 (1x2 tiles) -- half the B tile and half the MFMAs of a 128-wide tile that would be half empty.
+template <int P, int BNT>
 __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvParams p) {
+    constexpr int NI = BNT == 128 ? 2 : 1;        // 32-row MFMA tiles per wave along M
+    constexpr int NBI = BNT / 64;                 // 64-row staging passes of the B tile
+    constexpr int SLD = BNT + 4;                  // staging slab row stride (floats)
     // one LDS region: operand tiles during the k-loop, fp32 staging tile in the epilogue
     // Operand rows are 32 bf16 = 64 B, unpadded; the 16-B chunk index is XOR-swizzled
     // with bits 2..3 of the row, so the 16 rows a ds_read_b128 group touches cover
     // all 16 four-bank groups (conflict-free) and a block needs 48 KB -> 3 blocks/CU.
-    constexpr int TILE_B = 2 * P * BM * BK * 2, STAGE_B = 64 * 132 * 4;
+    constexpr int TILE_B = P * (BM + BNT) * BK * 2, STAGE_B = 64 * SLD * 4;
     __shared__ __attribute__((aligned(16))) unsigned char smem[TILE_B > STAGE_B ? TILE_B : STAGE_B];
     typedef __bf16 (*tile_t)[BM][BK];
+    typedef __bf16 (*tileb_t)[BNT][BK];
     tile_t sA = (tile_t)smem;
-    tile_t sB = (tile_t)(smem + P * BM * BK * 2);
-    __shared__ float s_colsum[BN];   // per-block column sums of the output (colsum mode)
-    if (threadIdx.x < BN) s_colsum[threadIdx.x] = 0.f;   // ordered by the k-loop's barriers
+    tileb_t sB = (tileb_t)(smem + P * BM * BK * 2);
+    __shared__ float s_colsum[BNT];   // per-block column sums of the output (colsum mode)
+    if (threadIdx.x < BNT) s_colsum[threadIdx.x] = 0.f;   // ordered by the k-loop's barriers
 
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = BNT == 128 ? wave >> 1 : wave, wc = BNT == 128 ? wave & 1 : 0;   // wave tile (32*NI) x 64
     const int bid = xcd_remap(blockIdx.x, p.gm * p.gn);
     const int m0 = (bid / p.gn) * BM;
-    const int n0 = (bid % p.gn) * BN;
+    const int n0 = (bid % p.gn) * BNT;
 
     // each thread stages two 16-B chunks per part for A and for B:
     // row = (t>>2) + 64*i (i = 0,1), chunk = t&3 (8 bf16 each)
@@ -400,16 +408,16 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvParams p) {
         a_iw0[i] = ow * p.sw - p.pl;
         a_nbase[i] = (long)p.seg_x0[sg] + (long)n * a_H[i] * a_W[i];
     }
-    bool b_ok[2];
-    const __bf16 *bptr[2];
+    bool b_ok[NBI];
+    const __bf16 *bptr[NBI];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NBI; ++i) {
         const int row = (t >> 2) + 64 * i;
         b_ok[i] = (n0 + row) < p.Cout;
         bptr[i] = p.w + (long)(n0 + (b_ok[i] ? row : 0)) * p.Ktot;
     }
 
-    bf16x8 ra[P][2], rb[P][2];
+    bf16x8 ra[P][2], rb[P][NBI];
     const int nk = p.KH * p.KW * p.cin_chunks;
     const bf16x8 zero8 = {};
 
@@ -441,7 +449,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvParams p) {
         }
         const long koff = (long)tap * p.Cin + ci;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < NBI; ++i)
 #pragma unroll
             for (int pp = 0; pp < P; ++pp)
                 rb[pp][i] = (b_ok[i] && cok) ? *(const bf16x8 *)(bptr[i] + pp * p.w_part_stride + koff)
@@ -455,14 +463,14 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvParams p) {
 #pragma unroll
             for (int pp = 0; pp < P; ++pp) {
                 *(bf16x8 *)&sA[pp][row][schunk] = ra[pp][i];
-                *(bf16x8 *)&sB[pp][row][schunk] = rb[pp][i];
+                if (i < NBI) *(bf16x8 *)&sB[pp][row][schunk] = rb[pp][i < NBI ? i : 0];
             }
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[NI][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -477,16 +485,18 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvParams p) {
         if (ks + 1 < nk) load_tile(ks + 1);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 a[2][P], b[2][P];
+            bf16x8 a[NI][P], b[2][P];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int pp = 0; pp < P; ++pp) {
-                    a[i][pp] = *(const bf16x8 *)&sA[pp][wr * 64 + i * 32 + frow][((kk * 2 + fhi) ^ fsw) * 8];
+                    if (i < NI)
+                        a[i < NI ? i : 0][pp] =
+                            *(const bf16x8 *)&sA[pp][wr * (32 * NI) + i * 32 + frow][((kk * 2 + fhi) ^ fsw) * 8];
                     b[i][pp] = *(const bf16x8 *)&sB[pp][wc * 64 + i * 32 + frow][((kk * 2 + fhi) ^ fsw) * 8];
                 }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < NI; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) mfma_products<P>(a[i], b[j], acc[i][j]);
         }
@@ -502,24 +512,26 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvParams p) {
     // fp32 tile is staged in two 64-row halves ([64][132] floats, reusing the operand
     // tiles), read back row-major: thread t owns columns 4*(t&31)..+3 of rows
     // (t>>5) + 8q.  Per element: v = acc*scale[c] + shift[c] (+ residual) (ReLU).
-    float(*stage)[132] = (float(*)[132])smem;
+    float(*stage)[SLD] = (float(*)[SLD])smem;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        if (wr == h) {
+        // rows 64h .. 64h+63 of the tile: waves wr == h (BNT 128, 64 rows each) or wr>>1 == h (BNT 64, 32 each)
+        if ((BNT == 128 ? wr : wr >> 1) == h) {
+            const int rbase = BNT == 128 ? 0 : (wr & 1) * 32;
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < NI; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        stage[i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)][wc * 64 + j * 32 + (lane & 31)] =
+                        stage[rbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)][wc * 64 + j * 32 + (lane & 31)] =
                             acc[i][j][r];
         }
         __syncthreads();
-        epilogue_slab<P, 32, 132>(p, &stage[0][0], m0 + h * 64, n0, t, s_colsum);
+        epilogue_slab<P, BNT / 4, SLD, 256>(p, &stage[0][0], m0 + h * 64, n0, t, s_colsum);
         __syncthreads();
     }
-    if (p.colsum && t < BN && n0 + t < p.Cout && s_colsum[t] != 0.f)   // one global atomic per column
+    if (p.colsum && t < BNT && n0 + t < p.Cout && s_colsum[t] != 0.f)   // one global atomic per column
         atomicAdd(p.colsum + n0 + t, s_colsum[t]);
 }
 
@@ -692,7 +704,7 @@ __global__ __launch_bounds__(512) void conv_fwd256_kernel(const ConvParams p) {
                               (lane & 31)] = acc[2 * (h & 1) + ii][j][r];
         }
         __syncthreads();
-        epilogue_slab<P, 64, 260>(p, stage, m0 + h * 64, n0, t, s_colsum);
+        epilogue_slab<P, 64, 260, 512>(p, stage, m0 + h * 64, n0, t, s_colsum);
         __syncthreads();
     }
     if (p.colsum && t < T2 && n0 + t < p.Cout && s_colsum[t] != 0.f) atomicAdd(p.colsum + n0 + t, s_colsum[t]);
@@ -1165,14 +1177,18 @@ extern "C" int sln_conv2d_fwd_ms_f32(const uint16_t *x_parts, int nseg, const in
             hipLaunchKernelGGL(conv_fwd256_kernel<3>, dim3((unsigned)nb2), dim3(512), 0, (hipStream_t)stream, p);
         return sln_launch_status();
     }
+    // 64-wide N tile when the whole output is at most 64 channels wide (SLN_CONV_BN64=0 disables)
+    const char *e64 = getenv("SLN_CONV_BN64");
+    const bool narrow = Cout <= 64 && !(e64 && atoi(e64) == 0);
     p.gm = sln_div_up(M, BM);
-    p.gn = sln_div_up(Cout, BN);
+    p.gn = sln_div_up(Cout, narrow ? 64 : BN);
     const long nblk = (long)p.gm * p.gn;
     if (nblk > 2147483647L) return SLN_ERR_UNSUPPORTED;
-    if (parts == 2)
-        hipLaunchKernelGGL(conv_fwd_kernel<2>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, p);
-    else
-        hipLaunchKernelGGL(conv_fwd_kernel<3>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, p);
+    const dim3 g((unsigned)nblk), b(256);
+    if (parts == 2 && narrow) hipLaunchKernelGGL((conv_fwd_kernel<2, 64>), g, b, 0, (hipStream_t)stream, p);
+    else if (parts == 2) hipLaunchKernelGGL((conv_fwd_kernel<2, 128>), g, b, 0, (hipStream_t)stream, p);
+    else if (narrow) hipLaunchKernelGGL((conv_fwd_kernel<3, 64>), g, b, 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((conv_fwd_kernel<3, 128>), g, b, 0, (hipStream_t)stream, p);
     return sln_launch_status();
 }
 
