@@ -718,7 +718,6 @@ __global__ __launch_bounds__(512) void conv_fwd256_kernel(const ConvParams p) {
 // (8 consecutive k per lane) are fetched with two ds_read_b64_tr_b16 each.
 // Split-K over pixel chunks, fp32 atomics into the (callee-zeroed) gradient.
 // (An unpadded XOR-swizzled image, 3 blocks/CU, measured 1-3 % slower here.)
-#define WLD 160  // padded row length in bf16 (320 B)
 
 struct WgradParams {
     const __bf16 *gz;   // [P][M][Cop]
@@ -729,24 +728,29 @@ struct WgradParams {
     int M, gm, gn_per_tap, ksplit, pix_per_split, xcd_wgrad;
 };
 
+template <int LD>
 __device__ __forceinline__ bf16x8 tr_frag(const __bf16 *tile, int k0, int m0, int lane) {
     // lane 4q+p of a 16-lane group addresses row k0+q, columns m0+4p..+3; the group
     // receives the 4x16 block transposed: lane i gets column m0+i, rows k0..k0+3.
     const int li = lane & 15, q = li >> 2, pq = li & 3;
     typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
-    const __bf16 *p0 = tile + (k0 + q) * WLD + m0 + 4 * pq;
+    const __bf16 *p0 = tile + (k0 + q) * LD + m0 + 4 * pq;
     const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)p0);
-    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(p0 + 4 * WLD));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(p0 + 4 * LD));
     bf16x8 r;
     r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
     r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
     return r;
 }
 
-template <int P>
+// TM x TN output tile (Cout x Cin of one tap), 128 or 64 each: 2x2 waves of (TM/2) x (TN/2); the 64-wide
+// sides serve the 64-channel C2 stage, where a 128-wide tile would be half (or three quarters) empty.
+template <int P, int TM, int TN>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
-    __shared__ __attribute__((aligned(16))) __bf16 sA[P][BK][WLD];  // [k=pix][m=co]
-    __shared__ __attribute__((aligned(16))) __bf16 sB[P][BK][WLD];  // [k=pix][n=ci]
+    constexpr int LDA = TM + 32, LDB = TN + 32;    // +32 bf16 (64 B): the four k-rows of a tr read 16 banks apart
+    constexpr int NA = TM / 64, NB = TN / 64;      // 32-wide MFMA tiles per wave along M / N
+    __shared__ __attribute__((aligned(16))) __bf16 sA[P][BK][LDA];  // [k=pix][m=co]
+    __shared__ __attribute__((aligned(16))) __bf16 sB[P][BK][LDB];  // [k=pix][n=ci]
 
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
@@ -760,13 +764,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     const int nt = rest % p.gn_per_tap;
     const int tap = rest / p.gn_per_tap;
     const int kh = tap / p.KW, kw = tap - kh * p.KW;
-    const int m0 = mt * BM, n0 = nt * BN;
+    const int m0 = mt * TM, n0 = nt * TN;
 
     // staging: a tile part is 32 rows x 128 bf16 = 32 x 16 chunks of 16 B; thread t
     // handles rows (t>>4) and (t>>4)+16, chunk t&15
     const int ch = (t & 15) * 8;
-    const bool a_cok = (m0 + ch) < p.Cop;
-    const bool b_cok = (n0 + ch) < p.Cip;
+    const bool a_cok = ch < TM && (m0 + ch) < p.Cop;
+    const bool b_cok = ch < TN && (n0 + ch) < p.Cip;
     const int pix_begin = split * p.pix_per_split;
     const int pix_end = min(p.M, pix_begin + p.pix_per_split);
     const int nk = (pix_end - pix_begin + BK - 1) / BK;
@@ -800,17 +804,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
             const int row = (t >> 4) + 16 * i;
 #pragma unroll
             for (int pp = 0; pp < P; ++pp) {
-                *(bf16x8 *)&sA[pp][row][ch] = ra[pp][i];
-                *(bf16x8 *)&sB[pp][row][ch] = rb[pp][i];
+                if (ch < TM) *(bf16x8 *)&sA[pp][row][ch] = ra[pp][i];
+                if (ch < TN) *(bf16x8 *)&sB[pp][row][ch] = rb[pp][i];
             }
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[NA][NB];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NA; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NB; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -824,19 +828,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
         if (ks + 1 < nk) load_tile(ks + 1);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 a[2][P], b[2][P];
+            bf16x8 a[NA][P], b[NB][P];
             const int k0 = kk * 16 + 8 * (g >> 1);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < NA; ++i)
 #pragma unroll
-                for (int pp = 0; pp < P; ++pp) {
-                    a[i][pp] = tr_frag(&sA[pp][0][0], k0, wr * 64 + i * 32 + 16 * (g & 1), lane);
-                    b[i][pp] = tr_frag(&sB[pp][0][0], k0, wc * 64 + i * 32 + 16 * (g & 1), lane);
-                }
+                for (int pp = 0; pp < P; ++pp)
+                    a[i][pp] = tr_frag<LDA>(&sA[pp][0][0], k0, wr * (TM / 2) + i * 32 + 16 * (g & 1), lane);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < NB; ++j)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) mfma_products<P>(a[i], b[j], acc[i][j]);
+                for (int pp = 0; pp < P; ++pp)
+                    b[j][pp] = tr_frag<LDB>(&sB[pp][0][0], k0, wc * (TN / 2) + j * 32 + 16 * (g & 1), lane);
+#pragma unroll
+            for (int i = 0; i < NA; ++i)
+#pragma unroll
+                for (int j = 0; j < NB; ++j) mfma_products<P>(a[i], b[j], acc[i][j]);
         }
         __syncthreads();
         if (ks + 1 < nk) {
@@ -846,14 +853,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     }
     // epilogue: row = co, col = ci; atomics (split-K partial sums)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int ci = n0 + wc * 64 + j * 32 + (lane & 31);
+    for (int j = 0; j < NB; ++j) {
+        const int ci = n0 + wc * (TN / 2) + j * 32 + (lane & 31);
         if (ci >= p.Cin) continue;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < NA; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int co = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int co = m0 + wr * (TM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (co >= p.Cout) continue;
                 const float v = acc[i][j][r];
                 if (v != 0.f) atomicAdd(p.gw + ((long)co * p.KH * p.KW + tap) * p.Cin + ci, v);
@@ -1273,8 +1280,11 @@ extern "C" int sln_conv2d_wgrad_f32(const uint16_t *gz_parts, int Cout, int Cout
             return sln_launch_status();
         }
     }
-    p.gm = sln_div_up(Cout, BM);
-    p.gn_per_tap = sln_div_up(Cin, BN);
+    const char *e64 = getenv("SLN_WGRAD_T64");                 // 0 disables the 64-wide sides
+    const bool t64 = !(e64 && atoi(e64) == 0);
+    const int TMs = (t64 && Cout <= 64) ? 64 : BM, TNs = (t64 && Cin <= 64) ? 64 : BN;
+    p.gm = sln_div_up(Cout, TMs);
+    p.gn_per_tap = sln_div_up(Cin, TNs);
     const long ntile = (long)p.gm * p.gn_per_tap * KH * KW;
     // split the pixel range: ~24 blocks per CU (short blocks balance the tail; swept 2..32
     // on the train step), but at least 1024 pixels (32 k-steps) per block
@@ -1289,9 +1299,15 @@ extern "C" int sln_conv2d_wgrad_f32(const uint16_t *gz_parts, int Cout, int Cout
     p.pix_per_split = (int)pps;
     const long nblk = ntile * ks;
     if (nblk > 2147483647L) return SLN_ERR_UNSUPPORTED;
-    if (parts == 2)
-        hipLaunchKernelGGL(conv_wgrad_kernel<2>, dim3((unsigned)nblk), dim3(256), 0, st, p);
-    else
-        hipLaunchKernelGGL(conv_wgrad_kernel<3>, dim3((unsigned)nblk), dim3(256), 0, st, p);
+    const dim3 g((unsigned)nblk), b(256);
+#define SLN_WG(PP, A, B) hipLaunchKernelGGL((conv_wgrad_kernel<PP, A, B>), g, b, 0, st, p)
+    if (parts == 2) {
+        if (TMs == 64 && TNs == 64) SLN_WG(2, 64, 64); else if (TMs == 64) SLN_WG(2, 64, 128);
+        else if (TNs == 64) SLN_WG(2, 128, 64); else SLN_WG(2, 128, 128);
+    } else {
+        if (TMs == 64 && TNs == 64) SLN_WG(3, 64, 64); else if (TMs == 64) SLN_WG(3, 64, 128);
+        else if (TNs == 64) SLN_WG(3, 128, 64); else SLN_WG(3, 128, 128);
+    }
+#undef SLN_WG
     return sln_launch_status();
 }
