@@ -51,7 +51,7 @@ def step_gflop_per_image(stage, dim, arch):
 def _pmc_for(kernel):
     """Measured HBM bytes per launch of `kernel` over one steady-state step (committed PMC passes)."""
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_v10_pmc_traffic.json")))[kernel]["last_step"]
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_v11_pmc_traffic.json")))[kernel]["last_step"]
         return {"hbm_read_bytes_per_launch_raw": pmc["read_bytes_per_launch_raw"],
                 "hbm_read_bytes_per_launch_x2_corrected": pmc["read_bytes_per_launch_x2_gfx950_wide_load_correction"],
                 "hbm_write_bytes_per_launch": pmc["write_bytes_per_launch"]}
@@ -83,13 +83,13 @@ def dominant_kernel_roofline(prof, elapsed, parts):
     mult = 6 if parts == 3 else 3
     traffic = None
     try:   # HBM bytes per launch from the committed rocprofv3 PMC passes (not collectable live)
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_v10_pmc_traffic.json")))[name]["last_step"]
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_v11_pmc_traffic.json")))[name]["last_step"]
         traffic = {"hbm_read_bytes_per_launch_raw": pmc["read_bytes_per_launch_raw"],
                    "hbm_read_bytes_per_launch_x2_corrected": pmc["read_bytes_per_launch_x2_gfx950_wide_load_correction"],
                    "hbm_write_bytes_per_launch": pmc["write_bytes_per_launch"],
                    "algorithmic_read_bytes_per_launch": int(rd_b / n),      # live: this run's launches
                    "algorithmic_write_bytes_per_launch": int(wr_b / n),
-                   "source": "profiles/r1_v10_pmc_traffic.json, last steady-state step (rocprofv3 --pmc FETCH_SIZE / "
+                   "source": "profiles/r1_v11_pmc_traffic.json, last steady-state step (rocprofv3 --pmc FETCH_SIZE / "
                              "WRITE_SIZE, separate passes); algorithmic bytes counted live over the timed launches"}
     except Exception:
         pass
