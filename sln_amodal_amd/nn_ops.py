@@ -108,6 +108,12 @@ def max_pool_same(x, kernel, stride):
     input is post-ReLU."""
     pt, pb = same_pad(x.shape[2], kernel, stride)
     pl, pr = same_pad(x.shape[3], kernel, stride)
+    H, W = x.shape[2], x.shape[3]
+    if pt == 0 and pl == 0 and pb < kernel and pr < kernel and \
+            -(-(H - kernel) // stride) + 1 == -(-H // stride) and -(-(W - kernel) // stride) + 1 == -(-W // stride):
+        # bottom/right padding only (the even sizes of the path): a clipped last window equals a
+        # zero-padded one for the non-negative input, and ceil_mode saves the padded copy of the map
+        return F.max_pool2d(x, kernel, stride, padding=0, ceil_mode=True)
     return F.max_pool2d(F.pad(x, (pl, pr, pt, pb)), kernel, stride)
 
 
