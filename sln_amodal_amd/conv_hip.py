@@ -320,12 +320,18 @@ class _ConvFn(torch.autograd.Function):
                 (not with_res or (CHAIN_BLOCK_OUTPUT and relu)):
             chain_out.update(active=True, scale=scale, relu=bool(relu), parts=parts, with_res=with_res,
                              want_bias=bool(bias is not None and ctx.needs_input_grad[2]))
-            ctx.chain_out = chain_out
+            chain_out.setdefault("readers", 1)      # 2: two sibling convs read the output (RPN heads)
+            if chain_out["readers"] == 2:
+                if with_res:
+                    chain_out["active"] = False     # (not needed on the path: keep the simple cases)
+                else:
+                    ctx.set_materialize_grads(False)   # both readers return None: backward sees gy = None
+            ctx.chain_out = chain_out if chain_out["active"] else None
         # (a block output's reader must also carry the shortcut's gradient: only as a link head)
         if CHAIN_GRAD_PREP and chain_in is not None and chain_in.get("active") and stride == (1, 1) and \
                 ctx.needs_input_grad[0] and chain_in["parts"] == parts and \
                 (not chain_in["with_res"] or ctx.link_head is not None):
-            chain_in["consumer"] = True
+            chain_in["consumer"] = chain_in.get("consumer", 0) + 1
             ctx.chain_in = chain_in
         # the producer's ReLU mask is this layer's own input: saved here as an input tensor
         # (the shared dict must not hold activations: a dict -> output -> grad_fn -> ctx -> dict
@@ -334,6 +340,7 @@ class _ConvFn(torch.autograd.Function):
         ctx.save_for_backward(xp if need_w else None, weight, scale, y if relu else None, mask_x)
         ctx.cfg = (stride, dil, pads, relu, bias is not None, residual is not None, (N, Ci, H, W),
                    parts)
+        ctx.out_hw = (OH, OW)
         return y
 
     @staticmethod
@@ -343,12 +350,23 @@ class _ConvFn(torch.autograd.Function):
         pt, pb, pl, pr = pads
         Co, Ci, KH, KW = weight.shape
         N, _, H, W = xshape
-        OH, OW = gy.shape[2], gy.shape[3]
+        OH, OW = ctx.out_hw if gy is None else (gy.shape[2], gy.shape[3])
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         want_res = has_res and ctx.needs_input_grad[5]
         want_bias = has_bias and ctx.needs_input_grad[2]
         ch = ctx.chain_out
-        if ch is not None and ch.get("consumer"):
+        if ch is not None and ch.get("readers") == 2 and ch.get("consumer") != 2:
+            ch = None                      # only one of the two readers took part: ordinary path
+            if gy is None:
+                raise RuntimeError("chained gradient: no gradient arrived for a two-reader activation")
+        if ch is not None and ch.get("readers") == 2:
+            if gy is not None or "gz" not in ch:
+                raise RuntimeError("chained gradient: a two-reader activation has a third consumer, or "
+                                   "one of its readers did not run")
+            gz, g_res = ch.pop("gz"), None
+            g_bias = ch.pop("gbias") if want_bias else None
+            CHAIN_STATS[1] += 1
+        elif ch is not None and ch.get("consumer"):
             # what arrives must be exactly what the reader produced: the zero-stride placeholder,
             # or (block outputs) the reader's own masked dx -- anything else means autograd added a
             # second reader's gradient, which the handed-over parts do not contain
@@ -375,7 +393,27 @@ class _ConvFn(torch.autograd.Function):
             raise RuntimeError("identity-shortcut gradient was handed over but dx is not computed")
         if need_x:
             wt = _split_weights(weight, flip_swap=True, parts=parts)
-            if ctx.chain_in is not None and ctx.chain_in["with_res"]:
+            two = ctx.chain_in is not None and ctx.chain_in.get("readers") == 2
+            if two and ctx.chain_in.get("consumer") != 2:
+                two = False
+                ctx.chain_in = None                 # the sibling is not chained: ordinary data gradient
+            if two and "partial" not in ctx.chain_in:
+                # first of the two readers to run: plain fp32 data gradient, parked for the sibling
+                ctx.chain_in["partial"] = _fwd(gz, N, OH, OW, wt, Ci, KH, KW, (1, 1), dil,
+                                               dil[0] * (KH - 1) - pt, dil[1] * (KW - 1) - pl, H, W, None, None,
+                                               None, False, cin=Co)
+                gx = None
+            elif two:
+                ci = ctx.chain_in
+                _, gz_up, gb_up = _fwd(gz, N, OH, OW, wt, Ci, KH, KW, (1, 1), dil, dil[0] * (KH - 1) - pt,
+                                       dil[1] * (KW - 1) - pl, H, W, None, None, _nhwc(ci.pop("partial")), False,
+                                       cin=Co, out_parts=True,
+                                       mask=_nhwc(mask_x) if mask_x is not None else None, want_y=False,
+                                       want_colsum=ci["want_bias"], post_scale=ci["scale"])
+                ci["gz"], ci["gbias"] = gz_up, gb_up
+                gx = None
+                CHAIN_STATS[0] += 1
+            elif ctx.chain_in is not None and ctx.chain_in["with_res"]:
                 ci = ctx.chain_in
                 gx, gz_up, gb_up = _fwd(gz, N, OH, OW, wt, Ci, KH, KW, (1, 1), dil, dil[0] * (KH - 1) - pt,
                                         dil[1] * (KW - 1) - pl, H, W, None, None,
@@ -391,7 +429,7 @@ class _ConvFn(torch.autograd.Function):
                                        out_parts=True, mask=_nhwc(mask_x) if mask_x is not None else None,
                                        want_y=False, want_colsum=ci["want_bias"])
                 ci["gz"], ci["gbias"] = gz_up, gb_up
-                gx = _dummy_grad(gy.device).expand(N, Ci, H, W)   # never read: see chain_out above
+                gx = _dummy_grad(weight.device).expand(N, Ci, H, W)   # never read: see chain_out above
                 CHAIN_STATS[0] += 1
             elif stride == (1, 1):
                 gx = _fwd(gz, N, OH, OW, wt, Ci, KH, KW, (1, 1), dil, dil[0] * (KH - 1) - pt,
@@ -401,12 +439,12 @@ class _ConvFn(torch.autograd.Function):
                 # strided 1x1: the gradient lives on the stride lattice, zero elsewhere
                 small = _fwd(gz, N, OH, OW, wt, Ci, 1, 1, (1, 1), (1, 1), 0, 0, OH, OW, None, None,
                              None, False, cin=Co)
-                gx = torch.zeros((N, H, W, Ci), dtype=torch.float32, device=gy.device).permute(0, 3, 1, 2)
+                gx = torch.zeros((N, H, W, Ci), dtype=torch.float32, device=weight.device).permute(0, 3, 1, 2)
                 gx[:, :, ::stride[0], ::stride[1]] = small
             else:
                 raise NotImplementedError("data gradient of a strided %dx%d conv" % (KH, KW))
         if need_w:
-            gw_t = torch.empty((Co, KH, KW, Ci), dtype=torch.float32, device=gy.device)
+            gw_t = torch.empty((Co, KH, KW, Ci), dtype=torch.float32, device=weight.device)
             e0 = _prof_begin()
             _lib.check(_lib.lib().sln_conv2d_wgrad_f32(
                 ops._ptr(gz), Co, gz.shape[2], ops._ptr(xp), N, H, W, Ci, xp.shape[2], parts, KH, KW,

@@ -44,6 +44,9 @@ def roi_levels(boxes, image_shape):
     return lvl.round().int().clamp(2, 5).view(-1)
 
 
+import os
+CHAIN_TWO_READERS = os.environ.get("SLN_CHAIN_TWO_READERS", "1") != "0"   # RPN heads (A/B switch)
+
 class _PyramidCrop(torch.autograd.Function):
     """All-level crop in one launch; gradient flows to the four maps only."""
 
@@ -308,11 +311,14 @@ class RPN(nn.Module):
 
     def forward(self, x):
         B = x.shape[0]
-        x = nn_ops.conv_bn_act(x, self.conv_shared, relu=True, same=True)
+        # the shared map has exactly two readers (the two 1x1 heads): whichever data gradient runs second
+        # adds the first one, applies the ReLU mask and hands conv_shared its prepared gradient
+        ch = {"readers": 2} if CHAIN_TWO_READERS else None
+        x = nn_ops.conv_bn_act(x, self.conv_shared, relu=True, same=True, chain_out=ch)
         # NHWC output == the reference's permute(0,2,3,1).contiguous()
-        logits = nn_ops.conv_bn_act(x, self.conv_class).permute(0, 2, 3, 1).reshape(B, -1, 2)
+        logits = nn_ops.conv_bn_act(x, self.conv_class, chain_in=ch).permute(0, 2, 3, 1).reshape(B, -1, 2)
         probs = self.softmax(logits)
-        bbox = nn_ops.conv_bn_act(x, self.conv_bbox).permute(0, 2, 3, 1).reshape(B, -1, 4)
+        bbox = nn_ops.conv_bn_act(x, self.conv_bbox, chain_in=ch).permute(0, 2, 3, 1).reshape(B, -1, 4)
         return [logits, probs, bbox]
 
 

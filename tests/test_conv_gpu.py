@@ -370,3 +370,41 @@ def test_tile256_kernel_is_deterministic_and_agrees_with_tile128(shape, tile_mod
         assert torch.equal(y, y0) and torch.equal(y._sln_parts[1], p0)
     err = (y0 - y128).abs().max().item() / y128.abs().max().item()
     assert err < 2e-6, err
+
+
+def test_two_reader_chain_of_the_rpn_heads_matches_autograd_accumulation():
+    """RPN: the shared 3x3 map is read by the class and the box head.  Whichever data gradient runs
+    second adds the first (as the epilogue's residual), applies the shared conv's ReLU mask and hands it
+    its prepared gradient; both heads return None to autograd.  One fp32 addition per element either
+    way: the gradient reaching the RPN's input is bit-identical, bias / weight gradients differ by
+    summation order only."""
+    from sln_amodal_amd import conv_hip
+    from sln_amodal_amd.modal.modals import RPN
+    from tests._util import key_init_
+    rpn = RPN(3, 1, 64).cuda()
+    key_init_(rpn)
+    g = torch.Generator().manual_seed(21)
+    x0 = torch.randn(2, 64, 19, 23, generator=g).cuda().contiguous(memory_format=torch.channels_last)
+    up_l = torch.randn(2, 19 * 23 * 3, 2, generator=g).cuda()
+    up_b = torch.randn(2, 19 * 23 * 3, 4, generator=g).cuda()
+    res = {}
+    saved = conv_hip.CHAIN_GRAD_PREP
+    try:
+        for mode in (True, False):
+            conv_hip.CHAIN_GRAD_PREP = mode
+            conv_hip.CHAIN_STATS[:] = [0, 0]
+            x = x0.clone().requires_grad_(True)
+            rpn.zero_grad(set_to_none=True)
+            logits, probs, bbox = rpn(x)
+            ((logits * up_l).sum() + (bbox * up_b).sum()).backward()
+            assert conv_hip.CHAIN_STATS == ([1, 1] if mode else [0, 0])
+            res[mode] = (logits.detach().clone(), bbox.detach().clone(), x.grad.clone(),
+                         {k: p.grad.clone() for k, p in rpn.named_parameters()})
+    finally:
+        conv_hip.CHAIN_GRAD_PREP = saved
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+    assert torch.equal(res[True][2], res[False][2])
+    assert set(res[True][3]) == set(res[False][3]) and len(res[True][3]) == 6
+    for k in res[True][3]:
+        a, b = res[True][3][k], res[False][3][k]
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-5 * float(b.abs().max()) + 1e-7), k
