@@ -380,10 +380,11 @@ class Mask(nn.Module):
         x = torch.cat((cls_feature, x), dim=1)  # GLM channels first (modals.py:481)
         x = x.contiguous(memory_format=torch.channels_last)
         conv = nn_ops.conv_bn_act
-        x = conv(x, self.conv1, self.bn1, relu=True, same=True)
-        x = conv(x, self.conv2, self.bn2, relu=True, same=True)
-        x = conv(x, self.conv3, self.bn3, relu=True, same=True)
-        feat = conv(x, self.conv4, self.bn4, relu=True, same=True)
+        c12, c23, c34 = {}, {}, {}   # conv1 -> conv2 -> conv3 -> conv4: one reader each (chained gradients)
+        x = conv(x, self.conv1, self.bn1, relu=True, same=True, chain_out=c12)
+        x = conv(x, self.conv2, self.bn2, relu=True, same=True, chain_in=c12, chain_out=c23)
+        x = conv(x, self.conv3, self.bn3, relu=True, same=True, chain_in=c23, chain_out=c34)
+        feat = conv(x, self.conv4, self.bn4, relu=True, same=True, chain_in=c34)   # feat is also returned
         x = nn_ops.deconv2x2_relu(feat, self.deconv)
         x = conv(x, self.conv5)  # logits; the sigmoid lives in the losses (modals.py:497)
         return x, feat
