@@ -15,14 +15,16 @@
 //   act_split      x fp32 -> xparts [P][M][Cp] bf16 (one HBM-bound pass; the
 //                  consumer GEMMs then need no VALU work at all on their operands)
 //   conv_fwd       y = relu?( conv(xparts, wparts)*scale + shift + residual )
-//   grad_prep      gz = gy * (y>0) * scale  -> gzparts (+ fp32 gu, + bias grad)
+//   grad_prep      gz = gy * (y>0) * scale  -> gzparts (+ fp32 gu, + bias grad) -- or, where the
+//                  layer's output has one known reader (two for the RPN), done by that reader's
+//                  data-gradient epilogue (mask / post_scale / colsum / parts-only modes)
 //   conv_fwd       gx = conv(gzparts, wTparts)        (data gradient, stride 1)
 //   conv_wgrad     gw[co][tap][ci] = sum_pix gz[pix][co] * x[pix@tap][ci]
 //                  ("TN" GEMM: both operands are pixel-major, fragments are
 //                  fetched with the ds_read_b64_tr_b16 transposing LDS read)
 //
-// (conv_fwd256_kernel further down is the same GEMM on 256x256 tiles with an LDS-DMA pipeline;
-// sln_conv_fwd_tile picks one of the two per launch.)
+// (conv_fwd256_kernel / conv_wgrad256_kernel further down are the same GEMMs on 256x256 tiles with
+// an LDS-DMA pipeline; sln_conv_fwd_tile / sln_conv_wgrad_tile pick per launch.)
 // conv_fwd GEMM view: M = N*OH*OW output pixels, N = Cout, K = KH*KW*Cin walked
 // tap by tap in 32-channel chunks; taps outside the image read zero (the
 // reference's SamePad2d / conv padding).  Tile 128x128x32, 256 threads = 4 waves
