@@ -1,0 +1,88 @@
+"""Data-parallel train step of the real model with two processes.  RCCL needs one GPU per rank, which
+the test boxes do not have, so both ranks share cuda:0 and exchange through gloo (SLN_DIST_BACKEND):
+everything except the transport is the production path -- replica broadcast (and the cache
+invalidation it implies), gradient hooks, ordered bucket all-reduce, clip, SGD -- and the replicas
+must stay bit-identical."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), SLN_DIST_BACKEND="gloo")
+    from sln_amodal_amd import parallel, synthetic
+    from sln_amodal_amd.config import Config
+    from sln_amodal_amd.model import MaskRCNN
+    r, local, w = parallel.init_distributed()
+    assert (r, w, local) == (rank, world, 0)
+    torch.cuda.set_device(local)
+
+    class C(Config):
+        NAME = "dp"
+        IMAGE_MAX_DIM = 256
+        ARCHITECTURE = "resnet50"
+
+    cfg = C()
+    torch.manual_seed(100 + rank)                      # replicas start DIFFERENT: the broadcast must fix it
+    m = MaskRCNN(cfg, "/tmp/sln_dp_logs").apply_amodal_heads().cuda()
+    m.set_trainable(".*", exclusive_off=False)
+    for p in m.GLM_modual.parameters():
+        p.requires_grad = False
+    batch = synthetic.make_batch(cfg, 2, 256, 256, seed=50 + rank, anchors_f64=m.anchors_f64)   # disjoint shards
+    synthetic.calibrate_batchnorm(m, batch["images"])  # per-rank statistics (and cached BN affines) ...
+    synthetic.calibrate_glm(m, batch["images"])
+    synthetic.warm_start_rpn(m, [batch], iters=10)
+    parallel.broadcast_parameters(m)                   # ... replaced by rank 0's here
+    opt = m.make_optimizer(0.01)
+    red = parallel.GradientAllReducer([p for p in m.parameters() if p.requires_grad]).attach()
+    for _ in range(3):
+        loss, _parts = m.train_step(batch, opt, lambda params: red.finish())
+    assert bool(torch.isfinite(loss))
+    flat = torch.cat([p.detach().reshape(-1).double() for p in m.parameters()] +
+                     [b.detach().reshape(-1).double() for b in m.buffers()])
+    # the replicas must also COMPUTE the same thing (stale per-rank caches of weight parts or BN affines
+    # would leave the parameters equal -- the gradients are averaged -- but not the forward pass)
+    xs = torch.randn(1, 3, 256, 256, generator=torch.Generator().manual_seed(9)).cuda()
+    with torch.no_grad():
+        p2 = m.fpn(xs.contiguous(memory_format=torch.channels_last))[0].double()
+    digest = torch.stack([flat.sum(), flat.abs().sum(), (flat * flat).sum(), p2.sum(), p2.abs().sum()]).cpu()
+    gathered = [torch.zeros_like(digest) for _ in range(world)]
+    dist.all_gather(gathered, digest)
+    print("rank", rank, "digests", [g.tolist() for g in gathered], flush=True)
+    assert torch.equal(gathered[0][:3], gathered[1][:3]), (rank, gathered)            # state: bit-identical
+    # forward: equal up to the stem's aten/MIOpen convolution, whose algorithm choice is per process
+    assert torch.allclose(gathered[0][3:], gathered[1][3:], rtol=1e-5, atol=0), (rank, gathered)
+    dist.destroy_process_group()
+    out.put(rank)
+
+
+def test_two_rank_train_steps_keep_replicas_identical():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+    for p in procs:
+        if p.is_alive():
+            p.terminate()
+            p.join(10)
+    assert [p.exitcode for p in procs] == [0, 0]
+    assert sorted(q.get(timeout=5) for _ in range(2)) == [0, 1]
