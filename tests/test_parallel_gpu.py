@@ -66,7 +66,7 @@ def _worker(rank, world, port, out):
     print("rank", rank, "digests", [g.tolist() for g in gathered], flush=True)
     assert torch.equal(gathered[0][:3], gathered[1][:3]), (rank, gathered)            # state: bit-identical
     # forward: equal up to the stem's aten/MIOpen convolution, whose algorithm choice is per process
-    assert torch.allclose(gathered[0][3:], gathered[1][3:], rtol=1e-5, atol=0), (rank, gathered)
+    assert torch.allclose(gathered[0][3:], gathered[1][3:], rtol=1e-4, atol=0), (rank, gathered)   # stale caches: O(1) off
     dist.destroy_process_group()
     out.put(rank)
 
