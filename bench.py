@@ -35,6 +35,9 @@ def split_peak(parts):
     bounds the algorithmic rate at 2500/6 = 416.7 (2500/3 = 833.3) TFLOP/s."""
     return PEAK_BF16_MFMA_TFLOPS / (6 if parts == 3 else 3)
 PEAK_HBM_GBS = 8000.0
+# HBM bytes per launch cannot be collected live (PMC needs rocprofv3 around the process): the bench line
+# REPLAYS the committed counter passes of the same command and marks them as such
+PMC_TRAFFIC = os.path.join("profiles", "r1_v11_pmc_traffic.json")
 
 
 def step_gflop_per_image(stage, dim, arch):
@@ -51,8 +54,8 @@ def step_gflop_per_image(stage, dim, arch):
 def _pmc_for(kernel):
     """Measured HBM bytes per launch of `kernel` over one steady-state step (committed PMC passes)."""
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_v11_pmc_traffic.json")))[kernel]["last_step"]
-        return {"hbm_read_bytes_per_launch_raw": pmc["read_bytes_per_launch_raw"],
+        pmc = json.load(open(os.path.join(ROOT, PMC_TRAFFIC)))[kernel]["last_step"]
+        return {"replayed": True, "hbm_read_bytes_per_launch_raw": pmc["read_bytes_per_launch_raw"],
                 "hbm_read_bytes_per_launch_x2_corrected": pmc["read_bytes_per_launch_x2_gfx950_wide_load_correction"],
                 "hbm_write_bytes_per_launch": pmc["write_bytes_per_launch"]}
     except Exception:
@@ -83,13 +86,13 @@ def dominant_kernel_roofline(prof, elapsed, parts):
     mult = 6 if parts == 3 else 3
     traffic = None
     try:   # HBM bytes per launch from the committed rocprofv3 PMC passes (not collectable live)
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_v11_pmc_traffic.json")))[name]["last_step"]
-        traffic = {"hbm_read_bytes_per_launch_raw": pmc["read_bytes_per_launch_raw"],
+        pmc = json.load(open(os.path.join(ROOT, PMC_TRAFFIC)))[name]["last_step"]
+        traffic = {"replayed": True, "hbm_read_bytes_per_launch_raw": pmc["read_bytes_per_launch_raw"],
                    "hbm_read_bytes_per_launch_x2_corrected": pmc["read_bytes_per_launch_x2_gfx950_wide_load_correction"],
                    "hbm_write_bytes_per_launch": pmc["write_bytes_per_launch"],
                    "algorithmic_read_bytes_per_launch": int(rd_b / n),      # live: this run's launches
                    "algorithmic_write_bytes_per_launch": int(wr_b / n),
-                   "source": "profiles/r1_v11_pmc_traffic.json, last steady-state step (rocprofv3 --pmc FETCH_SIZE / "
+                   "source": PMC_TRAFFIC + ", last steady-state step (rocprofv3 --pmc FETCH_SIZE / "
                              "WRITE_SIZE, separate passes); algorithmic bytes counted live over the timed launches"}
     except Exception:
         pass
@@ -115,6 +118,33 @@ def dominant_kernel_roofline(prof, elapsed, parts):
                               for k, v in by.items() if k != name}}
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start one fresh interpreter per GPU
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in its environment, rendezvous on 127.0.0.1) and
+    relay rank 0's JSON line.  This parent never initialises the GPU (device_count() does not),
+    and the ranks are child processes, not an exec of this one."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n and os.environ.get("SLN_DIST_BACKEND") != "gloo":
+        print("bench.py: --gpus %d requested but %d visible (SLN_DIST_BACKEND=gloo lets several ranks "
+              "share a GPU for a functional check)" % (n, have), file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -129,13 +159,15 @@ def main():
     ap.add_argument("--parts", type=int, default=None, choices=[2, 3],
                     help="bf16 parts per fp32 operand in the conv stack (default 3 = fp32-class)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus))
 
     from sln_amodal_amd import nn_ops, parallel, synthetic
     from sln_amodal_amd.config import Config
     from sln_amodal_amd.model import LAYER_REGEX, MaskRCNN
 
     rank, local, world = parallel.init_distributed()
-    if world != args.gpus and world > 1:
+    if world != args.gpus:   # never print a line whose n_gpus differs from what was asked for
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)

@@ -17,7 +17,10 @@
  *   - return value: 0 = SLN_OK, otherwise an SLN_ERR_* code; never exit()s
  *     (the reference CPU crop exit(-1)s on a bad box index,
  *     roialign/roi_align/src/crop_and_resize.c:39-42).
- *   - thread-safe: no global mutable state.
+ *   - thread-safe: no global mutable state, and no entry point reads the process
+ *     environment: every kernel / tile choice is a pure function of the arguments.
+ *     (Only a process started with SLN_DEBUG_KNOBS set -- A/B sessions and the test
+ *     suite's forced tile modes -- consults SLN_* tuning variables.)
  */
 #ifndef SLN_AMODAL_H
 #define SLN_AMODAL_H

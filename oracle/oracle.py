@@ -249,7 +249,8 @@ def detection_target_layer(proposals, gt_class_ids, gt_boxes, gt_masks, perm_pos
     pos_count = 0
     if pos_idx.size:
         want = int(rois_per_image * positive_ratio)
-        pos_idx = pos_idx[np.asarray(perm_pos)[:want]]
+        perm_pos = np.asarray(perm_pos)
+        pos_idx = pos_idx[perm_pos[perm_pos < pos_idx.size][:want]]   # (a longer permutation is restricted)
         pos_count = pos_idx.size
         pos_rois = proposals[pos_idx]
         assign = ov[pos_idx].argmax(axis=1)
@@ -267,7 +268,8 @@ def detection_target_layer(proposals, gt_class_ids, gt_boxes, gt_masks, perm_pos
     neg_count = 0
     if neg_idx.size and pos_count > 0:
         want = int((1.0 / positive_ratio) * pos_count - pos_count)
-        neg_idx = neg_idx[np.asarray(perm_neg)[:want]]
+        perm_neg = np.asarray(perm_neg)
+        neg_idx = neg_idx[perm_neg[perm_neg < neg_idx.size][:want]]
         neg_count = neg_idx.size
         neg_rois = proposals[neg_idx]
     if pos_count and neg_count:

@@ -43,8 +43,10 @@ class InferenceConfig(Amodalfig):
 class AmodalDataset(object):
     """Iterable of training batches (dicts, see MaskRCNN.train_step)."""
 
-    def __init__(self, config, model, root=None, limit=-1, seed=1234, device="cuda", max_objects=8):
+    def __init__(self, config, model, root=None, limit=-1, seed=1234, device="cuda", max_objects=8,
+                 rank=0, world=1):
         self.config, self.model, self.device, self.seed = config, model, device, seed
+        self.rank, self.world = rank, world   # data-parallel shard of the file list
         self.max_objects = max_objects
         self.files = []
         if root:
@@ -83,7 +85,8 @@ class AmodalDataset(object):
         B, dim, step = self.config.BATCH_SIZE, self.config.IMAGE_MAX_DIM, 0
         while True:
             if self.files:
-                idx = [(step * B + i) % len(self.files) for i in range(B)]
+                # disjoint shards: global step `step` covers files [step*world*B, (step+1)*world*B)
+                idx = [((step * self.world + self.rank) * B + i) % len(self.files) for i in range(B)]
                 yield self._load_real([self.files[i] for i in idx])
             else:
                 yield synthetic.make_batch(self.config, B, dim, dim, n_obj=self.max_objects,
@@ -140,16 +143,20 @@ def main(argv=None):
     model.to(device)
     for p in model.GLM_modual.parameters():
         p.requires_grad = False
-    parallel.broadcast_parameters(model)
     data = AmodalDataset(config, model, None if args.synthetic else args.dataset, args.limit,
-                         seed=1234 + rank, device=device)
+                         seed=1234 + rank, device=device, rank=rank, world=world)
+
+    if args.command == "train" and not os.path.exists(str(model_path)):
+        # no checkpoint: emulate pretrained statistics.  Calibrate FIRST (the batch is rank-specific),
+        # broadcast AFTER, so that every replica computes with rank 0's frozen-BN statistics.
+        first = next(iter(data))
+        synthetic.calibrate_batchnorm(model, first["images"][:4])
+        synthetic.calibrate_glm(model, first["images"][:2])
+    parallel.broadcast_parameters(model)
 
     if args.command == "train":
-        if not os.path.exists(str(model_path)):     # no checkpoint: emulate pretrained statistics
-            first = next(iter(data))
-            synthetic.calibrate_batchnorm(model, first["images"][:4])
-            synthetic.calibrate_glm(model, first["images"][:2])
         params = lambda: [p for p in model.parameters() if p.requires_grad]
+        reducer = None
         for lr, epochs, layers in ((config.LEARNING_RATE, 2, "heads"), (config.LEARNING_RATE, 3, "4+"),
                                    (config.LEARNING_RATE / 10, 1, "all")):
             model.set_trainable(".*", exclusive_off=False)   # the reference can only switch off
@@ -157,6 +164,8 @@ def main(argv=None):
                 p.requires_grad = False
             from .model import LAYER_REGEX
             model.set_trainable(LAYER_REGEX[layers])
+            if reducer is not None:
+                reducer.detach()     # the previous stage's hooks must not fire next to the new reducer's
             reducer = parallel.GradientAllReducer(params()).attach()
             model.train_model(data, None, learning_rate=lr, epochs=epochs, layers=layers,
                               grad_sync=(lambda ps: reducer.finish()) if world > 1 else None)

@@ -13,10 +13,20 @@ class Config(object):
 
     GPU_COUNT = 1
     IMAGES_PER_GPU = 1
-    # Reference: batch 1 with gradient accumulation over BATCH_SIZE steps
-    # (config.py:39-40).  Here it is the per-GPU image batch of one step.
+    # Reference: batch 1 with gradient accumulation over BATCH_SIZE iterations
+    # (config.py:39-40, model.py:440-444).  Here it is the per-GPU image batch of one step.
     BATCH_SIZE = 1
+    # OPTIMIZER steps per epoch.  The reference multiplies this by BATCH_SIZE in __init__
+    # (config.py:184) because ITS step is one image and its optimizer steps every BATCH_SIZE
+    # iterations: 2500 updates of BATCH_SIZE images per epoch.  One train_step here already
+    # consumes BATCH_SIZE images and updates once, so the number stays 2500 (data-parallel
+    # runs divide it by the world size: amodal_train.main).
     STEPS_PER_EPOCH = 2500
+    # Step loss over the B images of a batch: "mean" (default) or "sum".  The reference SUMS 16
+    # per-image gradients (and clips the running sum to 5.0 after every image, model.py:441);
+    # a batched step can only clip once, so "sum" reproduces the reference's step size only
+    # while the clip is inactive.  With "mean" the same LEARNING_RATE takes 1/B-size steps.
+    LOSS_REDUCTION = "mean"
     VALIDATION_STEPS = 100
 
     ARCHITECTURE = "resnet101"            # reference hard-codes this (model.py:163)
@@ -72,7 +82,6 @@ class Config(object):
     STRICT_IMAGE_DIVISIBILITY = False     # reference raises unless H,W % 64 == 0 (model.py:153-157)
 
     def __init__(self):
-        self.STEPS_PER_EPOCH = self.BATCH_SIZE * self.STEPS_PER_EPOCH
         self.IMAGE_SHAPE = np.array([self.IMAGE_MAX_DIM, self.IMAGE_MAX_DIM, 3])
         self.BACKBONE_SHAPES = np.array(
             [[int(math.ceil(self.IMAGE_SHAPE[0] / s)), int(math.ceil(self.IMAGE_SHAPE[1] / s))]

@@ -370,8 +370,14 @@ class _ConvFn(torch.autograd.Function):
             # what arrives must be exactly what the reader produced: the zero-stride placeholder,
             # or (block outputs) the reader's own masked dx -- anything else means autograd added a
             # second reader's gradient, which the handed-over parts do not contain
-            ok = "gz" in ch and (gy.data_ptr() == ch.pop("gu_ptr", None) if ch["with_res"]
+            # (block outputs: the reader keeps its own reference to that dx in the dict, so autograd is
+            # never its sole owner and cannot fold a second reader's gradient into it IN PLACE -- a sum
+            # is a new tensor, caught by the pointer; the version guards the in-place case anyway)
+            ref = ch.pop("gu_ref", None)
+            ok = "gz" in ch and ((ref is not None and gy.data_ptr() == ref.data_ptr() and
+                                  gy._version == ch.pop("gu_version", None)) if ch["with_res"]
                                  else gy.stride() == (0, 0, 0, 0))
+            del ref
             if not ok:
                 raise RuntimeError("chained gradient: the consumer's dgrad did not run, or the "
                                    "activation has a second consumer")
@@ -420,7 +426,7 @@ class _ConvFn(torch.autograd.Function):
                                         _nhwc(id_grad) if id_grad is not None else None, False, cin=Co,
                                         out_parts=True, mask=_nhwc(mask_x), want_y=True,
                                         want_colsum=ci["want_bias"], post_scale=ci["scale"])
-                ci["gz"], ci["gbias"], ci["gu_ptr"] = gz_up, gb_up, gx.data_ptr()
+                ci["gz"], ci["gbias"], ci["gu_ref"], ci["gu_version"] = gz_up, gb_up, gx, gx._version
                 CHAIN_STATS[0] += 1
             elif ctx.chain_in is not None:
                 ci = ctx.chain_in

@@ -1052,6 +1052,16 @@ __global__ __launch_bounds__(512) void conv_wgrad256_kernel(const WgradParams p)
 }
 
 // ---------------------------------------------------------------- C ABI
+// Tuning knobs (A/B runs, the tests' forced tile modes) exist only in debug sessions: unless the
+// process was started with SLN_DEBUG_KNOBS set, no entry point reads the environment and every
+// choice is a pure function of its arguments.
+static inline int sln_knob(const char *name, int dflt) {
+    static const bool enabled = getenv("SLN_DEBUG_KNOBS") != nullptr;
+    if (!enabled) return dflt;
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
 static inline int ew_grid(long total) {
     long g = (total + 255) / 256;
     if (g > 4096) g = 4096;
@@ -1113,11 +1123,10 @@ extern "C" int sln_conv_grad_prep_f32(const float *gy, const float *y, const flo
 // and K is long enough to amortise the pipeline; else 128.  SLN_CONV_TILE256 = 0 never,
 // 1 (default) by this rule, 2 always (tests); read on every call.
 extern "C" int sln_conv_fwd_tile(int64_t M, int Cout, int64_t K, int parts) {
-    const char *e = getenv("SLN_CONV_TILE256");
-    const int mode = e ? atoi(e) : 1;
+    const int mode = sln_knob("SLN_CONV_TILE256", 1);
     if (M < 1 || Cout < 1 || M > 2147483647L - T2) return BM;
     if (mode == 2) return T2;
-    if (mode != 1 || (parts != 3 && !getenv("SLN_TILE256_P2"))) return BM;   // P2 knob: preview runs only
+    if (mode != 1 || (parts != 3 && !sln_knob("SLN_TILE256_P2", 0))) return BM;   // P2 knob: preview runs only
     const long nb2 = sln_div_up(M, T2) * (long)sln_div_up(Cout, T2);
     const double fill = (double)nb2 / (double)(sln_div_up(nb2, 256) * 256L);
     // at least 176 of the last 256 columns in use (ASPP's Cout = 182: +6...11 % per launch over
@@ -1187,8 +1196,7 @@ extern "C" int sln_conv2d_fwd_ms_f32(const uint16_t *x_parts, int nseg, const in
         return sln_launch_status();
     }
     // 64-wide N tile when the whole output is at most 64 channels wide (SLN_CONV_BN64=0 disables)
-    const char *e64 = getenv("SLN_CONV_BN64");
-    const bool narrow = Cout <= 64 && !(e64 && atoi(e64) == 0);
+    const bool narrow = Cout <= 64 && sln_knob("SLN_CONV_BN64", 1) != 0;
     p.gm = sln_div_up(M, BM);
     p.gn = sln_div_up(Cout, narrow ? 64 : BN);
     const long nblk = (long)p.gm * p.gn;
@@ -1226,11 +1234,10 @@ extern "C" int sln_conv2d_fwd_f32(const uint16_t *x_parts, int N, int H, int W, 
 // channel counts fill >= 176 (>= 160 of the last 256) columns, the tap tiles fit one round and there
 // are enough pixels; else 128.  SLN_WGRAD_TILE256 = 0 never, 1 (default) by this rule, 2 always.
 extern "C" int sln_conv_wgrad_tile(int64_t M, int Cout, int Cin, int taps, int parts) {
-    const char *e = getenv("SLN_WGRAD_TILE256");
-    const int mode = e ? atoi(e) : 1;
+    const int mode = sln_knob("SLN_WGRAD_TILE256", 1);
     if (M < 1 || Cout < 1 || Cin < 1 || taps < 1) return BM;
     if (mode == 2) return T2;
-    if (mode != 1 || (parts != 3 && !getenv("SLN_TILE256_P2"))) return BM;   // P2 knob: preview runs only
+    if (mode != 1 || (parts != 3 && !sln_knob("SLN_TILE256_P2", 0))) return BM;   // P2 knob: preview runs only
     const long nt2 = (long)sln_div_up(Cout, T2) * sln_div_up(Cin, T2) * taps;
     const bool wide = Cout >= 176 && (Cout % T2 == 0 || Cout % T2 >= 160) && Cin >= 176 &&
                       (Cin % T2 == 0 || Cin % T2 >= 160);
@@ -1273,7 +1280,7 @@ extern "C" int sln_conv2d_wgrad_f32(const uint16_t *gz_parts, int Cout, int Cout
             pps2 = ((pps2 + T2K - 1) / T2K) * T2K;
             ks2 = (M + pps2 - 1) / pps2;
             p.gm = (int)gm2; p.gn_per_tap = (int)gn2; p.ksplit = (int)ks2; p.pix_per_split = (int)pps2;
-            { const char *x = getenv("SLN_WGRAD_XCD"); p.xcd_wgrad = x ? atoi(x) : 1; }
+            p.xcd_wgrad = sln_knob("SLN_WGRAD_XCD", 1);
             const long nb2 = nt2 * ks2;
             if (parts == 2)
                 hipLaunchKernelGGL(conv_wgrad256_kernel<2>, dim3((unsigned)nb2), dim3(512), 0, st, p);
@@ -1282,8 +1289,7 @@ extern "C" int sln_conv2d_wgrad_f32(const uint16_t *gz_parts, int Cout, int Cout
             return sln_launch_status();
         }
     }
-    const char *e64 = getenv("SLN_WGRAD_T64");                 // 0 disables the 64-wide sides
-    const bool t64 = !(e64 && atoi(e64) == 0);
+    const bool t64 = sln_knob("SLN_WGRAD_T64", 1) != 0;        // 0 disables the 64-wide sides
     const int TMs = (t64 && Cout <= 64) ? 64 : BM, TNs = (t64 && Cin <= 64) ? 64 : BN;
     p.gm = sln_div_up(Cout, TMs);
     p.gn_per_tap = sln_div_up(Cin, TNs);

@@ -88,7 +88,48 @@ class _PyramidCrop(torch.autograd.Function):
         return (None, None, None, None) + tuple(grads)
 
 
-def pyramid_roi_align(inputs, pool_size, image_shape, box_ind=None):
+class _PyramidCropInto(torch.autograd.Function):
+    """The mask head's torch.cat((glm_crop, roi_features), 1) (modals.py:481) without the copy: the
+    roi features are cropped straight into channels [coff, coff+C) of the wide NHWC buffer whose
+    first channels already hold the GLM crop (pyramid_roi_align_image(..., cat_extra=C))."""
+
+    @staticmethod
+    def forward(ctx, buf, coff, boxes, box_ind, level, pool, *maps):
+        import ctypes as C
+        from .. import _lib
+        maps = [m if m.is_contiguous(memory_format=torch.channels_last) else
+                m.contiguous(memory_format=torch.channels_last) for m in maps]
+        B, Cc = maps[0].shape[0], maps[0].shape[1]
+        ptrs = (C.c_void_p * 4)(*[m.data_ptr() for m in maps])
+        hw = (C.c_int * 8)(*[d for m in maps for d in (m.shape[2], m.shape[3])])
+        _lib.check(_lib.lib().sln_pyramid_crop_fwd_f32(
+            ptrs, hw, B, Cc, ops._ptr(boxes), ops._ptr(box_ind), ops._ptr(level), boxes.shape[0], pool,
+            pool, 0.0, ops._ptr(buf), buf.shape[1], coff, ops._stream()), "sln_pyramid_crop_fwd_f32")
+        ctx.save_for_backward(boxes, box_ind, level)
+        ctx.shapes = [tuple(m.shape) for m in maps]
+        ctx.pool, ctx.coff = pool, coff
+        ctx.mark_dirty(buf)
+        return buf
+
+    @staticmethod
+    def backward(ctx, g):
+        import ctypes as C
+        from .. import _lib
+        boxes, box_ind, level = ctx.saved_tensors
+        g = g.contiguous(memory_format=torch.channels_last)
+        B, Cc = ctx.shapes[0][0], ctx.shapes[0][1]
+        grads = [torch.empty(s, dtype=torch.float32, device=g.device,
+                             memory_format=torch.channels_last) for s in ctx.shapes]
+        ptrs = (C.c_void_p * 4)(*[t.data_ptr() for t in grads])
+        hw = (C.c_int * 8)(*[d for s in ctx.shapes for d in (s[2], s[3])])
+        _lib.check(_lib.lib().sln_pyramid_crop_bwd_f32(
+            ops._ptr(g), g.shape[1], ctx.coff, ops._ptr(boxes), ops._ptr(box_ind), ops._ptr(level),
+            boxes.shape[0], ctx.pool, ctx.pool, B, Cc, ptrs, hw, ops._stream()),
+            "sln_pyramid_crop_bwd_f32")
+        return (None, None, None, None, None, None) + tuple(grads)
+
+
+def pyramid_roi_align(inputs, pool_size, image_shape, box_ind=None, into=None):
     """inputs = [boxes] + [P2, P3, P4, P5].
     boxes: [B,R,4] (or the reference's [1,R,4]) normalised (y1,x1,y2,x2); image b's
     rois index feature-map batch entry b.  Padded roi slots may be marked by
@@ -111,6 +152,11 @@ def pyramid_roi_align(inputs, pool_size, image_shape, box_ind=None):
     level = roi_levels(flat, image_shape)
     chlast = all(m.is_contiguous(memory_format=torch.channels_last) and not m.is_contiguous()
                  for m in feature_maps)
+    if chlast and len(feature_maps) == 4 and into is not None:   # (buffer, channel offset): fused cat
+        return _PyramidCropInto.apply(into[0], int(into[1]), flat, box_ind.contiguous(), level.contiguous(),
+                                      int(pool_size), *feature_maps)
+    if into is not None:
+        raise RuntimeError("pyramid_roi_align(into=...) needs four channels-last feature maps")
     if chlast and len(feature_maps) == 4:
         return _PyramidCrop.apply(flat, box_ind.contiguous(), level.contiguous(), int(pool_size),
                                   *feature_maps)
@@ -127,10 +173,14 @@ def pyramid_roi_align(inputs, pool_size, image_shape, box_ind=None):
     return pooled
 
 
-def pyramid_roi_align_image(inputs, pool_size, image_shape, istrain=False, box_ind=None):
+def pyramid_roi_align_image(inputs, pool_size, image_shape, istrain=False, box_ind=None, cat_extra=0):
     """Single-map crop used for the GLM probabilities and the raw image
     (modals.py:112-157): ignores pyramid levels and `image_shape`.
-    inputs = [boxes [B,R,4] | [R,4], image [B,C,H,W]]."""
+    inputs = [boxes [B,R,4] | [R,4], image [B,C,H,W]].
+    cat_extra = E > 0 (channels-last image, no gradient): the crop is written into the first C
+    channels of a [K, C+E, pool, pool] NHWC buffer and returned as a view of it that carries the
+    buffer (`_sln_cat_buf`) -- Mask.forward then crops its E roi-feature channels in behind it
+    instead of concatenating two tensors."""
     boxes, image = inputs[0], inputs[1]
     if boxes.dim() == 3:
         R = boxes.shape[1]
@@ -140,6 +190,24 @@ def pyramid_roi_align_image(inputs, pool_size, image_shape, istrain=False, box_i
         boxes = boxes.reshape(-1, 4)
     elif box_ind is None:
         box_ind = torch.zeros(boxes.shape[0], dtype=torch.int32, device=boxes.device)
+    if cat_extra and image.is_cuda and not image.is_contiguous() and \
+            image.is_contiguous(memory_format=torch.channels_last):
+        import ctypes as C
+        from .. import _lib
+        with torch.no_grad():
+            K, Cc = boxes.shape[0], image.shape[1]
+            wide = torch.empty((K, pool_size, pool_size, Cc + cat_extra), dtype=torch.float32,
+                               device=image.device).permute(0, 3, 1, 2)
+            ptrs = (C.c_void_p * 4)(*[image.data_ptr()] * 4)
+            hw = (C.c_int * 8)(*[image.shape[2], image.shape[3]] * 4)
+            level = torch.full((K,), 2, dtype=torch.int32, device=image.device)
+            _lib.check(_lib.lib().sln_pyramid_crop_fwd_f32(
+                ptrs, hw, image.shape[0], Cc, ops._ptr(boxes.detach().contiguous()),
+                ops._ptr(box_ind.contiguous()), ops._ptr(level), K, pool_size, pool_size, 0.0,
+                ops._ptr(wide), Cc + cat_extra, 0, ops._stream()), "sln_pyramid_crop_fwd_f32")
+            view = wide[:, :Cc]
+        view._sln_cat_buf = wide
+        return view
     return CropAndResizeFunction(pool_size, pool_size, 0)(image, boxes.contiguous(),
                                                           box_ind.contiguous())
 
@@ -376,9 +444,16 @@ class Mask(nn.Module):
         self.relu = nn.ReLU(inplace=True)
 
     def forward(self, x, rois, cls_feature, box_ind=None):
-        x = pyramid_roi_align([rois] + list(x), self.pool_size, self.image_shape, box_ind)
-        x = torch.cat((cls_feature, x), dim=1)  # GLM channels first (modals.py:481)
-        x = x.contiguous(memory_format=torch.channels_last)
+        wide = getattr(cls_feature, "_sln_cat_buf", None)
+        if wide is not None and wide.shape[1] == cls_feature.shape[1] + self.depth:
+            # GLM channels first (modals.py:481): they are already in `wide`; crop the roi features in
+            # behind them (one launch, no concatenation copy)
+            x = pyramid_roi_align([rois] + list(x), self.pool_size, self.image_shape, box_ind,
+                                  into=(wide, cls_feature.shape[1]))
+        else:
+            x = pyramid_roi_align([rois] + list(x), self.pool_size, self.image_shape, box_ind)
+            x = torch.cat((cls_feature, x), dim=1)  # GLM channels first (modals.py:481)
+            x = x.contiguous(memory_format=torch.channels_last)
         conv = nn_ops.conv_bn_act
         c12, c23, c34 = {}, {}, {}   # conv1 -> conv2 -> conv3 -> conv4: one reader each (chained gradients)
         x = conv(x, self.conv1, self.bn1, relu=True, same=True, chain_out=c12)

@@ -231,8 +231,11 @@ class MaskRCNN(nn.Module):
         # dead-end crop the reference computes for its (absent) refine net (model.py:651-663)
         image_path = pyramid_roi_align_image([rois, molded_images.contiguous()], 32, cfg.IMAGE_SHAPE,
                                              istrain=True, box_ind=box_ind).detach() / 140.0
-        GLM_feature = pyramid_roi_align_image([rois, probs], 16, (65, 65), istrain=True,
-                                              box_ind=box_ind).detach()
+        # cropped into the head of the mask head's 439-channel input buffer (no torch.cat later)
+        GLM_feature = pyramid_roi_align_image([rois, probs], cfg.MASK_POOL_SIZE, (65, 65), istrain=True,
+                                              box_ind=box_ind, cat_extra=256)
+        if getattr(GLM_feature, "_sln_cat_buf", None) is None:
+            GLM_feature = GLM_feature.detach()
         mrcnn_class_logits, mrcnn_class, mrcnn_bbox = self.classifier(mrcnn_feature_maps, rois, box_ind)
         mrcnn_mask, _feat = self.mask(mrcnn_feature_maps, rois, GLM_feature, box_ind)
         nc = mrcnn_class_logits.shape[1]
@@ -295,7 +298,10 @@ class MaskRCNN(nn.Module):
                            priorities=priorities)
         loss, parts = self.compute_losses(out, batch["rpn_match"], batch["rpn_bbox"])
         optimizer.zero_grad(set_to_none=True)
-        loss.backward()
+        if getattr(self.config, "LOSS_REDUCTION", "mean") == "sum":   # the reference's gradient SUM over images
+            (loss * batch["images"].shape[0]).backward()
+        else:
+            loss.backward()
         if grad_sync is not None:
             grad_sync([p for p in self.parameters() if p.requires_grad])
         # after the all-reduce: a parameter without a local gradient may have received one from a peer,
@@ -311,17 +317,36 @@ class MaskRCNN(nn.Module):
         batch dicts (see train_step)."""
         if layers in LAYER_REGEX:
             layers = LAYER_REGEX[layers]
-        log("\nStarting at epoch {}. LR={}\n".format(self.epoch + 1, learning_rate))
-        log("Checkpoint Path: {}".format(self.checkpoint_path))
+        import torch.distributed as dist
+        ddp = dist.is_available() and dist.is_initialized()
+        rank0 = (not ddp) or dist.get_rank() == 0
+        steps = max(1, self.config.STEPS_PER_EPOCH // (dist.get_world_size() if ddp else 1))
+        if rank0:
+            log("\nStarting at epoch {}. LR={}\n".format(self.epoch + 1, learning_rate))
+            log("Checkpoint Path: {}".format(self.checkpoint_path))
         self.set_trainable(layers)
         optimizer = self.make_optimizer(learning_rate)
         for epoch in range(epochs):
-            log("Epoch {}/{}.".format(epoch, epochs))
+            if rank0:
+                log("Epoch {}/{}.".format(epoch, epochs))
             self.current_epoch += 1
-            self.train_epoch(train_dataset, optimizer, self.config.STEPS_PER_EPOCH, grad_sync)
-            os.makedirs(self.log_dir, exist_ok=True)
-            torch.save(self.state_dict(), self.checkpoint_path.format(self.epoch))
+            self.train_epoch(train_dataset, optimizer, steps, grad_sync)
+            self.save_checkpoint(self.checkpoint_path.format(self.epoch))
             self.epoch += 1
+
+    def save_checkpoint(self, path):
+        """state_dict -> `path` (model.py:366 of the reference), written by rank 0 only, to a
+        temporary file that is renamed into place (a reader -- `--model last` -- never sees a torn
+        file); the other ranks wait, so nobody races ahead and reads it half written."""
+        import torch.distributed as dist
+        ddp = dist.is_available() and dist.is_initialized()
+        if (not ddp) or dist.get_rank() == 0:
+            os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+            tmp = path + ".tmp.%d" % os.getpid()
+            torch.save(self.state_dict(), tmp)
+            os.replace(tmp, path)
+        if ddp:
+            dist.barrier()
 
     def train_epoch(self, datagenerator, optimizer, steps, grad_sync=None):
         loss_sum = torch.zeros((), device=self.anchors.device)

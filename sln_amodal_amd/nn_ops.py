@@ -65,6 +65,11 @@ def bn_affine(bn):
     return scale, shift
 
 
+def _is_stem(conv):
+    """The 3-channel 7x7/2 input convolutions (modals.py:311, resnet_deeplab.py stem)."""
+    return conv.in_channels == 3 and tuple(conv.kernel_size) == (7, 7)
+
+
 def conv_bn_act(x, conv, bn=None, relu=False, residual=None, same=False, link=None, chain_in=None,
                 chain_out=None):
     """x [B,C,H,W] (any memory format; channels-last preferred).
@@ -88,8 +93,12 @@ def conv_bn_act(x, conv, bn=None, relu=False, residual=None, same=False, link=No
     if hip is not None and x.is_cuda and hip.supports(conv, x):
         return hip.conv_bn_act(x, conv, bn, relu, residual, (pt, pb, pl, pr), link=link,
                                chain_in=chain_in, chain_out=chain_out)
-    if BACKEND == "hip" and conv.in_channels >= 8:   # (3-channel stems are aten by design)
-        raise RuntimeError("HIP conv backend requested but unavailable for this layer")
+    if BACKEND != "torch" and x.is_cuda and not _is_stem(conv):
+        # no silent aten/MIOpen fallback on the GPU: only the two 3-channel 7x7 stems are aten by design
+        raise RuntimeError("conv %s -> %s k%s groups=%d dtype=%s has no HIP path (nn_ops.BACKEND=%r); "
+                           "set BACKEND='torch' explicitly to run it on aten" %
+                           (conv.in_channels, conv.out_channels, tuple(conv.kernel_size), conv.groups,
+                            x.dtype, BACKEND))
     if pt == pb and pl == pr:
         y = F.conv2d(x, conv.weight, conv.bias, stride, (pt, pl), dilation)
     else:
@@ -144,7 +153,9 @@ def deconv2x2_relu(x, deconv):
 def linear(x, lin):
     """nn.Linear on [R, C] rows through the same GEMM kernel (a 1x1 conv on R 1x1 'images')."""
     hip = _hip_conv() if BACKEND in ("auto", "hip") else None
-    if hip is None or not x.is_cuda or x.shape[1] % 8:
+    if BACKEND != "torch" and x.is_cuda and (hip is None or x.shape[1] % 8):
+        raise RuntimeError("linear with %d input features has no HIP path" % x.shape[1])
+    if hip is None or not x.is_cuda:
         return F.linear(x, lin.weight, lin.bias)
     R, C = x.shape
     y = hip._ConvFn.apply(x.reshape(R, C, 1, 1), lin.weight.reshape(lin.out_features, C, 1, 1), lin.bias,

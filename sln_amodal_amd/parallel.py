@@ -82,6 +82,22 @@ class GradientAllReducer(object):
             self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
         return self
 
+    def detach(self):
+        """Remove the hooks and drop every pending bucket (call before building the reducer of the
+        next training stage: hooks of a stale reducer would keep launching collectives of their own
+        between the new reducer's, in an order that is only accidentally the same on every rank)."""
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        for w in self._work:
+            if w is not None:
+                w.wait()
+        self._flat = [None] * len(self.buckets)
+        self._work = [None] * len(self.buckets)
+        self._pending = [len(b) for b in self.buckets]
+        self._next = 0
+        return self
+
     def _on_grad(self, p):
         bi = self._owner[id(p)]
         self._pending[bi] -= 1

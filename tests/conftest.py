@@ -3,6 +3,10 @@ import sys
 
 import pytest
 
+# the suite forces kernel / tile variants through the library's debug knobs (csrc/conv.hip sln_knob):
+# they are honoured only when this is set before the library's first call
+os.environ.setdefault("SLN_DEBUG_KNOBS", "1")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -114,3 +114,41 @@ def test_wgrad_tile_rule_is_a_pure_host_function(monkeypatch):
     assert L.sln_conv_wgrad_tile(65536, 256, 256, 9, 3) == 128
     monkeypatch.setenv("SLN_WGRAD_TILE256", "2")
     assert L.sln_conv_wgrad_tile(100, 8, 8, 1, 2) == 256
+
+
+def test_environment_is_ignored_without_the_debug_switch():
+    """The shipped contract: no entry point reads the environment.  In a process started WITHOUT
+    SLN_DEBUG_KNOBS the tile knobs have no effect."""
+    import subprocess
+    import sys
+    code = ("from sln_amodal_amd import _lib; L = _lib.lib(); "
+            "print(L.sln_conv_fwd_tile(100, 8, 8, 3), L.sln_conv_wgrad_tile(100, 8, 8, 1, 3), "
+            "L.sln_conv_fwd_tile(65536, 256, 2304, 3))")
+    env = {k: v for k, v in os.environ.items() if k != "SLN_DEBUG_KNOBS"}
+    env.update(SLN_CONV_TILE256="2", SLN_WGRAD_TILE256="2", PYTHONPATH=ROOT)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-1000:]
+    assert out.stdout.split() == ["128", "128", "256"]
+
+
+def test_reference_import_names_resolve_after_dropin_install():
+    """code written against the reference's top-level names
+    (modal.modals, nms.nms_wrapper, roialign..., model, config, utils) imports this package."""
+    import subprocess
+    import sys
+    code = (
+        "import sln_amodal_amd.dropin as d; names = d.install(); "
+        "from modal.modals import pyramid_roi_align, FPN, RPN, Classifier, Mask, ResNet, SamePad2d; "
+        "from modal.Functions import proposal_layer, detection_target_layer, build_rpn_targets; "
+        "from modal.loss import compute_rpn_class_loss; "
+        "from modal.deeplabv2 import DeepLabV2_ResNet101_MSC; "
+        "from nms.nms_wrapper import nms; "
+        "from roialign.roi_align.crop_and_resize import CropAndResizeFunction, CropAndResize; "
+        "import model, config, utils; "
+        "import sln_amodal_amd.model as m; assert model is m and model.MaskRCNN is m.MaskRCNN; "
+        "assert config.Config().IMAGE_SHAPE[0] == 1024; print(len(names))")
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True,
+                         timeout=300, cwd="/tmp")
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert int(out.stdout.strip()) >= 15

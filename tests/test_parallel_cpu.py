@@ -93,3 +93,18 @@ def test_gradient_allreduce_world2_gloo(hooks):
             p.join(10)
     assert [p.exitcode for p in procs] == [0, 0]
     assert sorted(q.get(timeout=5) for _ in range(2)) == [0, 1]
+
+
+def test_bench_refuses_a_gpu_count_it_cannot_give():
+    """bench.py --gpus N never prints a line for a different N: with fewer visible GPUs (none here) the
+    self-launcher exits non-zero before starting any rank."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "SLN_DIST_BACKEND")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert "--gpus 2 requested" in r.stderr

@@ -86,3 +86,24 @@ def test_two_rank_train_steps_keep_replicas_identical():
             p.join(10)
     assert [p.exitcode for p in procs] == [0, 0]
     assert sorted(q.get(timeout=5) for _ in range(2)) == [0, 1]
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` without torchrun: the parent (which never touches the GPU) starts two
+    ranks itself and relays rank 0's line -- n_gpus must be what was asked for.  One-GPU box: both ranks
+    share cuda:0 and exchange through gloo (SLN_DIST_BACKEND), small shapes."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env["SLN_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
+                        "--warmup", "1", "--batch", "2", "--dim", "256", "--arch", "resnet50",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "dp2"
+    assert out["value"] > 0 and out["scaling"] == "weak"
