@@ -114,9 +114,26 @@ def _neg_count_table(rois_per_image, positive_ratio, device):
                         device=device)
 
 
+def priorities_from_draws(candidates, draws):
+    """Recorded reference draws -> priorities.  candidates [B,P] bool (the set the reference
+    permuted, in index order); draws[b] = the recorded torch.randperm(len(set)) of image b
+    (Functions.py:291, 359).  The k-th drawn candidate gets priority -k, everything else -inf-like,
+    so that descending priority visits the candidates in the reference's order.  Host-side helper for
+    parity tests (it synchronises)."""
+    B, P = candidates.shape
+    pr = torch.full((B, P), -1e9, device=candidates.device)
+    for b in range(B):
+        idx = torch.nonzero(candidates[b])[:, 0]
+        d = torch.as_tensor(draws[b], dtype=torch.long, device=candidates.device)
+        if d.numel() != idx.numel():
+            raise ValueError("image %d: %d recorded draws for %d candidates" % (b, d.numel(), idx.numel()))
+        pr[b, idx[d]] = -torch.arange(d.numel(), device=candidates.device, dtype=torch.float32)
+    return pr
+
+
 def detection_target_layer(proposals, gt_class_ids, gt_boxes, gt_masks, config,
                            num_proposals=None, labels=None, priority_pos=None,
-                           priority_neg=None):
+                           priority_neg=None, replay=None):
     """Sub-sample proposals and build their targets, batched and sync-free.
 
     proposals    [B,P,4] normalised, zero padded; num_proposals [B] or None (=P)
@@ -127,6 +144,8 @@ def detection_target_layer(proposals, gt_class_ids, gt_boxes, gt_masks, config,
                  decode+crop+round kernel (never materialising float planes)
     priority_*   [B,P] float: candidates are taken in descending priority
                  (default uniform random == the reference's randperm prefix)
+    replay       (draws_pos, draws_neg): per-image recorded torch.randperm draws of the
+                 reference, replayed through the same priority path (parity tests)
 
     Returns dict(rois [B,R,4], class_ids [B,R] int32, deltas [B,R,4],
     masks [B,R,L,h,w], roi_valid [B,R] bool, gt_assign [B,R]).  R =
@@ -148,6 +167,9 @@ def detection_target_layer(proposals, gt_class_ids, gt_boxes, gt_masks, config,
     iou_max, assign = ov.max(dim=2)
     pos = (iou_max >= 0.5) & prop_valid
     neg = (iou_max < 0.5) & prop_valid & gt_valid.any(dim=1, keepdim=True)
+    if replay is not None:
+        priority_pos = priorities_from_draws(pos, replay[0])
+        priority_neg = priorities_from_draws(neg, replay[1])
     if priority_pos is None:
         priority_pos = torch.rand((B, P), device=dev)
     if priority_neg is None:

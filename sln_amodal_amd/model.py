@@ -223,7 +223,8 @@ class MaskRCNN(nn.Module):
         tgt = detection_target_layer(rpn_rois, gt_class_ids, gt_boxes,
                                      None if labels is not None else gt_layer, cfg,
                                      num_proposals=num_rois, labels=labels,
-                                     priority_pos=pr.get("pos"), priority_neg=pr.get("neg"))
+                                     priority_pos=pr.get("pos"), priority_neg=pr.get("neg"),
+                                     replay=pr.get("replay"))
         rois, roi_valid = tgt["rois"], tgt["roi_valid"]
         R = rois.shape[1]
         box_ind = torch.arange(B, dtype=torch.int32, device=rois.device).repeat_interleave(R)
@@ -304,12 +305,17 @@ class MaskRCNN(nn.Module):
             loss.backward()
         if grad_sync is not None:
             grad_sync([p for p in self.parameters() if p.requires_grad])
-        # after the all-reduce: a parameter without a local gradient may have received one from a peer,
-        # and every rank must clip over the same set
-        params = [p for p in self.parameters() if p.requires_grad and p.grad is not None]
-        torch.nn.utils.clip_grad_norm_(params, self.config.GRADIENT_CLIP_NORM)
-        optimizer.step()
+        self.optimizer_step(optimizer)
         return loss.detach(), parts
+
+    def optimizer_step(self, optimizer):
+        """Global-norm clip (5.0) over every gradient, then momentum SGD with weight decay on the
+        non-'bn' parameters (model.py:441-444, 352-358).  Runs after the all-reduce: a parameter
+        without a local gradient may have received one from a peer, and every rank must clip over
+        the same set."""
+        params = [p for p in self.parameters() if p.requires_grad and p.grad is not None]
+        self.last_grad_norm = torch.nn.utils.clip_grad_norm_(params, self.config.GRADIENT_CLIP_NORM)
+        optimizer.step()
 
     def train_model(self, train_dataset, val_dataset, learning_rate, epochs, layers,
                     grad_sync=None):
@@ -365,11 +371,15 @@ class MaskRCNN(nn.Module):
         subtract the mean pixel, build image metas (model.py:709-745)."""
         cfg = self.config
         molded, metas, windows = [], [], []
+        from PIL import Image
         for image in images:
-            t = torch.from_numpy(np.ascontiguousarray(image)).permute(2, 0, 1).unsqueeze(0).float()
-            t = F.interpolate(t, size=(cfg.IMAGE_MAX_DIM, cfg.IMAGE_MAX_DIM), mode="bilinear",
-                              align_corners=False)
-            m = t[0].permute(1, 2, 0).numpy() - cfg.MEAN_PIXEL
+            # utils.py:351-356: scipy.misc.imresize(image, (max_dim, max_dim)) = PIL bilinear resize of
+            # the uint8 image (host-side preprocessing, as in the reference)
+            u8 = np.ascontiguousarray(image).astype(np.uint8)
+            if u8.shape[:2] != (cfg.IMAGE_MAX_DIM, cfg.IMAGE_MAX_DIM):
+                u8 = np.asarray(Image.fromarray(u8).resize((cfg.IMAGE_MAX_DIM, cfg.IMAGE_MAX_DIM),
+                                                           Image.BILINEAR))
+            m = u8.astype(np.float32) - cfg.MEAN_PIXEL
             window = (0, 0, cfg.IMAGE_MAX_DIM, cfg.IMAGE_MAX_DIM)
             molded.append(m.astype(np.float32))
             windows.append(window)

@@ -1,0 +1,114 @@
+"""Parity checks against reference-generated goldens that run unchanged on either device: the CPU
+suite calls them with device='cpu' (torch ops), the GPU suite with device='cuda' (the product path)."""
+import zlib
+
+import numpy as np
+import torch
+
+from tests._util import e2e_init_, golden
+
+
+def t(a, device):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+
+
+def check_losses(device):
+    """Six losses (values 1e-6) and their gradients (1e-5) vs modal/loss.py:10-152."""
+    from sln_amodal_amd.modal import loss as L
+    g = golden("losses")
+    leaves = {k: t(g[k], device).clone().requires_grad_(True) for k in
+              ("rpn_logits", "rpn_bbox_p", "cls_logits", "pdl", "pmask")}
+    T = lambda k: t(g[k], device)
+    vals = [L.compute_rpn_class_loss(T("rpn_match"), leaves["rpn_logits"]),
+            L.compute_rpn_bbox_loss(T("rpn_bbox_t"), T("rpn_match"), leaves["rpn_bbox_p"]),
+            L.compute_mrcnn_class_loss(T("tcls"), leaves["cls_logits"]),
+            L.compute_mrcnn_bbox_loss(T("tdl"), T("tcls"), leaves["pdl"]),
+            L.compute_layer_loss(T("tmask"), T("tcls"), leaves["pmask"])[0],
+            L.compute_amodal_loss(T("tmask"), T("tcls"), leaves["pmask"])[0]]
+    got = np.array([float(v) for v in vals])
+    assert np.allclose(got, g["losses"], rtol=1e-6, atol=1e-6), (got, g["losses"])
+    sum(vals).backward()
+    for leaf, key in (("rpn_logits", "g_rpn_logits"), ("rpn_bbox_p", "g_rpn_bbox"),
+                      ("cls_logits", "g_cls_logits"), ("pdl", "g_pdl"), ("pmask", "g_pmask")):
+        assert np.allclose(leaves[leaf].grad.cpu().numpy(), g[key], rtol=1e-5, atol=1e-7), key
+
+
+def check_rpn_targets(dim, device):
+    """build_rpn_targets replays the reference's recorded np.random.choice draws: match vector exact,
+    deltas 1e-6 (Functions.py:739-847)."""
+    from sln_amodal_amd.config import Config
+    from sln_amodal_amd.modal.Functions import build_rpn_targets
+    g = golden("rpn_targets_%d" % dim)
+    a = t(golden("anchors_%d" % dim)["anchors"], device)
+    pr = torch.ones(1, a.shape[0], device=device)
+    for i in range(int(g["n_draws"])):          # the reference's np.random.choice picks = dropped ids
+        pr[0, t(g["draw%d" % i], device).long()] = 0
+    gt = t(g["gt_boxes"], device).unsqueeze(0)
+    match, bbox = build_rpn_targets((dim, dim, 3), a, torch.ones(1, gt.shape[1], dtype=torch.int32, device=device),
+                                    gt, Config(), priority=pr)
+    assert np.array_equal(match[0].cpu().numpy(), g["rpn_match"])
+    assert np.allclose(bbox[0].cpu().numpy(), g["rpn_bbox"], rtol=1e-6, atol=1e-6)
+
+
+def check_box_ops(device):
+    from sln_amodal_amd import utils
+    from sln_amodal_amd.modal.Functions import apply_box_deltas, bbox_overlaps, clip_boxes
+    g = golden("box_ops")
+    T = lambda k: t(g[k], device)
+    dec = apply_box_deltas(T("anchors"), T("deltas") * torch.tensor([[0.1, 0.1, 0.2, 0.2]], device=device))
+    assert np.allclose(dec.cpu().numpy(), g["decoded"], rtol=1e-6, atol=1e-5)
+    assert np.allclose(clip_boxes(dec, [0, 0, 256, 256]).cpu().numpy(), g["clipped"], rtol=1e-6, atol=1e-5)
+    assert np.allclose(bbox_overlaps(T("b1"), T("b2")).cpu().numpy(), g["overlaps"], rtol=1e-6, atol=1e-7)
+    assert np.allclose(utils.box_refinement(t(g["b1"][:9], device), T("b2")).cpu().numpy(), g["refine"],
+                       rtol=1e-5, atol=1e-6)
+
+
+def e2e_model(device, dim=128):
+    """This repo's MaskRCNN (ResNet-101 + heads surgery + GLM) with the e2e fixtures' initialisation."""
+    from sln_amodal_amd.config import Config
+    from sln_amodal_amd.model import MaskRCNN
+
+    class C(Config):
+        NAME = "e2e"
+        IMAGE_MAX_DIM = dim
+        IMAGE_MIN_DIM = dim
+        STRICT_IMAGE_DIVISIBILITY = True
+
+    cfg = C()
+    m = MaskRCNN(cfg, "/tmp/sln_e2e_logs").apply_amodal_heads()
+    e2e_init_(m)
+    m = m.to(device)
+    m.set_trainable(".*", exclusive_off=False)
+    for p in m.GLM_modual.parameters():
+        p.requires_grad = False
+    return m, cfg
+
+
+def check_optimizer_step(device):
+    """Two rounds of clip(5.0) -> SGD(momentum .9, wd 1e-4 on non-'bn' names) on name-keyed seeded
+    gradients, against the optimizer the reference's train_model built (model.py:352-358, 441-444):
+    total norms 1e-5 rel., parameter slices 1e-6."""
+    g = golden("optimizer_step")
+    m, cfg = e2e_model(device)
+    params = dict(m.named_parameters())
+    names = [str(n) for n in g["names"]]
+    for n in names:
+        assert np.array_equal(params[n].detach().reshape(-1)[:256].cpu().numpy(), g["before/" + n]), n
+    assert abs(float(g["weight_decay"][0]) - cfg.WEIGHT_DECAY) < 1e-12 and float(g["weight_decay"][1]) == 0.0
+    assert abs(float(g["momentum"]) - cfg.LEARNING_MOMENTUM) < 1e-12
+    # every trainable non-GLM parameter sits in the weight-decay group (all BatchNorm is frozen); the
+    # reference's no-decay group holds only the (gradient-less) GLM BatchNorm parameters
+    assert all(str(n).startswith("GLM_modual") for n in g["nowd_names"])
+    opt = m.make_optimizer(float(g["lr"]))
+    for rnd in range(2):
+        for n, p in params.items():
+            if not p.requires_grad:
+                continue
+            gen = torch.Generator().manual_seed((zlib.crc32(n.encode()) + 7919 * (rnd + 1)) & 0x7FFFFFFF)
+            p.grad = (torch.randn(p.shape, generator=gen) * float(g["grad_scale"][rnd])).to(device)
+        m.optimizer_step(opt)
+        want = float(g["norm%d" % rnd])
+        assert abs(float(m.last_grad_norm) - want) <= 1e-5 * want, (rnd, float(m.last_grad_norm), want)
+        for n in names:
+            got = params[n].detach().reshape(-1)[:256].cpu().numpy()
+            assert np.allclose(got, g["after%d/" % rnd + n], rtol=1e-6, atol=1e-7), (rnd, n)

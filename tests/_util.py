@@ -44,3 +44,38 @@ def seeded_dets(n, seed, span=256.0, tie_free=True):
     boxes = np.concatenate([tl, np.minimum(tl + wh, span)], axis=1)
     scores = rng.permutation(n).astype(np.float64) / max(n, 1) + rng.uniform(0, 0.5 / max(n, 1), n)
     return np.concatenate([boxes, scores[:, None]], axis=1).astype(np.float32)
+
+
+E2E_RESCALE = (
+    # (suffix or exact key, factor): applied on top of key_init_ so that a randomly initialised
+    # 100-layer detector stays in a sane numeric range on +-128 pixel inputs (no NaN box decodes,
+    # un-saturated softmaxes, proposals that overlap the ground truth) -- identical on both sides
+    ("fpn.C1.0.weight", 1.0 / 64),                       # pixel scale -> O(1) activations
+    ("GLM_modual.base.layer1.conv1.conv.weight", 1.0 / 64),
+    (".bn3.weight", 0.3),                                # residual branches of the detector backbone
+    (".increase.bn.weight", 0.3),                        # ... and of the DeepLab bottlenecks
+    ("rpn.conv_class.weight", 0.2),
+    ("rpn.conv_bbox.weight", 0.05),
+    ("classifier.linear_bbox.weight", 0.2),
+    ("GLM_modual.base.aspp.c0.weight", 0.5), ("GLM_modual.base.aspp.c1.weight", 0.5),
+    ("GLM_modual.base.aspp.c2.weight", 0.5), ("GLM_modual.base.aspp.c3.weight", 0.5),
+)
+
+
+# added after the rescale: with all-positive (post-ReLU) features a random 2-class head votes the same
+# way for every roi; centre its logit difference so that inference keeps about half the rois
+E2E_SHIFT = (("classifier.linear_class.bias", (-1.17, 1.17)),)
+
+
+def e2e_init_(module):
+    """key_init_ + the E2E_RESCALE / E2E_SHIFT rules; used by tools/gen_golden_e2e.py on the
+    reference's MaskRCNN and by the end-to-end parity tests on this repo's."""
+    key_init_(module)
+    with torch.no_grad():
+        for key, t in module.state_dict().items():
+            for pat, f in E2E_RESCALE:
+                if key == pat or (pat.startswith(".") and key.endswith(pat)):
+                    t.mul_(f)
+            for pat, v in E2E_SHIFT:
+                if key == pat:
+                    t.add_(torch.tensor(v, dtype=t.dtype, device=t.device))

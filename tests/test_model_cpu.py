@@ -68,22 +68,13 @@ def test_glm_matches_reference_module():
 
 
 def test_losses_match_reference():
-    from sln_amodal_amd.modal import loss as L
-    g = golden("losses")
-    leaves = {k: t(g[k]).clone().requires_grad_(True) for k in
-              ("rpn_logits", "rpn_bbox_p", "cls_logits", "pdl", "pmask")}
-    vals = [L.compute_rpn_class_loss(t(g["rpn_match"]), leaves["rpn_logits"]),
-            L.compute_rpn_bbox_loss(t(g["rpn_bbox_t"]), t(g["rpn_match"]), leaves["rpn_bbox_p"]),
-            L.compute_mrcnn_class_loss(t(g["tcls"]), leaves["cls_logits"]),
-            L.compute_mrcnn_bbox_loss(t(g["tdl"]), t(g["tcls"]), leaves["pdl"]),
-            L.compute_layer_loss(t(g["tmask"]), t(g["tcls"]), leaves["pmask"])[0],
-            L.compute_amodal_loss(t(g["tmask"]), t(g["tcls"]), leaves["pmask"])[0]]
-    got = np.array([float(v) for v in vals])
-    assert np.allclose(got, g["losses"], rtol=1e-6, atol=1e-6)
-    sum(vals).backward()
-    for leaf, key in (("rpn_logits", "g_rpn_logits"), ("rpn_bbox_p", "g_rpn_bbox"),
-                      ("cls_logits", "g_cls_logits"), ("pdl", "g_pdl"), ("pmask", "g_pmask")):
-        assert np.allclose(leaves[leaf].grad.numpy(), g[key], rtol=1e-5, atol=1e-7), key
+    from tests._parity import check_losses
+    check_losses("cpu")
+
+
+def test_optimizer_step_matches_reference_optimizer():
+    from tests._parity import check_optimizer_step
+    check_optimizer_step("cpu")
 
 
 def test_total_loss_batch_semantics():
@@ -104,30 +95,14 @@ def test_total_loss_batch_semantics():
 
 @pytest.mark.parametrize("dim", [128, 256])
 def test_build_rpn_targets_replays_reference_draws(dim):
-    from sln_amodal_amd.config import Config
-    from sln_amodal_amd.modal.Functions import build_rpn_targets
-    g = golden("rpn_targets_%d" % dim)
-    a = t(golden("anchors_%d" % dim)["anchors"])
-    pr = torch.ones(1, a.shape[0])
-    for i in range(int(g["n_draws"])):          # the reference's np.random.choice picks = dropped ids
-        pr[0, t(g["draw%d" % i]).long()] = 0
-    gt = t(g["gt_boxes"]).unsqueeze(0)
-    match, bbox = build_rpn_targets((dim, dim, 3), a, torch.ones(1, gt.shape[1], dtype=torch.int32), gt,
-                                    Config(), priority=pr)
-    assert np.array_equal(match[0].numpy(), g["rpn_match"])
-    assert np.allclose(bbox[0].numpy(), g["rpn_bbox"], rtol=1e-6, atol=1e-6)
+    from tests._parity import check_rpn_targets
+    check_rpn_targets(dim, "cpu")
 
 
 def test_box_ops_and_anchors_match_reference():
     from sln_amodal_amd import utils
-    from sln_amodal_amd.modal.Functions import apply_box_deltas, bbox_overlaps, clip_boxes
-    g = golden("box_ops")
-    dec = apply_box_deltas(t(g["anchors"]), t(g["deltas"]) * torch.tensor([[0.1, 0.1, 0.2, 0.2]]))
-    assert np.allclose(dec.numpy(), g["decoded"], rtol=1e-6, atol=1e-5)
-    assert np.allclose(clip_boxes(dec, [0, 0, 256, 256]).numpy(), g["clipped"], rtol=1e-6, atol=1e-5)
-    assert np.allclose(bbox_overlaps(t(g["b1"]), t(g["b2"])).numpy(), g["overlaps"], rtol=1e-6, atol=1e-7)
-    assert np.allclose(utils.box_refinement(t(g["b1"][:9]), t(g["b2"])).numpy(), g["refine"], rtol=1e-5,
-                       atol=1e-6)
+    from tests._parity import check_box_ops
+    check_box_ops("cpu")
     for dim in (128, 256):
         ga = golden("anchors_%d" % dim)
         a = utils.generate_pyramid_anchors((32, 64, 128, 256, 512), [0.5, 1, 2], ga["shapes"],

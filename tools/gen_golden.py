@@ -273,7 +273,7 @@ def main():
          g_pmask=pmask.grad.numpy())
 
 
-if __name__ == "__main__" and "--modules" not in sys.argv:
+if __name__ == "__main__" and "--modules" not in sys.argv and "--module-grads" not in sys.argv:
     main()
 
 
@@ -343,3 +343,94 @@ def module_goldens():
 
 if __name__ == "__main__" and "--modules" in sys.argv:
     module_goldens()
+
+
+def module_grad_goldens():
+    """Backward goldens of the reference's nn.Modules ("outputs/grads <= 1e-4"):
+    FPN + RPN (ResNet-50, 64x64 input), Classifier and Mask on fixed maps / rois.  Loss = sum of
+    <output, seeded upstream>; recorded: the input gradient(s) and leading slices of weight gradients."""
+    ref_modals, ref_F = ref_harness.install()
+    from tests._util import key_init_
+    n_keep = 512
+    g = torch.Generator().manual_seed(41)
+    # ---- FPN + RPN ----
+    resnet = ref_modals.ResNet("resnet50", stage5=True)
+    fpn = ref_modals.FPN(*resnet.stages(), out_channels=256).eval()
+    rpn = ref_modals.RPN(3, 1, 256).eval()
+    key_init_(fpn); key_init_(rpn)
+    for m in list(fpn.modules()) + list(rpn.modules()):     # model.py:192-197: BN never trains
+        if isinstance(m, torch.nn.BatchNorm2d):
+            for p in m.parameters():
+                p.requires_grad = False
+    x = torch.randn(2, 3, 64, 64, generator=g, requires_grad=True)
+    p = fpn(x)
+    outs = [rpn(t) for t in p]
+    logits = torch.cat([o[0] for o in outs], 1)
+    bbox = torch.cat([o[2] for o in outs], 1)
+    up_l = torch.randn(logits.shape, generator=g)
+    up_b = torch.randn(bbox.shape, generator=g)
+    up_p = [torch.randn(t.shape, generator=g) * 0.1 for t in p[:4]]
+    loss = (logits * up_l).sum() + (bbox * up_b).sum() + sum((t * u).sum() for t, u in zip(p[:4], up_p))
+    loss.backward()
+    names = ["C1.0.weight", "C2.0.conv1.weight", "C2.2.conv2.weight", "C3.0.downsample.0.weight",
+             "C4.3.conv2.weight", "C5.2.conv3.weight", "C5.2.conv3.bias", "P5_conv1.weight",
+             "P3_conv1.weight", "P2_conv2.1.weight", "P2_conv2.1.bias"]
+    fp = dict(fpn.named_parameters()); rp = dict(rpn.named_parameters())
+    arrs = {"x": x.detach().numpy(), "gx": x.grad.numpy(), "up_logits": up_l.numpy(), "up_bbox": up_b.numpy(),
+            "loss": np.array(loss.item()), "fpn_names": np.array(names), "rpn_names": np.array(list(rp))}
+    for i, u in enumerate(up_p):
+        arrs["up_p%d" % i] = u.numpy()
+    for n in names:
+        arrs["fpn_g/" + n] = fp[n].grad.reshape(-1)[:n_keep].numpy()
+        arrs["fpn_gn/" + n] = np.array(float(fp[n].grad.norm()))
+    for n in rp:
+        arrs["rpn_g/" + n] = rp[n].grad.reshape(-1)[:n_keep].numpy()
+        arrs["rpn_gn/" + n] = np.array(float(rp[n].grad.norm()))
+    print("fpn/rpn loss", loss.item(), "gx", float(x.grad.abs().mean()))
+    save("module_grads_fpn_rpn", **arrs)
+    # ---- heads ----
+    C = 256
+    maps = [(torch.randn(1, C, s, s, generator=g) * 0.5).requires_grad_(True) for s in (32, 16, 8, 4)]
+    R = 12
+    ctr = torch.rand(R, 2, generator=g) * 0.6 + 0.2
+    size = torch.exp(torch.rand(R, 2, generator=g) * 3.0 - 3.2)
+    rois = torch.cat([ctr - size / 2, ctr + size / 2], 1).clamp(0, 1).unsqueeze(0)
+    cls = ref_modals.Classifier(256, 7, (128, 128, 3), 2).eval()
+    msk = ref_modals.Mask(256, 16, (128, 128, 3), 2).eval()
+    msk.conv1 = torch.nn.Conv2d(439, 256, kernel_size=3, stride=1)
+    key_init_(cls); key_init_(msk)
+    for m in list(cls.modules()) + list(msk.modules()):
+        if isinstance(m, torch.nn.BatchNorm2d):
+            for p_ in m.parameters():
+                p_.requires_grad = False
+    glm_feat = torch.randn(R, 183, 16, 16, generator=g) * 0.3
+    c_out = cls(list(maps), rois.clone())
+    m_out, _ = msk(list(maps), rois.clone(), glm_feat)
+    up_c = torch.randn(c_out[0].shape, generator=g)
+    up_bb = torch.randn(c_out[2].shape, generator=g)
+    up_m = torch.randn(m_out.shape, generator=g) * 0.05
+    loss = (c_out[0] * up_c).sum() + (c_out[2] * up_bb).sum() + (m_out * up_m).sum()
+    loss.backward()
+    cp = dict(cls.named_parameters()); mp = dict(msk.named_parameters())
+    arrs = {"native": np.array("oracle"), "rois": rois.numpy(), "glm_feat": glm_feat.numpy(),
+            "up_cls": up_c.numpy(), "up_bbox": up_bb.numpy(), "up_mask": up_m.numpy(),
+            "loss": np.array(loss.item()),
+            "cls_names": np.array([n for n, p_ in cp.items() if p_.grad is not None]),
+            "mask_names": np.array([n for n, p_ in mp.items() if p_.grad is not None])}
+    for i, m in enumerate(maps):
+        arrs["map%d" % i] = m.detach().numpy()
+        arrs["gmap%d" % i] = m.grad.numpy() if m.grad is not None else np.zeros(m.shape, np.float32)
+    for n, p_ in cp.items():
+        if p_.grad is not None:
+            arrs["cls_g/" + n] = p_.grad.reshape(-1)[:n_keep].numpy()
+            arrs["cls_gn/" + n] = np.array(float(p_.grad.norm()))
+    for n, p_ in mp.items():
+        if p_.grad is not None:
+            arrs["mask_g/" + n] = p_.grad.reshape(-1)[:n_keep].numpy()
+            arrs["mask_gn/" + n] = np.array(float(p_.grad.norm()))
+    print("heads loss", loss.item())
+    save("module_grads_heads", **arrs)
+
+
+if __name__ == "__main__" and "--module-grads" in sys.argv:
+    module_grad_goldens()
