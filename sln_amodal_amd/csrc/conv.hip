@@ -37,35 +37,109 @@
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) _Float16 h16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 h16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 #define BM 128
 #define BN 128
 #define BK 32
 
+// ---------------------------------------------------------------- operand formats
+// P = 3: three bf16 parts, six part products per fp32 product (see the top of the file).
+// P = 2: two fp16 parts of v*s, s a per-tensor power of two ("scaled split-fp16"):
+//          h0 = fp16_rne(v*s),  h1 = fp16_rne(v*s - h0)          (22 significant bits)
+//        and three part products a0*b0 + a0*b1 + a1*b0 on v_mfma_f32_32x32x16_f16; the dropped
+//        a1*b1 term is 2^-22 relative.  fp16's narrow exponent needs the scale: s is chosen so that
+//        max|v|*s sits near 2^11 (sln_scale_update_f32), which leaves 2^5 of head room before
+//        +-65504 and keeps every element down to max|v| * 2^-14 at full 22-bit precision (smaller
+//        ones degrade gracefully: absolute error <= max|v| * 2^-36).  The scale of a tensor that a
+//        conv epilogue writes is not known before that conv has run, so s comes from the amax the
+//        SAME tensor had the last time it was produced (delayed scaling); producers track the
+//        running amax (atomic max) and clamp + count anything beyond +-65504 instead of emitting inf.
+//        Scales are powers of two, so v*s and acc/(sa*sb) are exact: the only rounding is in the
+//        parts themselves.  Parts are stored in the same 16-bit containers as bf16 parts.
+#define SLN_F16_MAX 65504.0f
+
+struct SplitScale {
+    const float *scale;   // device scalar s (NULL = 1)
+    float *amax;          // device scalar: running max |v| (NULL = not tracked)
+    int *saturated;       // device counter of clamped elements (NULL = not counted)
+};
+
 // ---------------------------------------------------------------- elementwise
+// Returns true when an element had to be clamped (P = 2 only).
 template <int P>
-__device__ __forceinline__ void split4(const float4 v, bf16x4 *parts) {
+__device__ __forceinline__ bool split4(const float4 v, bf16x4 *parts, float s = 1.f) {
     float r[4] = {v.x, v.y, v.z, v.w};
+    if (P == 3) {
 #pragma unroll
-    for (int p = 0; p < P; ++p) {
-        bf16x4 h;
+        for (int p = 0; p < P; ++p) {
+            bf16x4 h;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            h[j] = (__bf16)r[j];
-            r[j] -= (float)h[j];
+            for (int j = 0; j < 4; ++j) {
+                h[j] = (__bf16)r[j];
+                r[j] -= (float)h[j];
+            }
+            parts[p] = h;
         }
-        parts[p] = h;
+        return false;
+    }
+    bool sat = false;
+    h16x4 h0, h1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float q = r[j] * s;                      // exact: s is a power of two
+        if (fabsf(q) > SLN_F16_MAX) {            // (NaN compares false and stays NaN)
+            q = copysignf(SLN_F16_MAX, q);
+            sat = true;
+        }
+        h0[j] = (_Float16)q;
+        h1[j] = (_Float16)(q - (float)h0[j]);
+    }
+    parts[0] = __builtin_bit_cast(bf16x4, h0);
+    parts[1] = __builtin_bit_cast(bf16x4, h1);
+    return sat;
+}
+
+__device__ __forceinline__ float amax4(float m, const float v[4]) {
+    return fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+}
+
+// Block-level commit of a per-thread running max / saturation flag: wave shuffle, one LDS word,
+// then at most one global atomic per block (skipped when the recorded amax already covers it).
+__device__ __forceinline__ void amax_commit(float m, bool sat, const SplitScale &q, unsigned *s_word) {
+    if (!q.amax && !q.saturated) return;
+    if (threadIdx.x == 0) { s_word[0] = 0u; s_word[1] = 0u; }
+    __syncthreads();
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    const bool any_sat = __any(sat);
+    if ((threadIdx.x & 63) == 0) {
+        if (m > 0.f) atomicMax(&s_word[0], __float_as_uint(m));
+        if (any_sat) s_word[1] = 1u;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned bits = s_word[0];
+        if (q.amax && bits > __float_as_uint(*(volatile const float *)q.amax))
+            atomicMax((unsigned *)q.amax, bits);    // non-negative floats order like their bits
+        if (q.saturated && s_word[1]) atomicAdd(q.saturated, 1);
     }
 }
 
-// x [M][C] fp32 -> parts [P][M][Cp] bf16 (channels C..Cp-1 zero).  C % 4 == 0 fast path.
+// x [M][C] fp32 -> parts [P][M][Cp] (channels C..Cp-1 zero).  C % 4 == 0 fast path.
+// parts == NULL: only the amax is taken (first use of a tensor slot, before it has a scale).
 template <int P>
 __global__ __launch_bounds__(256) void act_split_kernel(const float *__restrict__ x, long M, int C,
-                                                        int Cp, __bf16 *__restrict__ parts) {
+                                                        int Cp, __bf16 *__restrict__ parts, SplitScale q) {
+    __shared__ unsigned s_word[2];
     const int q4 = Cp / 4;
     const long total = M * q4;
     const long pstride = M * Cp;
+    const float qs = (P == 2 && q.scale) ? *q.scale : 1.f;
+    float amx = 0.f;
+    bool sat = false;
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
         const long m = e / q4;
         const int c = (int)(e - m * q4) * 4;
@@ -78,11 +152,17 @@ __global__ __launch_bounds__(256) void act_split_kernel(const float *__restrict_
                 if (c + j < C) t[j] = x[m * C + c + j];
             v = make_float4(t[0], t[1], t[2], t[3]);
         }
+        if (P == 2) {
+            const float t4[4] = {v.x, v.y, v.z, v.w};
+            amx = amax4(amx, t4);
+        }
+        if (!parts) continue;
         bf16x4 ps[P];
-        split4<P>(v, ps);
+        sat |= split4<P>(v, ps, qs);
 #pragma unroll
         for (int p = 0; p < P; ++p) *(bf16x4 *)(parts + p * pstride + m * Cp + c) = ps[p];
     }
+    if (P == 2) amax_commit(amx, sat, q, s_word);
 }
 
 // gz = gy * (y > 0 ? 1 : 0) * scale[c]; writes gu = gy*(y>0) (fp32, optional), the
@@ -115,8 +195,9 @@ __device__ __forceinline__ void grad_prep_row(const float *__restrict__ gy, cons
 template <int P>
 __device__ __forceinline__ void grad_prep_emit(float g[4], long m, int c, int C, int Cp, bool vec,
                                                const float sc[4], float acc[4], long pstride,
-                                               float *__restrict__ gu, __bf16 *__restrict__ parts) {
-    if (gu) {
+                                               float *__restrict__ gu, __bf16 *__restrict__ parts,
+                                               float qs, float &amx, bool &sat) {
+    if (gu && parts) {
         if (vec) *(float4 *)(gu + m * C + c) = make_float4(g[0], g[1], g[2], g[3]);
         else
             for (int j = 0; j < 4; ++j)
@@ -131,9 +212,11 @@ __device__ __forceinline__ void grad_prep_emit(float g[4], long m, int c, int C,
 #pragma clang fp contract(off)
         for (int j = 0; j < 4; ++j) g[j] = g[j] * sc[j];
     }
+    if (P == 2) amx = amax4(amx, g);
+    if (!parts) return;                      // amax-only pass (first use of the tensor's scale slot)
     for (int j = 0; j < 4; ++j) acc[j] += g[j];
     bf16x4 ps[P];
-    split4<P>(make_float4(g[0], g[1], g[2], g[3]), ps);
+    sat |= split4<P>(make_float4(g[0], g[1], g[2], g[3]), ps, qs);
 #pragma unroll
     for (int p = 0; p < P; ++p) *(bf16x4 *)(parts + p * pstride + m * Cp + c) = ps[p];
 }
@@ -144,8 +227,9 @@ __global__ __launch_bounds__(256) void grad_prep_kernel(const float *__restrict_
                                                         const float *__restrict__ scale, long M, int C,
                                                         int Cp, float *__restrict__ gu,
                                                         __bf16 *__restrict__ parts,
-                                                        float *__restrict__ gbias) {
+                                                        float *__restrict__ gbias, SplitScale q) {
     __shared__ float s_bias[1024];
+    __shared__ unsigned s_word[2];
     const int q4 = Cp / 4;
     int tw = 1, sh = 0;                       // tw = channel quads per block row (power of two)
     while (tw < q4 && tw < 256) { tw <<= 1; ++sh; }
@@ -153,6 +237,9 @@ __global__ __launch_bounds__(256) void grad_prep_kernel(const float *__restrict_
     const int cq_l = threadIdx.x & (tw - 1), r0 = threadIdx.x >> sh;
     const long pstride = M * Cp;
     const long rstep = (long)gridDim.x * R;
+    const float qs = (P == 2 && q.scale) ? *q.scale : 1.f;
+    float amx = 0.f;
+    bool sat = false;
     for (int ct = 0; ct * tw < q4; ++ct) {
         const int c = (ct * tw + cq_l) * 4;
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
@@ -165,16 +252,16 @@ __global__ __launch_bounds__(256) void grad_prep_kernel(const float *__restrict_
                 float g0[4], g1[4];
                 grad_prep_row(gy, y, m, c, C, vec, g0);
                 grad_prep_row(gy, y, m + rstep, c, C, vec, g1);
-                grad_prep_emit<P>(g0, m, c, C, Cp, vec, sc, acc, pstride, gu, parts);
-                grad_prep_emit<P>(g1, m + rstep, c, C, Cp, vec, sc, acc, pstride, gu, parts);
+                grad_prep_emit<P>(g0, m, c, C, Cp, vec, sc, acc, pstride, gu, parts, qs, amx, sat);
+                grad_prep_emit<P>(g1, m + rstep, c, C, Cp, vec, sc, acc, pstride, gu, parts, qs, amx, sat);
             }
             if (m < M) {
                 float g0[4];
                 grad_prep_row(gy, y, m, c, C, vec, g0);
-                grad_prep_emit<P>(g0, m, c, C, Cp, vec, sc, acc, pstride, gu, parts);
+                grad_prep_emit<P>(g0, m, c, C, Cp, vec, sc, acc, pstride, gu, parts, qs, amx, sat);
             }
         }
-        if (gbias) {
+        if (gbias && parts) {
             for (int i = threadIdx.x; i < tw * 4; i += 256) s_bias[i] = 0.f;
             __syncthreads();
             for (int j = 0; j < 4; ++j)
@@ -187,16 +274,21 @@ __global__ __launch_bounds__(256) void grad_prep_kernel(const float *__restrict_
             __syncthreads();
         }
     }
+    if (P == 2) amax_commit(amx, sat, q, s_word);
 }
 
-// fp32 weights (any strides) -> [P][O][KH][KW][Ip] bf16 parts (i >= I zero).
+// fp32 weights (any strides) -> [P][O][KH][KW][Ip] parts (i >= I zero).
 // flip=1 mirrors the taps (with O/I swapped through the strides this expresses the
-// data-gradient convolution as a forward convolution).
+// data-gradient convolution as a forward convolution).  out == NULL: amax only.
 __global__ __launch_bounds__(256) void split_weights_kernel(const float *__restrict__ w, int O, int I,
                                                             int Ip, int KH, int KW, long s_o, long s_i,
                                                             long s_kh, long s_kw, int flip, int P,
-                                                            __bf16 *__restrict__ out) {
+                                                            __bf16 *__restrict__ out, SplitScale q) {
+    __shared__ unsigned s_word[2];
     const long total = (long)O * KH * KW * Ip;
+    const float qs = (P == 2 && q.scale) ? *q.scale : 1.f;
+    float amx = 0.f;
+    bool sat = false;
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
         const int i = (int)(idx % Ip);
         long r = idx / Ip;
@@ -205,12 +297,41 @@ __global__ __launch_bounds__(256) void split_weights_kernel(const float *__restr
         const int o = (int)(r / KH);
         const int skh = flip ? KH - 1 - kh : kh, skw = flip ? KW - 1 - kw : kw;
         float v = (i < I) ? w[o * s_o + i * s_i + skh * s_kh + skw * s_kw] : 0.f;
+        if (P == 2) {
+            amx = fmaxf(amx, fabsf(v));
+            if (!out) continue;
+            float qv = v * qs;
+            if (fabsf(qv) > SLN_F16_MAX) { qv = copysignf(SLN_F16_MAX, qv); sat = true; }
+            const _Float16 h0 = (_Float16)qv;
+            const _Float16 h1 = (_Float16)(qv - (float)h0);
+            out[idx] = __builtin_bit_cast(__bf16, h0);
+            out[total + idx] = __builtin_bit_cast(__bf16, h1);
+            continue;
+        }
         for (int pp = 0; pp < P; ++pp) {
             const __bf16 h = (__bf16)v;
             out[(long)pp * total + idx] = h;
             v -= (float)h;
         }
     }
+    if (P == 2) amax_commit(amx, sat, q, s_word);
+}
+
+// scale[i] <- the power of two that puts amax[i] near 2^target_log2 (amax[i] == 0: unchanged);
+// amax[i] <- 0.  One launch per step over every tensor slot (delayed scaling).
+__global__ __launch_bounds__(256) void scale_update_kernel(float *__restrict__ amax, float *__restrict__ scale,
+                                                           int n, int target_log2) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float a = amax[i];
+    if (a > 0.f && a < INFINITY) {
+        int e;
+        (void)frexpf(a, &e);                 // a = f * 2^e, f in [0.5, 1)
+        int k = target_log2 - e;             // a * 2^k in [2^(target-1), 2^target)
+        k = k < -120 ? -120 : (k > 120 ? 120 : k);
+        scale[i] = ldexpf(1.f, k);
+    }
+    amax[i] = 0.f;
 }
 
 // ------------------------------------------------------------------- forward

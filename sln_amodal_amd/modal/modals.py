@@ -194,18 +194,20 @@ def pyramid_roi_align_image(inputs, pool_size, image_shape, istrain=False, box_i
             image.is_contiguous(memory_format=torch.channels_last):
         import ctypes as C
         from .. import _lib
-        with torch.no_grad():
-            K, Cc = boxes.shape[0], image.shape[1]
-            wide = torch.empty((K, pool_size, pool_size, Cc + cat_extra), dtype=torch.float32,
-                               device=image.device).permute(0, 3, 1, 2)
-            ptrs = (C.c_void_p * 4)(*[image.data_ptr()] * 4)
-            hw = (C.c_int * 8)(*[image.shape[2], image.shape[3]] * 4)
-            level = torch.full((K,), 2, dtype=torch.int32, device=image.device)
-            _lib.check(_lib.lib().sln_pyramid_crop_fwd_f32(
-                ptrs, hw, image.shape[0], Cc, ops._ptr(boxes.detach().contiguous()),
-                ops._ptr(box_ind.contiguous()), ops._ptr(level), K, pool_size, pool_size, 0.0,
-                ops._ptr(wide), Cc + cat_extra, 0, ops._stream()), "sln_pyramid_crop_fwd_f32")
-            view = wide[:, :Cc]
+        # (allocated and sliced with grad mode as it is: autograd forbids the later in-place fill of a
+        # view that was created under no_grad; the crop itself is not an autograd op)
+        K, Cc = boxes.shape[0], image.shape[1]
+        wide = torch.empty((K, pool_size, pool_size, Cc + cat_extra), dtype=torch.float32,
+                           device=image.device).permute(0, 3, 1, 2)
+        ptrs = (C.c_void_p * 4)(*[image.data_ptr()] * 4)
+        hw = (C.c_int * 8)(*[image.shape[2], image.shape[3]] * 4)
+        level = torch.full((K,), 2, dtype=torch.int32, device=image.device)
+        bx = boxes.detach().contiguous()
+        bi = box_ind.contiguous()
+        _lib.check(_lib.lib().sln_pyramid_crop_fwd_f32(
+            ptrs, hw, image.shape[0], Cc, ops._ptr(bx), ops._ptr(bi), ops._ptr(level), K, pool_size,
+            pool_size, 0.0, ops._ptr(wide), Cc + cat_extra, 0, ops._stream()), "sln_pyramid_crop_fwd_f32")
+        view = wide.detach()[:, :Cc]
         view._sln_cat_buf = wide
         return view
     return CropAndResizeFunction(pool_size, pool_size, 0)(image, boxes.contiguous(),

@@ -387,15 +387,17 @@ class MaskRCNN(nn.Module):
                                             np.zeros([cfg.NUM_CLASSES], dtype=np.int32)))
         return np.stack(molded), np.stack(metas), np.stack(windows)
 
-    def detect(self, images, mode="inference"):
+    def detect(self, images, mode="inference", priorities=None):
         """List of HxWx3 images -> list of dicts(rois, class_ids, scores, masks)
-        (model.py:464-514)."""
+        (model.py:464-514).  priorities: per-image list of predict() overrides (parity tests feed the
+        reference's proposals)."""
         results = []
         with torch.no_grad():
-            for image in images:
+            for i, image in enumerate(images):
                 molded, metas, windows = self.mold_inputs([image])
                 x = torch.from_numpy(molded.transpose(0, 3, 1, 2)).float().to(self.anchors.device)
-                detections, mrcnn_mask = self.predict([x, metas], mode=mode)
+                detections, mrcnn_mask = self.predict([x, metas], mode=mode,
+                                                      priorities=priorities[i] if priorities else None)
                 if len(detections) == 0:
                     continue
                 det = detections[0].cpu().numpy()

@@ -86,8 +86,11 @@ def e2e_model(device, dim=128):
 
 def check_optimizer_step(device):
     """Two rounds of clip(5.0) -> SGD(momentum .9, wd 1e-4 on non-'bn' names) on name-keyed seeded
-    gradients, against the optimizer the reference's train_model built (model.py:352-358, 441-444):
-    total norms 1e-5 rel., parameter slices 1e-6."""
+    gradients, against the optimizer the reference's train_model built (model.py:352-358, 441-444).
+    Total norm: within 1e-6 of the exact (float64) norm of the same gradients, and within 3e-4 of the
+    fixture -- the reference's clip_grad_norm_ ran on torch-CPU, whose fp32 reduction over 45 M
+    elements is itself 1.2e-4 below the exact value (159.9058 vs 159.9245).  Parameter UPDATES
+    (after - before) within 2e-3 (fp32 cancellation on 6e-6-sized steps of 0.05-sized weights)."""
     g = golden("optimizer_step")
     m, cfg = e2e_model(device)
     params = dict(m.named_parameters())
@@ -100,15 +103,73 @@ def check_optimizer_step(device):
     # reference's no-decay group holds only the (gradient-less) GLM BatchNorm parameters
     assert all(str(n).startswith("GLM_modual") for n in g["nowd_names"])
     opt = m.make_optimizer(float(g["lr"]))
+    prev = {n: g["before/" + n].astype(np.float64) for n in names}
     for rnd in range(2):
+        exact = 0.0
         for n, p in params.items():
             if not p.requires_grad:
                 continue
             gen = torch.Generator().manual_seed((zlib.crc32(n.encode()) + 7919 * (rnd + 1)) & 0x7FFFFFFF)
-            p.grad = (torch.randn(p.shape, generator=gen) * float(g["grad_scale"][rnd])).to(device)
+            gr = torch.randn(p.shape, generator=gen) * float(g["grad_scale"][rnd])
+            exact += float(gr.double().pow(2).sum())
+            p.grad = gr.to(device)
         m.optimizer_step(opt)
-        want = float(g["norm%d" % rnd])
-        assert abs(float(m.last_grad_norm) - want) <= 1e-5 * want, (rnd, float(m.last_grad_norm), want)
+        want, got = float(g["norm%d" % rnd]), float(m.last_grad_norm)
+        assert abs(got - want) <= 3e-4 * want, (rnd, got, want)
+        if device != "cpu":
+            assert abs(got - exact ** 0.5) <= 1e-6 * exact ** 0.5, (rnd, got, exact ** 0.5)
         for n in names:
-            got = params[n].detach().reshape(-1)[:256].cpu().numpy()
-            assert np.allclose(got, g["after%d/" % rnd + n], rtol=1e-6, atol=1e-7), (rnd, n)
+            now = params[n].detach().reshape(-1)[:256].double().cpu().numpy()
+            ref = g["after%d/" % rnd + n].astype(np.float64)
+            d_ref, d_got = ref - prev[n], now - prev[n]
+            assert np.linalg.norm(d_got - d_ref) <= 2e-3 * np.linalg.norm(d_ref), (rnd, n)
+            prev[n] = ref
+
+
+def grad_close(got, want_slice, want_norm, name, tol=1e-4):
+    """Relative L2 over the stored slice (a slice that is all zero in the reference must be ~zero)."""
+    got = got.reshape(-1)[:want_slice.size].double().cpu().numpy()
+    den = max(np.linalg.norm(want_slice), 1e-6 * want_norm * (want_slice.size ** 0.5), 1e-30)
+    err = np.linalg.norm(got - want_slice) / den
+    assert err <= tol, (name, err)
+    return err
+
+
+def freeze_bn(*mods):
+    for mod in mods:
+        for m in mod.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                for p in m.parameters():
+                    p.requires_grad = False
+
+
+def check_fpn_rpn_grads(device, tight, deep_tol):
+    """Backward of the reference's FPN + RPN modules (ResNet-50, 64x64 input, seeded upstream
+    gradients): input gradient and leading slices of 17 weight / bias gradients, relative L2.
+    `tight` applies above C5 (FPN convs, RPN), `deep_tol` to C1..C4 and the input gradient."""
+    from sln_amodal_amd.modal.modals import FPN, RPN, ResNet
+    from tests._util import key_init_
+    g = golden("module_grads_fpn_rpn")
+    resnet = ResNet("resnet50", stage5=True)
+    fpn = FPN(*resnet.stages(), out_channels=256).eval()
+    rpn = RPN(3, 1, 256).eval()
+    key_init_(fpn); key_init_(rpn)
+    fpn, rpn = fpn.to(device), rpn.to(device)
+    freeze_bn(fpn, rpn)
+    x = t(g["x"], device).requires_grad_(True)
+    p = fpn(x)
+    outs = [rpn(q) for q in p]
+    logits = torch.cat([o[0] for o in outs], 1)
+    bbox = torch.cat([o[2] for o in outs], 1)
+    loss = (logits * t(g["up_logits"], device)).sum() + (bbox * t(g["up_bbox"], device)).sum() + \
+        sum((q * t(g["up_p%d" % i], device)).sum() for i, q in enumerate(p[:4]))
+    assert abs(float(loss) - float(g["loss"])) <= 1e-4 * max(abs(float(g["loss"])), 1.0)
+    loss.backward()
+    gx = x.grad.double().cpu().numpy()
+    assert np.linalg.norm(gx - g["gx"]) / np.linalg.norm(g["gx"]) <= deep_tol
+    fp, rp = dict(fpn.named_parameters()), dict(rpn.named_parameters())
+    for n in [str(s) for s in g["fpn_names"]]:
+        deep = n.startswith(("C1", "C2", "C3", "C4"))
+        grad_close(fp[n].grad, g["fpn_g/" + n], float(g["fpn_gn/" + n]), n, deep_tol if deep else tight)
+    for n in [str(s) for s in g["rpn_names"]]:
+        grad_close(rp[n].grad, g["rpn_g/" + n], float(g["rpn_gn/" + n]), n, tight)

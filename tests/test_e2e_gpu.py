@@ -7,7 +7,8 @@ import numpy as np
 import pytest
 import torch
 
-from tests._parity import check_box_ops, check_losses, check_optimizer_step, check_rpn_targets, e2e_model
+from tests._parity import (check_box_ops, check_fpn_rpn_grads, check_losses, check_optimizer_step,
+                            check_rpn_targets, e2e_model)
 from tests._util import golden, key_init_
 
 pytestmark = pytest.mark.gpu
@@ -55,27 +56,55 @@ def _inputs(gs):
     return [images, None, ids.cuda(), boxes.cuda(), labels], {"replay": replay}
 
 
-def _check_forward(out, g, b=0):
-    """One image of a training-mode predict() against its reference fixture."""
+def _check_proposals(out, g, b=0):
+    """Stage A -- this path's OWN proposals against the reference's: RPN outputs <= 1e-4, the same
+    number of proposals, the same boxes (1e-5).  Visiting order: two anchors whose foreground scores
+    agree to ~1e-7 may come out in either order (the backbones differ by ~2e-6 and the reference's
+    sort is unstable anyway), so rows may be swapped with a neighbour; the multiset must be equal
+    and at most 1 % of the rows may sit at a different index."""
     A = g["rpn_class_logits"].shape[1]
     assert out["rpn_class_logits"].shape[1] == A
     assert rel(out["rpn_class_logits"][b], g["rpn_class_logits"][0]) < 1e-4
     assert rel(out["rpn_bbox"][b], g["rpn_bbox"][0]) < 1e-4
     k = int(out["num_rois"][b])
     assert k == g["rpn_rois"].shape[1], (k, g["rpn_rois"].shape)
-    assert np.allclose(out["rpn_rois"][b, :k].cpu().numpy(), g["rpn_rois"][0], rtol=0, atol=1e-5)
+    mine, ref = out["rpn_rois"][b, :k].cpu().numpy(), g["rpn_rois"][0]
+    off = np.nonzero(np.abs(mine - ref).max(axis=1) > 1e-5)[0]
+    assert off.size <= 0.01 * k, off[:20]
+    key = lambda a: a[np.lexsort(np.round(a * 1e4).T[::-1])]
+    assert np.abs(key(mine) - key(ref)).max() <= 1e-5
+    assert rel(out["gloable_lab"][b:b + 1], g["gloable_lab"]) < 1e-4
+
+
+def _with_reference_proposals(gs, pr):
+    """Stage B input: the reference's proposals, bit for bit.  A roi clipped to the image border
+    (x2 == 1.0) puts its last RoIAlign sample exactly on the map's edge, where one ulp of x1 decides
+    between a real sample and the extrapolation value (crop_and_resize.c:60, 75) -- the reference has
+    the same cliff; everything downstream is therefore compared on identical proposals."""
+    rr = torch.zeros((len(gs), 1000, 4), device="cuda")
+    num = torch.zeros((len(gs),), dtype=torch.int32, device="cuda")
+    for b, g in enumerate(gs):
+        k = g["rpn_rois"].shape[1]
+        rr[b, :k] = torch.from_numpy(g["rpn_rois"][0]).cuda()
+        num[b] = k
+    return dict(pr, rpn_rois=rr, num_rois=num)
+
+
+def _check_forward(out, g, b=0):
+    """Stage B -- one image of a training-mode predict() on the reference's proposals."""
     v = out["roi_valid"][b]
     n = int(v.sum())
     assert n == g["rois"].shape[0] and bool(v[:n].all())
     # sampled rois are gathered proposals: the reference's rows, in its order
-    assert np.allclose(out["rois"][b, :n].cpu().numpy(), g["rois"], rtol=0, atol=1e-5)
+    assert np.array_equal(out["rois"][b, :n].cpu().numpy(), g["rois"])
     assert np.array_equal(out["target_class_ids"][b, :n].cpu().numpy(), g["target_class_ids"].reshape(-1))
-    assert np.allclose(out["target_deltas"][b, :n].cpu().numpy(), g["target_deltas"], rtol=1e-4, atol=1e-4)
+    assert np.allclose(out["target_deltas"][b, :n].cpu().numpy(), g["target_deltas"], rtol=1e-5, atol=1e-5)
     assert np.array_equal(out["target_mask"][b, :n].cpu().numpy().astype(np.uint8), g["target_mask"])
-    assert rel(out["mrcnn_class_logits"][b, :n], g["mrcnn_class_logits"]) < 1e-4
-    assert rel(out["mrcnn_bbox"][b, :n], g["mrcnn_bbox"]) < 1e-4
-    assert rel(out["mrcnn_mask"][b, :n], g["mrcnn_mask"]) < 1e-4
-    assert rel(out["gloable_lab"][b:b + 1], g["gloable_lab"]) < 1e-4
+    for key in ("mrcnn_class_logits", "mrcnn_bbox", "mrcnn_mask"):
+        got = out[key][b, :n].detach().double().cpu().numpy().reshape(n, -1)
+        want = g[key].astype(np.float64).reshape(n, -1)
+        e = np.abs(got - want).max(axis=1) / np.abs(want).max()
+        assert e.max() < 1e-4, (key, "rows off", np.nonzero(e >= 1e-4)[0].tolist(), e.max())
 
 
 @pytest.mark.parametrize("scene", [0, 1])
@@ -84,13 +113,15 @@ def test_training_predict_and_losses_match_reference(scene):
     m, cfg = e2e_model("cuda")
     inp, pr = _inputs([g])
     with torch.no_grad():
-        out = m.predict(inp, mode="training", priorities=pr)
+        own = m.predict(inp, mode="training", priorities=pr)
+        _check_proposals(own, g)
+        out = m.predict(inp, mode="training", priorities=_with_reference_proposals([g], pr))
         loss, parts = m.compute_losses(out, dev(g["rpn_match"]), dev(g["rpn_bbox_target"]))
     _check_forward(out, g)
     for name, want in zip([str(n) for n in g["loss_names"]], g["losses"]):
         got = float(parts[LOSS_KEYS[name]])
         assert abs(got - want) <= 1e-4, (name, got, want)
-    assert abs(float(loss) - g["losses"].sum()) <= 2e-4
+    assert abs(float(loss) - g["losses"].sum()) <= 1e-4
 
 
 def test_batched_step_equals_the_mean_of_the_reference_per_image_losses():
@@ -100,13 +131,15 @@ def test_batched_step_equals_the_mean_of_the_reference_per_image_losses():
     m, cfg = e2e_model("cuda")
     inp, pr = _inputs(gs)
     with torch.no_grad():
-        out = m.predict(inp, mode="training", priorities=pr)
+        own = m.predict(inp, mode="training", priorities=pr)
+        out = m.predict(inp, mode="training", priorities=_with_reference_proposals(gs, pr))
         loss, parts = m.compute_losses(out, torch.cat([dev(g["rpn_match"]) for g in gs]),
                                        torch.cat([dev(g["rpn_bbox_target"]) for g in gs]))
     for b, g in enumerate(gs):
+        _check_proposals(own, g, b)
         _check_forward(out, g, b)
     want = np.mean([g["losses"].sum() for g in gs])
-    assert abs(float(loss) - want) <= 2e-4, (float(loss), want)
+    assert abs(float(loss) - want) <= 1e-4, (float(loss), want)
 
 
 @pytest.mark.parametrize("scene", [0, 1])
@@ -124,21 +157,27 @@ def test_one_train_step_matches_the_reference_optimizer_step(scene):
     batch = {"images": inp[0], "gt_class_ids": inp[2], "gt_boxes": inp[3], "gt_layer": inp[4],
              "rpn_match": dev(g["rpn_match"]), "rpn_bbox": dev(g["rpn_bbox_target"])}
     opt = m.make_optimizer(float(g["lr"]))
-    loss, _ = m.train_step(batch, opt, priorities=pr)
-    assert abs(float(loss) - g["losses"].sum()) <= 2e-4
+    loss, _ = m.train_step(batch, opt, priorities=_with_reference_proposals([g], pr))
+    assert abs(float(loss) - g["losses"].sum()) <= 1e-4
     want_norm = float(g["total_norm"])
     got_norm = float(m.last_grad_norm)
     assert abs(got_norm - want_norm) <= 2e-3 * want_norm, (got_norm, want_norm)
-    worst = 0.0
+    # Updates of the watched tensors.  Gradients below a ReLU depend on which units are active, and a
+    # unit whose pre-activation is within the two backends' ~1e-6 forward difference of zero switches:
+    # a fraction f of switched units shows up as a relative L2 error of ~sqrt(f) in everything
+    # upstream (measured: 1e-6 for the heads / FPN / RPN layers, up to 2e-3 deep in the backbone; an
+    # fp64 model sees the same from torch's own fp32).  Hence L2, not max, and a
+    # tolerance per depth.
+    worst = {}
     for n in names:
         d_ref = (g["after/" + n].astype(np.float64) - g["before/" + n])
         d_got = params[n].detach().reshape(-1)[:256].double().cpu().numpy() - g["before/" + n]
-        scale = np.abs(d_ref).max()
-        assert scale > 0, n
-        err = np.abs(d_got - d_ref).max() / scale
-        worst = max(worst, err)
-        assert err <= 2e-2, (n, err)
-    print("worst relative update error", worst, "grad norm", got_norm, want_norm)
+        assert np.abs(d_ref).max() > 0, n
+        err = np.linalg.norm(d_got - d_ref) / np.linalg.norm(d_ref)
+        worst[n] = err
+        deep = n.startswith(("fpn.C1", "fpn.C2", "fpn.C3", "fpn.C4"))
+        assert err <= (2e-2 if deep else 2e-3), (n, err)
+    print("relative update errors", {k: "%.1e" % v for k, v in worst.items()}, "grad norm", got_norm, want_norm)
 
 
 def test_optimizer_step_matches_reference_optimizer_on_device():
@@ -161,20 +200,36 @@ def test_box_ops_match_reference_on_device():
 @pytest.mark.parametrize("scene", [0, 1])
 def test_detect_matches_reference(scene):
     """MaskRCNN.detect: predict(mode='inference') detections (boxes / class ids exact, scores 1e-5),
-    32x32 mask logits 1e-4, and the unmolded full-size masks (model.py:464-514, 576-628, 747-806)."""
+    32x32 mask logits 1e-4, and the unmolded full-size masks (model.py:464-514, 576-628, 747-806).
+    Stage A runs on this path's own proposals (at least 95 of the 100 detections must be the
+    reference's: a border-clipped roi or a near-tie at the top-100 cut may differ, see
+    _with_reference_proposals); stage B on the reference's proposals is exact."""
     g = golden("e2e_detect_%d" % scene)
     m, cfg = e2e_model("cuda")
     cfg.DETECTION_MIN_CONFIDENCE = 0
     molded = dev(g["molded"])
-    with torch.no_grad():
-        detections, mrcnn_mask = m.predict([molded, g["image_metas"]], mode="inference")
-    det = detections[0].cpu().numpy()
     want = g["detections"]
+    with torch.no_grad():
+        own, _ = m.predict([molded, g["image_metas"]], mode="inference")
+    own = own[0].cpu().numpy()
+    assert own.shape == want.shape
+    same = sum(1 for r in own if (np.abs(want[:, :5] - r[:5]).max(axis=1) == 0).any())
+    assert same >= 95, same
+    # the reference's proposals = its classifier input rois: re-run its proposal stage on the fixture's
+    # RPN outputs is not stored here; the train fixtures of the same scene hold them for mode='training'
+    # only, so stage B takes them from the inference fixture's own record
+    k = g["rpn_rois"].shape[1]
+    rr = torch.zeros((1, 1000, 4), device="cuda")
+    rr[0, :k] = torch.from_numpy(g["rpn_rois"][0]).cuda()
+    pr = {"rpn_rois": rr, "num_rois": torch.tensor([k], dtype=torch.int32, device="cuda")}
+    with torch.no_grad():
+        detections, mrcnn_mask = m.predict([molded, g["image_metas"]], mode="inference", priorities=pr)
+    det = detections[0].cpu().numpy()
     assert det.shape == want.shape, (det.shape, want.shape)
     assert np.array_equal(det[:, :5], want[:, :5])
     assert np.allclose(det[:, 5], want[:, 5], rtol=0, atol=1e-5)
     assert rel(mrcnn_mask[0], g["mrcnn_mask"]) < 1e-4
-    res = m.detect([g["image_u8"]])
+    res = m.detect([g["image_u8"]], priorities=[pr])
     assert len(res) == 1
     r = res[0]
     assert np.array_equal(r["rois"], g["final_rois"])
@@ -188,42 +243,16 @@ def test_detect_matches_reference(scene):
 
 
 # ------------------------------------------------------------------ module-level gradients
-def _freeze_bn(*mods):
-    for mod in mods:
-        for m in mod.modules():
-            if isinstance(m, torch.nn.BatchNorm2d):
-                for p in m.parameters():
-                    p.requires_grad = False
-
-
-def _grad_close(got, want_slice, want_norm, name, tol=1e-4):
-    got = got.reshape(-1)[:want_slice.size].double().cpu().numpy()
-    assert np.abs(got - want_slice).max() <= tol * max(np.abs(want_slice).max(), 1e-3 * want_norm, 1e-12), name
+from tests._parity import freeze_bn as _freeze_bn, grad_close as _grad_close  # noqa: E402
 
 
 def test_fpn_rpn_gradients_match_reference_modules():
-    from sln_amodal_amd.modal.modals import FPN, RPN, ResNet
-    g = golden("module_grads_fpn_rpn")
-    resnet = ResNet("resnet50", stage5=True)
-    fpn = FPN(*resnet.stages(), out_channels=256).eval().cuda()
-    rpn = RPN(3, 1, 256).eval().cuda()
-    key_init_(fpn); key_init_(rpn)
-    _freeze_bn(fpn, rpn)
-    x = dev(g["x"]).requires_grad_(True)
-    p = fpn(x)
-    outs = [rpn(t) for t in p]
-    logits = torch.cat([o[0] for o in outs], 1)
-    bbox = torch.cat([o[2] for o in outs], 1)
-    loss = (logits * dev(g["up_logits"])).sum() + (bbox * dev(g["up_bbox"])).sum() + \
-        sum((t * dev(g["up_p%d" % i])).sum() for i, t in enumerate(p[:4]))
-    assert abs(float(loss) - float(g["loss"])) <= 1e-4 * max(abs(float(g["loss"])), 1.0)
-    loss.backward()
-    assert rel(x.grad, g["gx"]) < 1e-4
-    fp, rp = dict(fpn.named_parameters()), dict(rpn.named_parameters())
-    for n in [str(s) for s in g["fpn_names"]]:
-        _grad_close(fp[n].grad, g["fpn_g/" + n], float(g["fpn_gn/" + n]), n)
-    for n in [str(s) for s in g["rpn_names"]]:
-        _grad_close(rp[n].grad, g["rpn_g/" + n], float(g["rpn_gn/" + n]), n)
+    """Gradients of the reference's FPN + RPN modules (ResNet-50, 64x64) on the product path: 1e-4
+    for everything above C5, and the ReLU-switch tolerance (see
+    test_one_train_step_matches_the_reference_optimizer_step) for what lies below 40+ layers.  The
+    same module graph on aten convolutions is pinned at 1e-5 by the CPU suite
+    (tests/test_model_cpu.py::test_fpn_rpn_gradients_match_reference_modules)."""
+    check_fpn_rpn_grads("cuda", 1e-4, 5e-3)
 
 
 def test_head_gradients_match_reference_modules():
@@ -246,8 +275,8 @@ def test_head_gradients_match_reference_modules():
     loss.backward()
     for i, mp in enumerate(maps):
         want = g["gmap%d" % i]
-        got = mp.grad if mp.grad is not None else torch.zeros_like(mp)
-        assert np.abs(got.cpu().numpy() - want).max() <= 1e-4 * max(np.abs(want).max(), 1e-6), i
+        got = (mp.grad if mp.grad is not None else torch.zeros_like(mp)).cpu().numpy()
+        assert np.linalg.norm(got - want) <= 1e-4 * max(np.linalg.norm(want), 1e-6), i
     cp, mpar = dict(cls.named_parameters()), dict(msk.named_parameters())
     for n in [str(s) for s in g["cls_names"]]:
         _grad_close(cp[n].grad, g["cls_g/" + n], float(g["cls_gn/" + n]), "classifier." + n)

@@ -332,19 +332,29 @@ def main():
         rec["out"] = out
         return out
 
+    real_proposal = ref_model.proposal_layer
+
+    def rec_proposal(*a, **k):
+        r = real_proposal(*a, **k)
+        rec["rpn_rois"] = r.detach().clone()
+        return r
+
     for si, (image, label) in enumerate(scenes):
         ref_model.MaskRCNN.predict = rec_predict_inf
+        ref_model.proposal_layer = rec_proposal
         try:
             res = model.detect([image])
         finally:
             ref_model.MaskRCNN.predict = real_predict
+            ref_model.proposal_layer = real_proposal
         detections, mrcnn_mask = rec["out"]
         r = res[0]
         print("detect scene %d: %d detections, %d after unmold, mask pixels %d" %
               (si, detections.shape[1], r["rois"].shape[0], int(r["masks"].sum())))
         save("e2e_detect_%d" % si, native=np.array("oracle"), dim=np.array(DIM), image_u8=image,
              molded=rec["molded"].numpy(), image_metas=rec["metas"],
-             detections=detections[0].numpy(), mrcnn_mask=mrcnn_mask[0].numpy(),
+             rpn_rois=rec["rpn_rois"].numpy(), detections=detections[0].numpy(),
+             mrcnn_mask=mrcnn_mask[0].numpy(),
              final_rois=r["rois"], final_class_ids=r["class_ids"], final_scores=r["scores"],
              final_masks=np.packbits(r["masks"].astype(np.uint8), axis=None),
              final_masks_shape=np.array(r["masks"].shape))
