@@ -168,8 +168,8 @@ int sln_pyramid_crop_bwd_f32(const float *grads, int g_cstride, int g_coffset, c
  * matrix cores with split-bf16 operands (fp32-class accuracy, see csrc/conv.hip).
  * Replaces the cuDNN calls behind nn.Conv2d (+ the separate BatchNorm / ReLU /
  * residual-add / F.pad passes around them) on the reference's path.
- * All activations are NHWC = [pixels][channels]; `parts` = 2 or 3 bf16 parts per
- * fp32 value; "*_pad" channel counts are multiples of 8 (zero filled).
+ * All activations are NHWC = [pixels][channels]; `parts` = 3 bf16 or 2 scaled fp16 parts per
+ * fp32 value (see "Operand formats" below); "*_pad" channel counts are multiples of 8 (zero filled).
  *
  * sln_conv_split_weights_f32  fp32 weights with element strides (s_o,s_i,s_kh,s_kw)
  *     -> out [parts][O][KH][KW][I_pad] bf16.  flip=1 mirrors the taps (data grad).
@@ -203,26 +203,50 @@ int sln_pyramid_crop_bwd_f32(const float *grads, int g_cstride, int g_coffset, c
  * sln_conv2d_wgrad_f32        gw [Cout][KH][KW][Cin] fp32 (zeroed by the callee) =
  *     sum over output pixels of gz[pix][co] * x[pix @ tap][ci]; split-K over pixel
  *     ranges with fp32 atomics (summation order not deterministic).
+ *
+ * Operand formats.  parts = 3: three bf16 parts per fp32 value, six part products per
+ * fp32 product.  parts = 2 ("scaled split-fp16"): two fp16 parts of v*s, s a per-tensor
+ * power of two, three part products (22-bit operands: the accuracy of fp32 at half the
+ * matrix work).  Every function that WRITES parts takes the tensor's scaling record
+ *     q_scale      device scalar s (NULL = 1): the parts encode v*s
+ *     q_amax       device scalar (optional): atomic running max |v| of what was split --
+ *                  the input of sln_scale_update_f32, which derives the scale the same
+ *                  tensor will use the next time it is produced (delayed scaling)
+ *     q_saturated  device counter (optional): += number of blocks that had to clamp an
+ *                  element to +-65504 (never inf: a stale scale costs accuracy, not NaNs)
+ * and with a NULL output pointer only takes the amax (first use of a tensor, before it has
+ * a scale); every function that READS parts takes its operands' scales (device scalars,
+ * NULL = 1) and divides them out of the accumulator -- exactly, powers of two.
+ * parts = 3 ignores all of these (pass NULL).
+ * sln_scale_update_f32        scale[i] <- 2^k with amax[i]*2^k in [2^(t-1), 2^t),
+ *     t = target_log2 (11 on the path); amax[i] == 0 keeps scale[i]; amax[i] <- 0.
  * ------------------------------------------------------------------------- */
 int sln_conv_split_weights_f32(const float *w, int O, int I, int I_pad, int KH, int KW, long s_o,
                                long s_i, long s_kh, long s_kw, int flip, int parts, uint16_t *out,
+                               const float *q_scale, float *q_amax, int32_t *q_saturated,
                                sln_stream_t stream);
 int sln_act_split_f32(const float *x, int64_t M, int C, int C_pad, int parts, uint16_t *out,
-                      sln_stream_t stream);
+                      const float *q_scale, float *q_amax, int32_t *q_saturated, sln_stream_t stream);
 int sln_conv_grad_prep_f32(const float *gy, const float *y, const float *scale, int64_t M, int C,
                            int C_pad, int parts, float *gu, uint16_t *gz_parts, float *gbias,
+                           const float *q_scale, float *q_amax, int32_t *q_saturated,
                            sln_stream_t stream);
+int sln_scale_update_f32(float *amax, float *scale, int n, int target_log2, sln_stream_t stream);
 int sln_conv2d_fwd_f32(const uint16_t *x_parts, int N, int H, int W, int Cin,
                        const uint16_t *w_parts, int parts, int Cout, int KH, int KW, int stride_h,
                        int stride_w, int dil_h, int dil_w, int pad_top, int pad_left, int OH, int OW,
                        const float *scale, const float *shift, const float *residual, int relu,
-                       float *y, uint16_t *y_parts, sln_stream_t stream);
+                       float *y, uint16_t *y_parts, const float *x_scale, const float *w_scale,
+                       const float *y_q_scale, float *y_q_amax, int32_t *y_q_saturated,
+                       sln_stream_t stream);
 int sln_conv2d_fwd_ms_f32(const uint16_t *x_parts, int nseg, const int32_t *seg_nhw, int Cin,
                           const uint16_t *w_parts, int parts, int Cout, int KH, int KW, int stride_h,
                           int stride_w, int dil_h, int dil_w, int pad_top, int pad_left, int pad_bottom,
                           int pad_right, const float *scale, const float *shift, const float *residual,
                           int relu, const float *mask, const float *post_scale, float *y,
-                          uint16_t *y_parts, float *colsum, sln_stream_t stream);
+                          uint16_t *y_parts, float *colsum, const float *x_scale,
+                          const float *w_scale, const float *y_q_scale, float *y_q_amax,
+                          int32_t *y_q_saturated, sln_stream_t stream);
 /* Tile edge (128 or 256) of the forward kernel the two functions above use for M output pixels,
  * Cout channels, K = KH*KW*Cin and `parts`: host-side rule, no GPU work (csrc/conv.hip). */
 int sln_conv_fwd_tile(int64_t M, int Cout, int64_t K, int parts);
@@ -231,7 +255,8 @@ int sln_conv_wgrad_tile(int64_t M, int Cout, int Cin, int taps, int parts);
 int sln_conv2d_wgrad_f32(const uint16_t *gz_parts, int Cout, int Cout_pad, const uint16_t *x_parts,
                          int N, int H, int W, int Cin, int Cin_pad, int parts, int KH, int KW,
                          int stride_h, int stride_w, int dil_h, int dil_w, int pad_top, int pad_left,
-                         int OH, int OW, float *gw, sln_stream_t stream);
+                         int OH, int OW, float *gw, const float *gz_scale, const float *x_scale,
+                         sln_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -32,17 +32,18 @@ SIGNATURES = {
     "sln_pyramid_crop_bwd_f32": (_i, [_p, _i, _i, _p, _p, _p, _i, _i, _i, _i, _i, C.POINTER(_p),
                                       C.POINTER(_i), _p]),
     "sln_conv_split_weights_f32": (_i, [_p, _i, _i, _i, _i, _i, C.c_long, C.c_long, C.c_long,
-                                        C.c_long, _i, _i, _p, _p]),
-    "sln_act_split_f32": (_i, [_p, C.c_int64, _i, _i, _i, _p, _p]),
-    "sln_conv_grad_prep_f32": (_i, [_p, _p, _p, C.c_int64, _i, _i, _i, _p, _p, _p, _p]),
+                                        C.c_long, _i, _i, _p, _p, _p, _p, _p]),
+    "sln_act_split_f32": (_i, [_p, C.c_int64, _i, _i, _i, _p, _p, _p, _p, _p]),
+    "sln_conv_grad_prep_f32": (_i, [_p, _p, _p, C.c_int64, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
+    "sln_scale_update_f32": (_i, [_p, _p, _i, _i, _p]),
     "sln_conv2d_fwd_f32": (_i, [_p, _i, _i, _i, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
-                                _i, _p, _p, _p, _i, _p, _p, _p]),
+                                _i, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
     "sln_conv2d_fwd_ms_f32": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
-                                   _p, _p, _p, _i, _p, _p, _p, _p, _p, _p]),
+                                   _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "sln_conv_fwd_tile": (_i, [C.c_int64, _i, C.c_int64, _i]),
     "sln_conv_wgrad_tile": (_i, [C.c_int64, _i, _i, _i, _i]),
     "sln_conv2d_wgrad_f32": (_i, [_p, _i, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
-                                  _i, _i, _i, _i, _p, _p]),
+                                  _i, _i, _i, _i, _p, _p, _p, _p]),
 }
 
 

@@ -6,14 +6,21 @@ backward:   gy --grad_prep(ReLU mask, BN scale, bias grad)--> gzparts
                  1x1: lattice scatter)
             gw = conv_wgrad(gzparts, xparts)
 Everything runs in libsln_amodal_hip.so; torch only owns the buffers.
+
+Operand formats (csrc/conv.hip): PARTS = 3 -> three bf16 parts, six matrix products per fp32
+product; PARTS = 2 -> two fp16 parts of v*s with a per-tensor power-of-two scale s, three products.
+The scales live on the device (ScaleBook): every tensor role of every layer owns a slot
+(scale, running amax); a producer splits with the scale derived from the amax the same tensor had
+the last time it was produced, and records the new amax -- no host round trip.  The first time a
+slot is used it is bootstrapped exactly (an amax pass, then the split).
 """
+import os
+
 import torch
 
 from . import _lib, ops
 
-import os
-
-# 3 = fp32-class accuracy (6 MFMA products); 2 = ~4e-6 per layer (3 products)
+# 3 = three bf16 parts (6 MFMA products); 2 = two scaled fp16 parts (3 products)
 PARTS = int(os.environ.get("SLN_CONV_PARTS", "3"))
 # parts used while autograd is disabled (the frozen GLM, inference): None = same as PARTS
 PARTS_NOGRAD = int(os.environ["SLN_CONV_PARTS_NOGRAD"]) if os.environ.get("SLN_CONV_PARTS_NOGRAD") else None
@@ -30,6 +37,89 @@ FUSE_OUTPUT_SPLIT = True   # conv epilogue writes the output's parts (skips the 
 _cache = _NoCache()   # kept for tools that call _cache.clear(); caches live on the tensors
 
 
+# ------------------------------------------------------------------ per-tensor scales (PARTS = 2)
+SCALE_TARGET_LOG2 = 11      # max|v| * s lands in [2^10, 2^11): 2^5 of head room below fp16's 65504
+
+
+class _Slot(object):
+    """One tensor role of one layer: views of its device-side scale / running amax."""
+    __slots__ = ("scale", "amax", "fresh", "book")
+
+    def __init__(self, book, idx):
+        self.book = book
+        self.scale = book.scale[idx:idx + 1]
+        self.amax = book.amax[idx:idx + 1]
+        self.fresh = True            # no scale yet: the first producer bootstraps it from an amax pass
+
+
+class ScaleBook(object):
+    def __init__(self, device, capacity=1 << 15):
+        self.device = device
+        self.amax = torch.zeros(capacity, dtype=torch.float32, device=device)
+        self.scale = torch.ones(capacity, dtype=torch.float32, device=device)
+        self.saturated = torch.zeros(1, dtype=torch.int32, device=device)
+        self.n = 0
+
+    def new_slot(self):
+        if self.n >= self.amax.numel():
+            raise RuntimeError("ScaleBook is full (%d tensor slots)" % self.n)
+        self.n += 1
+        return _Slot(self, self.n - 1)
+
+    def update(self):
+        """Delayed scaling: every slot's next scale from the amax it recorded since the last call."""
+        if self.n:
+            _lib.check(_lib.lib().sln_scale_update_f32(ops._ptr(self.amax), ops._ptr(self.scale), self.n,
+                                                       SCALE_TARGET_LOG2, ops._stream()), "sln_scale_update_f32")
+
+    def settle(self, slot):
+        """Bootstrap: slot.amax holds an exact amax pass -> its scale; clears the fresh flag."""
+        _lib.check(_lib.lib().sln_scale_update_f32(ops._ptr(slot.amax), ops._ptr(slot.scale), 1,
+                                                   SCALE_TARGET_LOG2, ops._stream()), "sln_scale_update_f32")
+        slot.fresh = False
+
+
+_books = {}
+
+
+def book(device):
+    b = _books.get(device.index)
+    if b is None:
+        b = _books[device.index] = ScaleBook(device)
+    return b
+
+
+def update_scales():
+    """Call once per step (MaskRCNN.predict does): scales follow the previous step's amax."""
+    for b in _books.values():
+        b.update()
+
+
+def saturation_count():
+    """Blocks that clamped a value to +-65504 since the start (host sync; tests / monitoring)."""
+    return sum(int(b.saturated.item()) for b in _books.values())
+
+
+def _slot(owner, key):
+    """The scale slot of tensor role `key` of the layer identified by `owner` (its weight Parameter:
+    the slot lives on the object, so it dies with the layer)."""
+    slots = getattr(owner, "_sln_slots", None)
+    if slots is None:
+        slots = {}
+        owner._sln_slots = slots
+    sl = slots.get(key)
+    if sl is None:
+        sl = slots[key] = book(owner.device).new_slot()
+    return sl
+
+
+def _q3(slot):
+    """(q_scale, q_amax, q_saturated) pointer triple of a slot (NULLs without one)."""
+    if slot is None:
+        return None, None, None
+    return ops._ptr(slot.scale), ops._ptr(slot.amax), ops._ptr(slot.book.saturated)
+
+
 def supports(conv, x):
     """The 3-channel stems (K = 7*7*3) stay on aten: padded to 8 channels the implicit
     GEMM wastes 5/8 of K and, in the weight gradient, 125/128 of the N tile."""
@@ -41,10 +131,10 @@ def _pad8(c):
     return (c + 7) // 8 * 8
 
 
-def _split_weights(weight, flip_swap=False, parts=None):
-    """[parts][O][KH][KW][I_pad] bf16.  Cached on the tensor object itself (keyed by its
-    version counter), so the cache dies with the tensor and can never alias a new
-    tensor that happens to reuse the address."""
+def _split_weights(weight, flip_swap=False, parts=None, owner=None):
+    """-> (wparts [parts][O][KH][KW][I_pad], scale tensor or None).  Cached on the tensor object
+    itself (keyed by its version counter), so the cache dies with the tensor and can never alias a
+    new tensor that happens to reuse the address."""
     parts = parts or PARTS
     cache = getattr(weight, "_sln_wparts", None)
     if cache is None:
@@ -55,7 +145,7 @@ def _split_weights(weight, flip_swap=False, parts=None):
             pass
     hit = cache.get((flip_swap, parts))
     if hit is not None and hit[0] == weight._version:
-        return hit[1]
+        return hit[1], hit[2]
     w = weight.detach()
     Co, Ci, KH, KW = w.shape
     s = w.stride()
@@ -65,11 +155,19 @@ def _split_weights(weight, flip_swap=False, parts=None):
         O, I, so, si = Co, Ci, s[0], s[1]
     Ip = _pad8(I)
     out = torch.empty((parts, O, KH, KW, Ip), dtype=torch.bfloat16, device=w.device)
-    _lib.check(_lib.lib().sln_conv_split_weights_f32(
-        ops._ptr(w), O, I, Ip, KH, KW, so, si, s[2], s[3], 1 if flip_swap else 0, parts,
-        ops._ptr(out), ops._stream()), "sln_conv_split_weights_f32")
-    cache[(flip_swap, parts)] = (weight._version, out)
-    return out
+    slot = _slot(owner if owner is not None else weight, ("w",)) if parts == 2 else None
+
+    def launch(dst):
+        _lib.check(_lib.lib().sln_conv_split_weights_f32(
+            ops._ptr(w), O, I, Ip, KH, KW, so, si, s[2], s[3], 1 if flip_swap else 0, parts,
+            ops._ptr(dst), *_q3(slot), ops._stream()), "sln_conv_split_weights_f32")
+    if slot is not None and slot.fresh:
+        launch(None)
+        slot.book.settle(slot)
+    launch(out)
+    q = slot.scale if slot is not None else None
+    cache[(flip_swap, parts)] = (weight._version, out, q)
+    return out, q
 
 
 _split = _split_weights
@@ -82,25 +180,42 @@ def _nhwc(t):
     return t.contiguous(memory_format=torch.channels_last)
 
 
-def act_parts(x, parts=None):
-    """x logical [N,C,H,W] (NHWC in memory) -> bf16 parts [P, N*H*W, C_pad].  Cached on
-    the tensor object: one activation often feeds several convs (block input ->
-    conv1 + downsample, ASPP's four branches, the P-maps -> RPN + heads)."""
+def _act_split(xc2d, M, C, parts, slot):
+    """fp32 [M, C] -> parts [P, M, C_pad]; bootstraps a fresh slot with an amax pass."""
+    Cp = _pad8(C)
+    out = torch.empty((parts, M, Cp), dtype=torch.bfloat16, device=xc2d.device)
+
+    def launch(dst):
+        _lib.check(_lib.lib().sln_act_split_f32(ops._ptr(xc2d), M, C, Cp, parts, ops._ptr(dst), *_q3(slot),
+                                                ops._stream()), "sln_act_split_f32")
+    if slot is not None and slot.fresh:
+        launch(None)
+        slot.book.settle(slot)
+    launch(out)
+    return out
+
+
+def act_parts(x, parts=None, owner=None, key=None):
+    """x logical [N,C,H,W] (NHWC in memory) -> (parts [P, N*H*W, C_pad], scale or None).  Cached on
+    the tensor object: one activation often feeds several convs (block input -> conv1 +
+    downsample, ASPP's four branches, the P-maps -> RPN + heads).  owner / key: the consuming layer's
+    scale slot for this input (PARTS = 2; the first consumer's slot serves the others)."""
     parts = parts or PARTS
     hit = getattr(x, "_sln_parts", None)
     if hit is not None and hit[0] == (x._version, parts):
-        return hit[1]
+        return hit[1], hit[2]
     xc = _nhwc(x.detach())
     N, C, H, W = xc.shape
-    Cp = _pad8(C)
-    out = torch.empty((parts, N * H * W, Cp), dtype=torch.bfloat16, device=x.device)
-    _lib.check(_lib.lib().sln_act_split_f32(ops._ptr(xc), N * H * W, C, Cp, parts, ops._ptr(out),
-                                            ops._stream()), "sln_act_split_f32")
+    slot = None
+    if parts == 2:
+        slot = _slot(owner if owner is not None else x, ("x",) + tuple(key or (H, W)))
+    out = _act_split(xc, N * H * W, C, parts, slot)
+    q = slot.scale if slot is not None else None
     try:
-        x._sln_parts = ((x._version, parts), out)
+        x._sln_parts = ((x._version, parts), out, q)
     except Exception:
         pass
-    return out
+    return out, q
 
 
 # bench.py sets this to a list to collect (start_event, end_event, flops, kernel) per
@@ -138,33 +253,48 @@ def _nbytes(*tensors):
 
 
 def _fwd(xparts, N, H, W, wparts, Cout, KH, KW, stride, dil, pt, pl, OH, OW, scale, shift, residual,
-         relu, cin=None, out_parts=False, mask=None, want_y=True, want_colsum=False, post_scale=None):
-    """One launch of conv_fwd_kernel.  mask / want_y=False / want_colsum: the epilogue extras of
+         relu, cin=None, out_parts=False, mask=None, want_y=True, want_colsum=False, post_scale=None,
+         xq=None, wq=None, yslot=None):
+    """One launch of the forward kernel.  mask / want_y=False / want_colsum: the epilogue extras of
     sln_conv2d_fwd_ms_f32 (a data gradient that is consumed only as the previous layer's
-    prepared gradient).  Returns y, or (y_or_None, parts, colsum) when any extra is used."""
+    prepared gradient).  xq / wq: the operands' scale tensors (PARTS = 2); yslot: the scale slot of
+    the output's own parts.  Returns y, or (y_or_None, parts, colsum) when any extra is used; the
+    parts' scale is yslot.scale."""
     import ctypes as C
     dev = xparts.device
+    P = wparts.shape[0]
     y = torch.empty((N, OH, OW, Cout), dtype=torch.float32, device=dev).permute(0, 3, 1, 2) if want_y else None
+    plain = mask is None and want_y and not want_colsum and post_scale is None
+    if out_parts and P == 2:
+        if yslot is None:
+            raise RuntimeError("two-part output split needs a scale slot")
+        if yslot.fresh and not plain:
+            raise RuntimeError("chained gradient preparation on a tensor without a scale (the chain "
+                               "must stay off until its slot has been bootstrapped)")
+    fresh = out_parts and P == 2 and yslot.fresh
     yp = None
-    if out_parts:   # the epilogue also emits the output's bf16 parts (next layer's operand)
+    if out_parts and not fresh:   # the epilogue also emits the output's parts (next layer's operand)
         alloc = torch.empty if Cout % 8 == 0 else torch.zeros   # pad channels must be zero
-        yp = alloc((wparts.shape[0], N * OH * OW, _pad8(Cout)), dtype=torch.bfloat16, device=dev)
+        yp = alloc((P, N * OH * OW, _pad8(Cout)), dtype=torch.bfloat16, device=dev)
     cs = torch.empty((Cout,), dtype=torch.float32, device=dev) if want_colsum else None
     pb = (OH - 1) * stride[0] + dil[0] * (KH - 1) + 1 - H - pt
     pr = (OW - 1) * stride[1] + dil[1] * (KW - 1) + 1 - W - pl
     seg = (C.c_int32 * 3)(N, H, W)
     e0 = _prof_begin()
     _lib.check(_lib.lib().sln_conv2d_fwd_ms_f32(
-        ops._ptr(xparts), 1, seg, xparts.shape[2], ops._ptr(wparts), wparts.shape[0], Cout, KH, KW,
+        ops._ptr(xparts), 1, seg, xparts.shape[2], ops._ptr(wparts), P, Cout, KH, KW,
         stride[0], stride[1], dil[0], dil[1], pt, pl, pb, pr, ops._ptr(scale), ops._ptr(shift),
         ops._ptr(residual), 1 if relu else 0, ops._ptr(mask), ops._ptr(post_scale), ops._ptr(y),
-        ops._ptr(yp), ops._ptr(cs), ops._stream()), "sln_conv2d_fwd_ms_f32")
-    if yp is not None and y is not None and post_scale is None:
-        y._sln_parts = ((y._version, wparts.shape[0]), yp)
+        ops._ptr(yp), ops._ptr(cs), ops._ptr(xq), ops._ptr(wq), *_q3(yslot if yp is not None and P == 2 else None),
+        ops._stream()), "sln_conv2d_fwd_ms_f32")
     _prof_end(e0, 2.0 * N * OH * OW * Cout * KH * KW * (cin or wparts.shape[4]),
-              _fwd_kernel_name(N * OH * OW, Cout, KH * KW * xparts.shape[2], wparts.shape[0]),
+              _fwd_kernel_name(N * OH * OW, Cout, KH * KW * xparts.shape[2], P),
               "fwd N%d %dx%d C%d->%d k%d s%d d%d" % (N, H, W, cin or wparts.shape[4], Cout, KH, stride[0], dil[0]),
               _nbytes(xparts, wparts, residual, mask), _nbytes(y, yp))
+    if fresh:   # first use of this output's slot: exact amax pass over y, then the split
+        yp = _act_split(_nhwc(y), N * OH * OW, Cout, P, yslot)
+    if yp is not None and y is not None and post_scale is None:
+        y._sln_parts = ((y._version, P), yp, yslot.scale if P == 2 else None)
     if mask is not None or not want_y or want_colsum:
         return y, yp, cs
     return y
@@ -197,14 +327,14 @@ class MultiScale(object):
             m += n
         return out
 
-    def get_parts(self, parts):
+    def get_parts(self, parts, owner=None):
+        """-> (parts, scale or None)."""
         if self.parts is None or self.parts.shape[0] != parts:
             M, C = self.y.shape
-            out = torch.empty((parts, M, _pad8(C)), dtype=torch.bfloat16, device=self.y.device)
-            _lib.check(_lib.lib().sln_act_split_f32(ops._ptr(self.y), M, C, _pad8(C), parts, ops._ptr(out),
-                                                    ops._stream()), "sln_act_split_f32")
-            self.parts = out
-        return self.parts
+            slot = _slot(owner, ("x_ms",) + tuple(self.segs)) if parts == 2 else None
+            self.parts = _act_split(self.y, M, C, parts, slot)
+            self.q = slot.scale if slot is not None else None
+        return self.parts, getattr(self, "q", None)
 
 
 def conv_bn_act_ms(x, conv, bn, relu, residual, pads):
@@ -233,11 +363,15 @@ def conv_bn_act_ms(x, conv, bn, relu, residual, pads):
         osegs.append((N, OH, OW))
         flops += 2.0 * N * OH * OW * Co * KH * KW * Ci
     M = sum(n * h * w for n, h, w in osegs)
-    xp = x.get_parts(parts)
-    wp = _split_weights(conv.weight, parts=parts)
+    xp, xq = x.get_parts(parts, owner=conv.weight)
+    wp, wq = _split_weights(conv.weight, parts=parts)
     y = torch.empty((M, Co), dtype=torch.float32, device=x.y.device)
-    alloc = torch.empty if Co % 8 == 0 else torch.zeros
-    yp = alloc((parts, M, _pad8(Co)), dtype=torch.bfloat16, device=x.y.device)
+    yslot = _slot(conv.weight, ("y_ms",) + tuple(osegs)) if parts == 2 else None
+    fresh = yslot is not None and yslot.fresh
+    yp = None
+    if not fresh:
+        alloc = torch.empty if Co % 8 == 0 else torch.zeros
+        yp = alloc((parts, M, _pad8(Co)), dtype=torch.bfloat16, device=x.y.device)
     seg = (C.c_int32 * (3 * len(x.segs)))(*[v for s_ in x.segs for v in s_])
     res = residual.y if residual is not None else None
     if res is not None and tuple(res.shape) != (M, Co):
@@ -246,14 +380,20 @@ def conv_bn_act_ms(x, conv, bn, relu, residual, pads):
     _lib.check(_lib.lib().sln_conv2d_fwd_ms_f32(
         ops._ptr(xp), len(x.segs), seg, xp.shape[2], ops._ptr(wp), parts, Co, KH, KW, sh, sw, dh, dw,
         pt, pl, pb, pr, ops._ptr(scale), ops._ptr(shift), ops._ptr(res), 1 if relu else 0, None, None,
-        ops._ptr(y), ops._ptr(yp), None, ops._stream()), "sln_conv2d_fwd_ms_f32")
+        ops._ptr(y), ops._ptr(yp), None, ops._ptr(xq), ops._ptr(wq),
+        *_q3(yslot if yp is not None else None), ops._stream()), "sln_conv2d_fwd_ms_f32")
     _prof_end(e0, flops, _fwd_kernel_name(M, Co, KH * KW * xp.shape[2], parts),
               "fwd ms%s C%d->%d k%d s%d d%d" % ("+".join("%dx%d" % (h, w) for _, h, w in x.segs), Ci, Co, KH, sh, dh),
               _nbytes(xp, wp, res), _nbytes(y, yp))
-    return MultiScale(osegs, y, yp)
+    if fresh:
+        yp = _act_split(y, M, Co, parts, yslot)
+    out = MultiScale(osegs, y, yp)
+    out.q = yslot.scale if yslot is not None else None
+    return out
 
 
-def _grad_prep(gy, y, scale, want_gu, want_bias, parts):
+def _grad_prep(gy, y, scale, want_gu, want_bias, parts, slot=None):
+    """-> (gz parts, gu or None, bias gradient or None); the parts' scale is slot.scale."""
     gy = _nhwc(gy)
     N, C, H, W = gy.shape
     M, Cp = N * H * W, _pad8(C)
@@ -263,17 +403,25 @@ def _grad_prep(gy, y, scale, want_gu, want_bias, parts):
     if write_gu:
         gu = torch.empty((N, H, W, C), dtype=torch.float32, device=gy.device).permute(0, 3, 1, 2)
     gb = torch.empty((C,), dtype=torch.float32, device=gy.device) if want_bias else None
-    _lib.check(_lib.lib().sln_conv_grad_prep_f32(
-        ops._ptr(gy), ops._ptr(y), ops._ptr(scale), M, C, Cp, parts,
-        ops._ptr(gu) if write_gu else None, ops._ptr(gz), ops._ptr(gb), ops._stream()),
-        "sln_conv_grad_prep_f32")
+    if parts == 2 and slot is None:
+        raise RuntimeError("two-part gradient preparation needs a scale slot")
+
+    def launch(dst):
+        _lib.check(_lib.lib().sln_conv_grad_prep_f32(
+            ops._ptr(gy), ops._ptr(y), ops._ptr(scale), M, C, Cp, parts,
+            ops._ptr(gu) if write_gu else None, ops._ptr(dst), ops._ptr(gb), *_q3(slot if parts == 2 else None),
+            ops._stream()), "sln_conv_grad_prep_f32")
+    if parts == 2 and slot.fresh:
+        launch(None)
+        slot.book.settle(slot)
+    launch(gz)
     return gz, (gu if want_gu else None), gb
 
 
 class _ConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, bn_scale, bn_shift, residual, relu, stride, dil, pads, link=None,
-                chain_in=None, chain_out=None):
+                chain_in=None, chain_out=None, owner=None):
         parts = PARTS
         if PARTS_NOGRAD and not any(ctx.needs_input_grad):
             parts = PARTS_NOGRAD
@@ -290,9 +438,15 @@ class _ConvFn(torch.autograd.Function):
         if scale is not None:
             scale = scale.detach().contiguous()
         res = _nhwc(residual.detach()) if residual is not None else None
-        xp = act_parts(x, parts)
-        y = _fwd(xp, N, H, W, _split_weights(weight, parts=parts), Co, KH, KW, stride, dil, pt, pl,
-                 OH, OW, scale, shift, res, relu, cin=Ci, out_parts=FUSE_OUTPUT_SPLIT)
+        # scale slots (PARTS = 2) live on the layer's persistent weight object: `owner` when the weight
+        # passed in is a temporary view of it (Linear / deconv reshapes)
+        own = owner if owner is not None else weight
+        xp, xq = act_parts(x, parts, owner=own)
+        wp, wq = _split_weights(weight, parts=parts, owner=own)
+        yslot = _slot(own, ("y", OH, OW)) if (parts == 2 and FUSE_OUTPUT_SPLIT) else None
+        gzslot = _slot(own, ("gz", OH, OW)) if parts == 2 else None
+        y = _fwd(xp, N, H, W, wp, Co, KH, KW, stride, dil, pt, pl, OH, OW, scale, shift, res, relu, cin=Ci,
+                 out_parts=FUSE_OUTPUT_SPLIT, xq=xq, wq=wq, yslot=yslot)
         need_w = ctx.needs_input_grad[1]
         # identity-shortcut link (Bottleneck.forward): the conv that consumes x (head) and the
         # conv that adds the same x as its residual (tail) share a dict, so that the tail's
@@ -316,10 +470,12 @@ class _ConvFn(torch.autograd.Function):
         # the masked fp32 gradient -- it is its shortcut's gradient -- so its reader writes that as
         # its dx and applies the BN scale to the parts only (post_scale); CHAIN_BLOCK_OUTPUT.
         with_res = residual is not None
+        # (PARTS = 2: a reader can only prepare this layer's gradient once that gradient's scale slot
+        # has a history, i.e. from the second step on; the first step bootstraps it in _grad_prep)
         if CHAIN_GRAD_PREP and chain_out is not None and (ctx.needs_input_grad[0] or need_w) and \
-                (not with_res or (CHAIN_BLOCK_OUTPUT and relu)):
+                (not with_res or (CHAIN_BLOCK_OUTPUT and relu)) and not (parts == 2 and gzslot.fresh):
             chain_out.update(active=True, scale=scale, relu=bool(relu), parts=parts, with_res=with_res,
-                             want_bias=bool(bias is not None and ctx.needs_input_grad[2]))
+                             want_bias=bool(bias is not None and ctx.needs_input_grad[2]), gz_slot=gzslot)
             chain_out.setdefault("readers", 1)      # 2: two sibling convs read the output (RPN heads)
             if chain_out["readers"] == 2:
                 if with_res:
@@ -337,15 +493,18 @@ class _ConvFn(torch.autograd.Function):
         # (the shared dict must not hold activations: a dict -> output -> grad_fn -> ctx -> dict
         # cycle through the C++ graph would never be collected)
         mask_x = x if (ctx.chain_in is not None and chain_in["relu"]) else None
-        ctx.save_for_backward(xp if need_w else None, weight, scale, y if relu else None, mask_x)
+        ctx.save_for_backward(xp if need_w else None, weight, scale, y if relu else None, mask_x,
+                              xq if need_w else None)
         ctx.cfg = (stride, dil, pads, relu, bias is not None, residual is not None, (N, Ci, H, W),
                    parts)
         ctx.out_hw = (OH, OW)
+        ctx.own, ctx.gzslot = own, gzslot
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        xp, weight, scale, y, mask_x = ctx.saved_tensors
+        xp, weight, scale, y, mask_x, xq = ctx.saved_tensors
+        own = ctx.own
         stride, dil, pads, relu, has_bias, has_res, xshape, parts = ctx.cfg
         pt, pb, pl, pr = pads
         Co, Ci, KH, KW = weight.shape
@@ -364,6 +523,7 @@ class _ConvFn(torch.autograd.Function):
                 raise RuntimeError("chained gradient: a two-reader activation has a third consumer, or "
                                    "one of its readers did not run")
             gz, g_res = ch.pop("gz"), None
+            gzq = ch.pop("gzq", None)
             g_bias = ch.pop("gbias") if want_bias else None
             CHAIN_STATS[1] += 1
         elif ch is not None and ch.get("consumer"):
@@ -382,11 +542,13 @@ class _ConvFn(torch.autograd.Function):
                 raise RuntimeError("chained gradient: the consumer's dgrad did not run, or the "
                                    "activation has a second consumer")
             gz = ch.pop("gz")
+            gzq = ch.pop("gzq", None)
             g_res = gy if (ch["with_res"] and want_res) else None   # already masked by the reader
             g_bias = ch.pop("gbias") if want_bias else None
             CHAIN_STATS[1] += 1
         else:
-            gz, g_res, g_bias = _grad_prep(gy, y, scale, want_res, want_bias, parts)
+            gz, g_res, g_bias = _grad_prep(gy, y, scale, want_res, want_bias, parts, slot=ctx.gzslot)
+            gzq = ctx.gzslot.scale if parts == 2 else None
         if ctx.link_tail is not None and g_res is not None:
             ctx.link_tail["idgrad"] = g_res     # consumed by the head's data gradient below
             g_res = None
@@ -398,7 +560,8 @@ class _ConvFn(torch.autograd.Function):
         if id_grad is not None and not need_x:
             raise RuntimeError("identity-shortcut gradient was handed over but dx is not computed")
         if need_x:
-            wt = _split_weights(weight, flip_swap=True, parts=parts)
+            wt, wtq = _split_weights(weight, flip_swap=True, parts=parts, owner=own)
+            qs = dict(xq=gzq, wq=wtq)
             two = ctx.chain_in is not None and ctx.chain_in.get("readers") == 2
             if two and ctx.chain_in.get("consumer") != 2:
                 two = False
@@ -407,7 +570,7 @@ class _ConvFn(torch.autograd.Function):
                 # first of the two readers to run: plain fp32 data gradient, parked for the sibling
                 ctx.chain_in["partial"] = _fwd(gz, N, OH, OW, wt, Ci, KH, KW, (1, 1), dil,
                                                dil[0] * (KH - 1) - pt, dil[1] * (KW - 1) - pl, H, W, None, None,
-                                               None, False, cin=Co)
+                                               None, False, cin=Co, **qs)
                 gx = None
             elif two:
                 ci = ctx.chain_in
@@ -415,8 +578,10 @@ class _ConvFn(torch.autograd.Function):
                                        dil[1] * (KW - 1) - pl, H, W, None, None, _nhwc(ci.pop("partial")), False,
                                        cin=Co, out_parts=True,
                                        mask=_nhwc(mask_x) if mask_x is not None else None, want_y=False,
-                                       want_colsum=ci["want_bias"], post_scale=ci["scale"])
+                                       want_colsum=ci["want_bias"], post_scale=ci["scale"],
+                                       yslot=ci["gz_slot"], **qs)
                 ci["gz"], ci["gbias"] = gz_up, gb_up
+                ci["gzq"] = ci["gz_slot"].scale if parts == 2 else None
                 gx = None
                 CHAIN_STATS[0] += 1
             elif ctx.chain_in is not None and ctx.chain_in["with_res"]:
@@ -425,26 +590,29 @@ class _ConvFn(torch.autograd.Function):
                                         dil[1] * (KW - 1) - pl, H, W, None, None,
                                         _nhwc(id_grad) if id_grad is not None else None, False, cin=Co,
                                         out_parts=True, mask=_nhwc(mask_x), want_y=True,
-                                        want_colsum=ci["want_bias"], post_scale=ci["scale"])
+                                        want_colsum=ci["want_bias"], post_scale=ci["scale"],
+                                        yslot=ci["gz_slot"], **qs)
                 ci["gz"], ci["gbias"], ci["gu_ref"], ci["gu_version"] = gz_up, gb_up, gx, gx._version
+                ci["gzq"] = ci["gz_slot"].scale if parts == 2 else None
                 CHAIN_STATS[0] += 1
             elif ctx.chain_in is not None:
                 ci = ctx.chain_in
                 _, gz_up, gb_up = _fwd(gz, N, OH, OW, wt, Ci, KH, KW, (1, 1), dil, dil[0] * (KH - 1) - pt,
                                        dil[1] * (KW - 1) - pl, H, W, ci["scale"], None, None, False, cin=Co,
                                        out_parts=True, mask=_nhwc(mask_x) if mask_x is not None else None,
-                                       want_y=False, want_colsum=ci["want_bias"])
+                                       want_y=False, want_colsum=ci["want_bias"], yslot=ci["gz_slot"], **qs)
                 ci["gz"], ci["gbias"] = gz_up, gb_up
+                ci["gzq"] = ci["gz_slot"].scale if parts == 2 else None
                 gx = _dummy_grad(weight.device).expand(N, Ci, H, W)   # never read: see chain_out above
                 CHAIN_STATS[0] += 1
             elif stride == (1, 1):
                 gx = _fwd(gz, N, OH, OW, wt, Ci, KH, KW, (1, 1), dil, dil[0] * (KH - 1) - pt,
                           dil[1] * (KW - 1) - pl, H, W, None, None,
-                          _nhwc(id_grad) if id_grad is not None else None, False, cin=Co)
+                          _nhwc(id_grad) if id_grad is not None else None, False, cin=Co, **qs)
             elif KH == 1 and KW == 1 and pads == (0, 0, 0, 0):
                 # strided 1x1: the gradient lives on the stride lattice, zero elsewhere
                 small = _fwd(gz, N, OH, OW, wt, Ci, 1, 1, (1, 1), (1, 1), 0, 0, OH, OW, None, None,
-                             None, False, cin=Co)
+                             None, False, cin=Co, **qs)
                 gx = torch.zeros((N, H, W, Ci), dtype=torch.float32, device=weight.device).permute(0, 3, 1, 2)
                 gx[:, :, ::stride[0], ::stride[1]] = small
             else:
@@ -454,15 +622,15 @@ class _ConvFn(torch.autograd.Function):
             e0 = _prof_begin()
             _lib.check(_lib.lib().sln_conv2d_wgrad_f32(
                 ops._ptr(gz), Co, gz.shape[2], ops._ptr(xp), N, H, W, Ci, xp.shape[2], parts, KH, KW,
-                stride[0], stride[1], dil[0], dil[1], pt, pl, OH, OW, ops._ptr(gw_t), ops._stream()),
-                "sln_conv2d_wgrad_f32")
+                stride[0], stride[1], dil[0], dil[1], pt, pl, OH, OW, ops._ptr(gw_t), ops._ptr(gzq),
+                ops._ptr(xq), ops._stream()), "sln_conv2d_wgrad_f32")
             wt_ = _lib.lib().sln_conv_wgrad_tile(N * OH * OW, Co, Ci, KH * KW, parts) if e0 is not None else 128
             _prof_end(e0, 2.0 * N * OH * OW * Co * KH * KW * Ci,
                       ("conv_wgrad256_kernel<%d>" if wt_ == 256 else "conv_wgrad_kernel<%d>") % parts,
                       "wgrad N%d %dx%d C%d->%d k%d s%d d%d" % (N, H, W, Ci, Co, KH, stride[0], dil[0]),
                       _nbytes(gz, xp), _nbytes(gw_t))
             gw = gw_t.permute(0, 3, 1, 2)  # logical [Co,Ci,KH,KW]
-        return gx, gw, g_bias, None, None, g_res, None, None, None, None, None, None, None
+        return gx, gw, g_bias, None, None, g_res, None, None, None, None, None, None, None, None
 
 
 _DUMMY = {}
@@ -482,4 +650,4 @@ def conv_bn_act(x, conv, bn, relu, residual, pads, weight=None, link=None, chain
         scale, shift = bn_affine(bn)
     return _ConvFn.apply(x, conv.weight if weight is None else weight, conv.bias, scale, shift,
                          residual, bool(relu), tuple(conv.stride), tuple(conv.dilation), tuple(pads),
-                         link if LINK_SHORTCUT_GRAD else None, chain_in, chain_out)
+                         link if LINK_SHORTCUT_GRAD else None, chain_in, chain_out, conv.weight)

@@ -1,6 +1,6 @@
 #include "common.h"
 
-extern "C" int sln_abi_version(void) { return 2; }  // 2: sln_conv2d_fwd_ms_f32 (groups, mask, colsum)
+extern "C" int sln_abi_version(void) { return 3; }  // 3: scaled split-fp16 operands (parts = 2): scale / amax arguments
 
 extern "C" const char *sln_error_string(int code) {
     switch (code) {

@@ -347,6 +347,11 @@ struct ConvParams {
     const float *post_scale;  // [Cout] or null: the PARTS (and colsum) hold output * post_scale[c]
     const float *mask;    // [M][Cout] or null: output elements whose mask value is not > 0 become 0
     float *colsum;        // [Cout] or null: += per-channel sums of the output (bias gradient)
+    // P = 2 (scaled split-fp16): the operands' scales (device scalars, NULL = 1): the accumulator
+    // holds (sx*x) (*) (sw*w), the epilogue multiplies by 1/(sx*sw); yq: scale / amax / saturation
+    // record of the output's own parts
+    const float *x_scale, *w_scale;
+    SplitScale yq;
     long x_part_stride, w_part_stride, y_part_stride;
     int Cop;
     int Cin, Cout, KH, KW, sh, sw, dh, dw, pt, pl, relu;
@@ -366,10 +371,21 @@ __device__ __forceinline__ void mfma_products(const bf16x8 (&a)[P], const bf16x8
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], c, 0, 0, 0);
+    } else {   // two fp16 parts: the same 16-bit containers, the f16 matrix instruction
+        const h16x8 a0 = __builtin_bit_cast(h16x8, a[0]), a1 = __builtin_bit_cast(h16x8, a[P - 1]);
+        const h16x8 b0 = __builtin_bit_cast(h16x8, b[0]), b1 = __builtin_bit_cast(h16x8, b[P - 1]);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, c, 0, 0, 0);
     }
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], c, 0, 0, 0);
+}
+
+// 1 / (sx * sw): exact for power-of-two scales
+__device__ __forceinline__ float operand_unscale(const float *sx, const float *sw) {
+    return 1.0f / ((sx ? *sx : 1.f) * (sw ? *sw : 1.f));
 }
 
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
@@ -384,7 +400,8 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 // v = acc*scale[c] + shift[c] (+ residual) (ReLU) (mask) -> y; parts / colsum of v (* post_scale).
 template <int P, int NCOLQ, int LD, int NTHREADS>
 __device__ __forceinline__ void epilogue_slab(const ConvParams &p, const float *stage, int m_base, int n0,
-                                              int t, float *s_colsum) {
+                                              int t, float *s_colsum, float alpha, float yqs, float &amx,
+                                              bool &sat) {
     constexpr int RG = NTHREADS / NCOLQ;      // row groups: thread t owns rows t/NCOLQ + RG*q
     constexpr int NQ = 64 / RG;
     const bool vec_ok = (p.Cout & 3) == 0;
@@ -397,6 +414,7 @@ __device__ __forceinline__ void epilogue_slab(const ConvParams &p, const float *
                 if (p.scale) sc[e] = p.scale[c + e];
                 if (p.shift) sf[e] = p.shift[c + e];
                 if (p.post_scale) ps_[e] = p.post_scale[c + e];
+                if (P == 2) sc[e] *= alpha;      // exact (power of two): acc * alpha * scale == acc * (alpha*scale)
             }
         // all residual rows of this half are requested before the first store: the
         // loads cannot be moved across the y stores by the compiler (may alias)
@@ -466,7 +484,8 @@ __device__ __forceinline__ void epilogue_slab(const ConvParams &p, const float *
             for (int e = 0; e < 4; ++e) csum[e] += v[e];
             if (p.yparts) {   // fused act_split of the output (Cop % 8 == 0, c % 4 == 0)
                 bf16x4 ps[3];
-                split4<P>(make_float4(v[0], v[1], v[2], v[3]), ps);
+                if (P == 2) amx = amax4(amx, v);
+                sat |= split4<P>(make_float4(v[0], v[1], v[2], v[3]), ps, yqs);
 #pragma unroll
                 for (int pp = 0; pp < P; ++pp)
                     *(bf16x4 *)(p.yparts + pp * p.y_part_stride + (long)m * p.Cop + c) = ps[pp];
@@ -498,7 +517,12 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvParams p) {
     tile_t sA = (tile_t)smem;
     tileb_t sB = (tileb_t)(smem + P * BM * BK * 2);
     __shared__ float s_colsum[BNT];   // per-block column sums of the output (colsum mode)
+    __shared__ unsigned s_word[2];    // block amax / saturation flag of the output parts (P = 2)
     if (threadIdx.x < BNT) s_colsum[threadIdx.x] = 0.f;   // ordered by the k-loop's barriers
+    const float alpha = P == 2 ? operand_unscale(p.x_scale, p.w_scale) : 1.f;
+    const float yqs = (P == 2 && p.yq.scale) ? *p.yq.scale : 1.f;
+    float amx = 0.f;
+    bool sat = false;
 
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
@@ -651,11 +675,12 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvParams p) {
                             acc[i][j][r];
         }
         __syncthreads();
-        epilogue_slab<P, BNT / 4, SLD, 256>(p, &stage[0][0], m0 + h * 64, n0, t, s_colsum);
+        epilogue_slab<P, BNT / 4, SLD, 256>(p, &stage[0][0], m0 + h * 64, n0, t, s_colsum, alpha, yqs, amx, sat);
         __syncthreads();
     }
     if (p.colsum && t < BNT && n0 + t < p.Cout && s_colsum[t] != 0.f)   // one global atomic per column
         atomicAdd(p.colsum + n0 + t, s_colsum[t]);
+    if (P == 2 && p.yparts) amax_commit(amx, sat, p.yq, s_word);
 }
 
 // ---------------------------------------------------------------- 256x256 forward tile
@@ -677,8 +702,13 @@ __global__ __launch_bounds__(512) void conv_fwd256_kernel(const ConvParams p) {
     constexpr int STAGE = 2 * P * REGION;     // A parts then B parts
     // ONE LDS object: with a second __shared__ array beside the DMA staging buffer hipcc (ROCm 7.2)
     // emits s_waitcnt vmcnt(0) before the first ds_read of every k-step, draining the DMA pipeline
-    __shared__ __attribute__((aligned(16))) unsigned char smem[3 * STAGE + T2 * 4];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[3 * STAGE + T2 * 4 + 16];
     float *s_colsum = (float *)(smem + 3 * STAGE);
+    unsigned *s_word = (unsigned *)(smem + 3 * STAGE + T2 * 4);
+    const float alpha = P == 2 ? operand_unscale(p.x_scale, p.w_scale) : 1.f;   // (scalar loads: not on vmcnt)
+    const float yqs = (P == 2 && p.yq.scale) ? *p.yq.scale : 1.f;
+    float amx = 0.f;
+    bool sat = false;
     typedef __attribute__((address_space(3))) void lds_void;
     typedef __attribute__((address_space(1))) const void glb_void;
 
@@ -827,10 +857,11 @@ __global__ __launch_bounds__(512) void conv_fwd256_kernel(const ConvParams p) {
                               (lane & 31)] = acc[2 * (h & 1) + ii][j][r];
         }
         __syncthreads();
-        epilogue_slab<P, 64, 260, 512>(p, stage, m0 + h * 64, n0, t, s_colsum);
+        epilogue_slab<P, 64, 260, 512>(p, stage, m0 + h * 64, n0, t, s_colsum, alpha, yqs, amx, sat);
         __syncthreads();
     }
     if (p.colsum && t < T2 && n0 + t < p.Cout && s_colsum[t] != 0.f) atomicAdd(p.colsum + n0 + t, s_colsum[t]);
+    if (P == 2 && p.yparts) amax_commit(amx, sat, p.yq, s_word);
 }
 
 // ------------------------------------------------------------ weight gradient
@@ -849,6 +880,7 @@ struct WgradParams {
     long gz_part_stride, x_part_stride;
     int N, H, W, Cin, Cip, Cout, Cop, KH, KW, sh, sw, dh, dw, pt, pl, OH, OW;
     int M, gm, gn_per_tap, ksplit, pix_per_split, xcd_wgrad;
+    const float *gz_scale, *x_scale;   // P = 2: operand scales (device scalars, NULL = 1)
 };
 
 template <int LD>
@@ -975,6 +1007,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
         }
     }
     // epilogue: row = co, col = ci; atomics (split-K partial sums)
+    const float alpha = P == 2 ? operand_unscale(p.gz_scale, p.x_scale) : 1.f;
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
         const int ci = n0 + wc * (TN / 2) + j * 32 + (lane & 31);
@@ -985,7 +1018,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
             for (int r = 0; r < 16; ++r) {
                 const int co = m0 + wr * (TM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (co >= p.Cout) continue;
-                const float v = acc[i][j][r];
+                const float v = acc[i][j][r] * alpha;
                 if (v != 0.f) atomicAdd(p.gw + ((long)co * p.KH * p.KW + tap) * p.Cin + ci, v);
             }
     }
@@ -1156,6 +1189,7 @@ __global__ __launch_bounds__(512) void conv_wgrad256_kernel(const WgradParams p)
             for (int j = 0; j < 2; ++j) mfma_products<P>(a[i], b[j], acc[i][j]);
     }
     // epilogue: row = co, col = ci; atomics (split-K partial sums)
+    const float alpha = P == 2 ? operand_unscale(p.gz_scale, p.x_scale) : 1.f;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int ci = n0 + wc * 64 + j * 32 + (lane & 31);
@@ -1166,7 +1200,7 @@ __global__ __launch_bounds__(512) void conv_wgrad256_kernel(const WgradParams p)
             for (int r = 0; r < 16; ++r) {
                 const int co = m0 + wr * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (co >= p.Cout) continue;
-                const float v = acc[i][j][r];
+                const float v = acc[i][j][r] * alpha;
                 if (v != 0.f) atomicAdd(p.gw + ((long)co * p.KH * p.KW + tap) * p.Cin + ci, v);
             }
     }
@@ -1191,50 +1225,67 @@ static inline int ew_grid(long total) {
 
 extern "C" int sln_conv_split_weights_f32(const float *w, int O, int I, int I_pad, int KH, int KW,
                                           long s_o, long s_i, long s_kh, long s_kw, int flip, int parts,
-                                          uint16_t *out, sln_stream_t stream) {
+                                          uint16_t *out, const float *q_scale, float *q_amax,
+                                          int32_t *q_saturated, sln_stream_t stream) {
     sln_enter();
-    if (!w || !out || O < 1 || I < 1 || I_pad < I || KH < 1 || KW < 1 || parts < 2 || parts > 3)
+    if (!w || O < 1 || I < 1 || I_pad < I || KH < 1 || KW < 1 || parts < 2 || parts > 3)
         return SLN_ERR_INVALID_ARG;
+    if (!out && !(parts == 2 && q_amax)) return SLN_ERR_INVALID_ARG;   // out == NULL: amax-only pass
     const long total = (long)O * KH * KW * I_pad;
+    const SplitScale q = {q_scale, q_amax, q_saturated};
     hipLaunchKernelGGL(split_weights_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, w, O,
-                       I, I_pad, KH, KW, s_o, s_i, s_kh, s_kw, flip, parts, (__bf16 *)out);
+                       I, I_pad, KH, KW, s_o, s_i, s_kh, s_kw, flip, parts, (__bf16 *)out, q);
     return sln_launch_status();
 }
 
 extern "C" int sln_act_split_f32(const float *x, int64_t M, int C, int C_pad, int parts, uint16_t *out,
+                                 const float *q_scale, float *q_amax, int32_t *q_saturated,
                                  sln_stream_t stream) {
     sln_enter();
     if (M < 0 || C < 1 || C_pad < C || (C_pad & 7) || parts < 2 || parts > 3) return SLN_ERR_INVALID_ARG;
     if (M == 0) return SLN_OK;
-    if (!x || !out) return SLN_ERR_INVALID_ARG;
+    if (!x || (!out && !(parts == 2 && q_amax))) return SLN_ERR_INVALID_ARG;
+    const SplitScale q = {q_scale, q_amax, q_saturated};
     if (parts == 2)
         hipLaunchKernelGGL(act_split_kernel<2>, dim3(ew_grid(M * (C_pad / 4))), dim3(256), 0,
-                           (hipStream_t)stream, x, (long)M, C, C_pad, (__bf16 *)out);
+                           (hipStream_t)stream, x, (long)M, C, C_pad, (__bf16 *)out, q);
     else
         hipLaunchKernelGGL(act_split_kernel<3>, dim3(ew_grid(M * (C_pad / 4))), dim3(256), 0,
-                           (hipStream_t)stream, x, (long)M, C, C_pad, (__bf16 *)out);
+                           (hipStream_t)stream, x, (long)M, C, C_pad, (__bf16 *)out, q);
     return sln_launch_status();
 }
 
 extern "C" int sln_conv_grad_prep_f32(const float *gy, const float *y, const float *scale, int64_t M,
                                       int C, int C_pad, int parts, float *gu, uint16_t *gz_parts,
-                                      float *gbias, sln_stream_t stream) {
+                                      float *gbias, const float *q_scale, float *q_amax,
+                                      int32_t *q_saturated, sln_stream_t stream) {
     sln_enter();
     if (M < 0 || C < 1 || C_pad < C || (C_pad & 7) || parts < 2 || parts > 3) return SLN_ERR_INVALID_ARG;
-    if (!gy || !gz_parts) return SLN_ERR_INVALID_ARG;
+    if (!gy || (!gz_parts && !(parts == 2 && q_amax))) return SLN_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream;
-    if (gbias && hipMemsetAsync(gbias, 0, sizeof(float) * C, st) != hipSuccess) return SLN_ERR_LAUNCH;
+    if (gz_parts && gbias && hipMemsetAsync(gbias, 0, sizeof(float) * C, st) != hipSuccess) return SLN_ERR_LAUNCH;
     if (M == 0) return SLN_OK;
     int tw = 1;
     while (tw < C_pad / 4 && tw < 256) tw <<= 1;
     long grid = sln_div_up(M, (long)(256 / tw) * 2);
     if (grid > 2048) grid = 2048;
+    const SplitScale q = {q_scale, q_amax, q_saturated};
     if (parts == 2)
         hipLaunchKernelGGL(grad_prep_kernel<2>, dim3((unsigned)grid), dim3(256), 0, st, gy, y, scale, (long)M,
-                           C, C_pad, gu, (__bf16 *)gz_parts, gbias);
+                           C, C_pad, gu, (__bf16 *)gz_parts, gbias, q);
     else
         hipLaunchKernelGGL(grad_prep_kernel<3>, dim3((unsigned)grid), dim3(256), 0, st, gy, y, scale, (long)M,
-                           C, C_pad, gu, (__bf16 *)gz_parts, gbias);
+                           C, C_pad, gu, (__bf16 *)gz_parts, gbias, q);
+    return sln_launch_status();
+}
+
+extern "C" int sln_scale_update_f32(float *amax, float *scale, int n, int target_log2, sln_stream_t stream) {
+    sln_enter();
+    if (n < 0 || target_log2 < -14 || target_log2 > 15) return SLN_ERR_INVALID_ARG;
+    if (n == 0) return SLN_OK;
+    if (!amax || !scale) return SLN_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(scale_update_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, amax,
+                       scale, n, target_log2);
     return sln_launch_status();
 }
 
@@ -1247,7 +1298,7 @@ extern "C" int sln_conv_fwd_tile(int64_t M, int Cout, int64_t K, int parts) {
     const int mode = sln_knob("SLN_CONV_TILE256", 1);
     if (M < 1 || Cout < 1 || M > 2147483647L - T2) return BM;
     if (mode == 2) return T2;
-    if (mode != 1 || (parts != 3 && !sln_knob("SLN_TILE256_P2", 0))) return BM;   // P2 knob: preview runs only
+    if (mode != 1) return BM;
     const long nb2 = sln_div_up(M, T2) * (long)sln_div_up(Cout, T2);
     const double fill = (double)nb2 / (double)(sln_div_up(nb2, 256) * 256L);
     // at least 176 of the last 256 columns in use (ASPP's Cout = 182: +6...11 % per launch over
@@ -1262,7 +1313,9 @@ extern "C" int sln_conv2d_fwd_ms_f32(const uint16_t *x_parts, int nseg, const in
                                      int pad_left, int pad_bottom, int pad_right, const float *scale,
                                      const float *shift, const float *residual, int relu,
                                      const float *mask, const float *post_scale, float *y,
-                                     uint16_t *y_parts, float *colsum, sln_stream_t stream) {
+                                     uint16_t *y_parts, float *colsum, const float *x_scale,
+                                     const float *w_scale, const float *y_q_scale, float *y_q_amax,
+                                     int32_t *y_q_saturated, sln_stream_t stream) {
     sln_enter();
     if (!x_parts || !w_parts || (!y && !y_parts) || !seg_nhw || nseg < 1 || nseg > SLN_MAX_SEG || Cin < 1 || Cout < 1 ||
         KH < 1 || KW < 1 || stride_h < 1 || stride_w < 1 || dil_h < 1 || dil_w < 1)
@@ -1295,6 +1348,8 @@ extern "C" int sln_conv2d_fwd_ms_f32(const uint16_t *x_parts, int nseg, const in
     p.x = (const __bf16 *)x_parts; p.w = (const __bf16 *)w_parts;
     p.scale = scale; p.shift = shift; p.residual = residual; p.y = y;
     p.yparts = (__bf16 *)y_parts; p.mask = mask; p.colsum = colsum; p.post_scale = post_scale;
+    p.x_scale = x_scale; p.w_scale = w_scale;
+    p.yq.scale = y_q_scale; p.yq.amax = y_q_amax; p.yq.saturated = y_q_saturated;
     p.Cop = (Cout + 7) / 8 * 8;
     p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW;
     p.sh = stride_h; p.sw = stride_w; p.dh = dil_h; p.dw = dil_w; p.pt = pad_top; p.pl = pad_left;
@@ -1335,7 +1390,8 @@ extern "C" int sln_conv2d_fwd_f32(const uint16_t *x_parts, int N, int H, int W, 
                                   int stride_h, int stride_w, int dil_h, int dil_w, int pad_top,
                                   int pad_left, int OH, int OW, const float *scale, const float *shift,
                                   const float *residual, int relu, float *y, uint16_t *y_parts,
-                                  sln_stream_t stream) {
+                                  const float *x_scale, const float *w_scale, const float *y_q_scale,
+                                  float *y_q_amax, int32_t *y_q_saturated, sln_stream_t stream) {
     // one image group; the caller's OH/OW fix the bottom/right padding
     if (N < 0 || H < 1 || W < 1 || OH < 1 || OW < 1 || KH < 1 || KW < 1 || stride_h < 1 || stride_w < 1 ||
         dil_h < 1 || dil_w < 1) {
@@ -1347,7 +1403,8 @@ extern "C" int sln_conv2d_fwd_f32(const uint16_t *x_parts, int N, int H, int W, 
     const int pad_right = (OW - 1) * stride_w + dil_w * (KW - 1) + 1 - W - pad_left;
     return sln_conv2d_fwd_ms_f32(x_parts, 1, seg, Cin, w_parts, parts, Cout, KH, KW, stride_h, stride_w,
                                  dil_h, dil_w, pad_top, pad_left, pad_bottom, pad_right, scale, shift,
-                                 residual, relu, nullptr, nullptr, y, y_parts, nullptr, stream);
+                                 residual, relu, nullptr, nullptr, y, y_parts, nullptr, x_scale, w_scale,
+                                 y_q_scale, y_q_amax, y_q_saturated, stream);
 }
 
 // Which weight-gradient kernel sln_conv2d_wgrad_f32 uses: 256 = conv_wgrad256_kernel (one (tap, 256 Cout
@@ -1358,7 +1415,7 @@ extern "C" int sln_conv_wgrad_tile(int64_t M, int Cout, int Cin, int taps, int p
     const int mode = sln_knob("SLN_WGRAD_TILE256", 1);
     if (M < 1 || Cout < 1 || Cin < 1 || taps < 1) return BM;
     if (mode == 2) return T2;
-    if (mode != 1 || (parts != 3 && !sln_knob("SLN_TILE256_P2", 0))) return BM;   // P2 knob: preview runs only
+    if (mode != 1) return BM;
     const long nt2 = (long)sln_div_up(Cout, T2) * sln_div_up(Cin, T2) * taps;
     const bool wide = Cout >= 176 && (Cout % T2 == 0 || Cout % T2 >= 160) && Cin >= 176 &&
                       (Cin % T2 == 0 || Cin % T2 >= 160);
@@ -1369,7 +1426,7 @@ extern "C" int sln_conv2d_wgrad_f32(const uint16_t *gz_parts, int Cout, int Cout
                                     const uint16_t *x_parts, int N, int H, int W, int Cin, int Cin_pad,
                                     int parts, int KH, int KW, int stride_h, int stride_w, int dil_h,
                                     int dil_w, int pad_top, int pad_left, int OH, int OW, float *gw,
-                                    sln_stream_t stream) {
+                                    const float *gz_scale, const float *x_scale, sln_stream_t stream) {
     sln_enter();
     if (!gz_parts || !x_parts || !gw || N < 0 || H < 1 || W < 1 || Cin < 1 || Cout < 1 || KH < 1 || KW < 1 ||
         OH < 1 || OW < 1 || Cin_pad < Cin || Cout_pad < Cout || (Cin_pad & 7) || (Cout_pad & 7))
@@ -1381,6 +1438,7 @@ extern "C" int sln_conv2d_wgrad_f32(const uint16_t *gz_parts, int Cout, int Cout
     if (N == 0) return SLN_OK;
     WgradParams p;
     p.gz = (const __bf16 *)gz_parts; p.x = (const __bf16 *)x_parts; p.gw = gw;
+    p.gz_scale = gz_scale; p.x_scale = x_scale;
     p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cip = Cin_pad; p.Cout = Cout; p.Cop = Cout_pad;
     p.KH = KH; p.KW = KW; p.sh = stride_h; p.sw = stride_w; p.dh = dil_h; p.dw = dil_w;
     p.pt = pad_top; p.pl = pad_left; p.OH = OH; p.OW = OW;

@@ -199,6 +199,9 @@ class MaskRCNN(nn.Module):
         image_metas = input[1]
         self._set_modes(mode)
         cfg = self.config
+        if molded_images.is_cuda:
+            from . import conv_hip       # delayed per-tensor operand scales follow the previous step's amax
+            conv_hip.update_scales()
         B, _, H, W = molded_images.shape
         probs, gloable_lab = self.glm_probs(molded_images)
         maps, rpn_class_logits, rpn_class, rpn_bbox = self.rpn_forward(molded_images)

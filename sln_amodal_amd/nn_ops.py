@@ -144,7 +144,8 @@ def deconv2x2_relu(x, deconv):
     Ci, Co = deconv.weight.shape[0], deconv.weight.shape[1]
     w2 = deconv.weight.permute(2, 3, 1, 0).reshape(4 * Co, Ci, 1, 1)
     b2 = deconv.bias.repeat(4) if deconv.bias is not None else None
-    y = hip._ConvFn.apply(x, w2, b2, None, None, None, True, (1, 1), (1, 1), (0, 0, 0, 0), None, None, None)
+    y = hip._ConvFn.apply(x, w2, b2, None, None, None, True, (1, 1), (1, 1), (0, 0, 0, 0), None, None, None,
+                          deconv.weight)
     N, _, H, W = y.shape
     y = y.permute(0, 2, 3, 1).reshape(N, H, W, 2, 2, Co).permute(0, 1, 3, 2, 4, 5)
     return y.reshape(N, 2 * H, 2 * W, Co).permute(0, 3, 1, 2)      # logical NCHW, NHWC in memory
@@ -159,5 +160,5 @@ def linear(x, lin):
         return F.linear(x, lin.weight, lin.bias)
     R, C = x.shape
     y = hip._ConvFn.apply(x.reshape(R, C, 1, 1), lin.weight.reshape(lin.out_features, C, 1, 1), lin.bias,
-                          None, None, None, False, (1, 1), (1, 1), (0, 0, 0, 0), None, None, None)
+                          None, None, None, False, (1, 1), (1, 1), (0, 0, 0, 0), None, None, None, lin.weight)
     return y.reshape(R, lin.out_features)

@@ -88,7 +88,7 @@ def test_forward_tile_rule_is_a_pure_host_function(monkeypatch):
     assert L.sln_conv_fwd_tile(65536, 256, 128, 3) == 128        # short reduction
     assert L.sln_conv_fwd_tile(67600, 256, 2304, 3) == 128       # 265 tiles: 52 % of two rounds
     assert L.sln_conv_fwd_tile(123440, 256, 2304, 3) == 256      # packed GLM scales: 483 tiles, 94 %
-    assert L.sln_conv_fwd_tile(65536, 256, 2304, 2) == 128       # 2-part path stays on 128
+    assert L.sln_conv_fwd_tile(65536, 256, 2304, 2) == 256       # same rule for both operand formats
     assert L.sln_conv_fwd_tile(65536, 182, 18432, 3) == 256      # ASPP: 182 of 256 columns is enough
     assert L.sln_conv_fwd_tile(65536, 150, 18432, 3) == 128      # 150 is not
     assert L.sln_conv_fwd_tile(65536, 256 + 100, 18432, 3) == 128  # nor a 100-column second tile
@@ -109,7 +109,7 @@ def test_wgrad_tile_rule_is_a_pure_host_function(monkeypatch):
     assert L.sln_conv_wgrad_tile(1048576, 64, 64, 9, 3) == 128      # narrow channels
     assert L.sln_conv_wgrad_tile(4096, 256, 256, 9, 3) == 128       # too few pixels
     assert L.sln_conv_wgrad_tile(65536, 2048, 2048, 9, 3) == 128    # 576 tap tiles: more than one round
-    assert L.sln_conv_wgrad_tile(65536, 256, 256, 9, 2) == 128      # 2-part path stays on 128
+    assert L.sln_conv_wgrad_tile(65536, 256, 256, 9, 2) == 256      # same rule for both operand formats
     monkeypatch.setenv("SLN_WGRAD_TILE256", "0")
     assert L.sln_conv_wgrad_tile(65536, 256, 256, 9, 3) == 128
     monkeypatch.setenv("SLN_WGRAD_TILE256", "2")

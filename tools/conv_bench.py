@@ -43,21 +43,25 @@ for parts in (2, 3):
         x = torch.randn(N, Cin, H, W, device="cuda").contiguous(memory_format=torch.channels_last)
         w = torch.randn(Cout, Cin, k, k, device="cuda") * 0.05
         pad = d * (k - 1) // 2
-        wp = conv_hip._split_weights(w)
+        wp, wq = conv_hip._split_weights(w)
         OH = (H + 2 * pad - d * (k - 1) - 1) // s + 1
         fl = 2.0 * N * OH * OH * Cout * Cin * k * k
-        xp = conv_hip.act_parts(x)
+        xp, xq = conv_hip.act_parts(x)
         t_split = timeit(lambda: conv_hip._lib.check(conv_hip._lib.lib().sln_act_split_f32(
-            conv_hip.ops._ptr(x), N * H * W, Cin, Cin, parts, conv_hip.ops._ptr(xp), conv_hip.ops._stream()), "s"))
-        t_hip = timeit(lambda: conv_hip._fwd(xp, N, H, W, wp, Cout, k, k, (s, s), (d, d), pad, pad, OH, OH, None, None, None, False))
+            conv_hip.ops._ptr(x), N * H * W, Cin, Cin, parts, conv_hip.ops._ptr(xp), conv_hip.ops._ptr(xq), None, None,
+            conv_hip.ops._stream()), "s"))
+        t_hip = timeit(lambda: conv_hip._fwd(xp, N, H, W, wp, Cout, k, k, (s, s), (d, d), pad, pad, OH, OH, None, None, None, False, xq=xq, wq=wq))
         wcl = w.contiguous(memory_format=torch.channels_last)
         t_ref = timeit(lambda: F.conv2d(x, wcl, None, s, pad, d))
         gy = torch.randn(N, Cout, OH, OH, device="cuda").contiguous(memory_format=torch.channels_last)
-        gz, _, _ = conv_hip._grad_prep(gy, None, None, False, False, parts)
+        gslot = conv_hip._slot(w, ("gz", OH, OH)) if parts == 2 else None
+        gz, _, _ = conv_hip._grad_prep(gy, None, None, False, False, parts, gslot)
+        gzq = gslot.scale if gslot is not None else None
         gw = torch.empty((Cout, k, k, Cin), device="cuda")
         t_wg = timeit(lambda: conv_hip._lib.check(conv_hip._lib.lib().sln_conv2d_wgrad_f32(
             conv_hip.ops._ptr(gz), Cout, gz.shape[2], conv_hip.ops._ptr(xp), N, H, W, Cin, xp.shape[2], parts, k, k,
-            s, s, d, d, pad, pad, OH, OH, conv_hip.ops._ptr(gw), conv_hip.ops._stream()), "w"))
+            s, s, d, d, pad, pad, OH, OH, conv_hip.ops._ptr(gw), conv_hip.ops._ptr(gzq), conv_hip.ops._ptr(xq),
+            conv_hip.ops._stream()), "w"))
         t_wref = timeit(lambda: torch.ops.aten.convolution_backward(gy, x, wcl, None, [s, s], [pad, pad], [d, d], False, [0, 0], 1, [False, True, False]))
         print("%-28s fwd hip %6.3f ms %5.0f TF (split %5.3f) aten %6.3f ms %5.0f TF x%.2f | wgrad hip %6.3f %5.0f TF aten %6.3f %5.0f TF x%.2f" %
               (name, t_hip, fl / t_hip / 1e9, t_split, t_ref, fl / t_ref / 1e9, t_ref / t_hip,

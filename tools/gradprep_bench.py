@@ -19,7 +19,7 @@ for (N, C, H) in [(16, 64, 256), (16, 256, 256), (16, 512, 128), (16, 1024, 64),
     y = torch.randn(N, H, H, C, device="cuda").permute(0, 3, 1, 2)
     sc = torch.rand(C, device="cuda") + 0.5
     for want_gu, want_bias in [(False, True), (False, False), (True, True)]:
-        ms = t(lambda: conv_hip._grad_prep(gy, y, sc, want_gu, want_bias, 3))
+        ms = t(lambda: conv_hip._grad_prep(gy, y, sc, want_gu, want_bias, 3, None))
         el = N * H * H * C
         b = el * (8 + 6 + (4 if want_gu else 0))
         print("N%d C%d H%d gu=%d bias=%d: %.3f ms  %.2f TB/s" % (N, C, H, want_gu, want_bias, ms, b / ms / 1e9))
