@@ -221,10 +221,26 @@ int sln_pyramid_crop_bwd_f32(const float *grads, int g_cstride, int g_coffset, c
  * sln_scale_update_f32        scale[i] <- 2^k with amax[i]*2^k in [2^(t-1), 2^t),
  *     t = target_log2 (11 on the path); amax[i] == 0 keeps scale[i]; amax[i] <- 0.
  * ------------------------------------------------------------------------- */
+/* Weight-part layouts.  ROWS: [parts][O][KH][KW][I_pad] (the 128x128 forward kernel).  TILED256: the
+ * LDS image of the 256x256 forward kernel -- for each 256-row Cout tile, each 16-channel K stage (in
+ * the kernel's own K order) and each part one contiguous 8-KB block, so that its 1-KiB DMA pieces
+ * read whole consecutive 128-B lines (sln_conv_tiled_weight_elems() elements per part, zero padded).
+ * (TILED256H: the same for the fp16 x 2 kernel's 32-channel stages.)  A forward call must pass the
+ * layout its kernel uses: sln_conv_fwd_weights_layout(). */
+#define SLN_WEIGHTS_ROWS 0
+#define SLN_WEIGHTS_TILED256 1
+#define SLN_WEIGHTS_TILED256H 2 /* parts = 2 only: 32-channel stages, 16-KB blocks */
+int64_t sln_conv_tiled_weight_elems(int O, int I, int KH, int KW, int layout);
+/* Debug sessions only (SLN_DEBUG_KNOBS + SLN_CONV_STAMP): per-wave cycle sums of the stamped
+ * diagnostic build of the fp16 forward kernel, [8 waves][4 phases][4 segments] -> host. */
+int sln_debug_read_stamps(uint64_t *out128);
+/* The layout a forward call must pass: M output pixels, Cout, Cin (padded, as in x_parts), taps =
+ * KH*KW, parts, and x_pixels = the number of input pixels (rows of x_parts). */
+int sln_conv_fwd_weights_layout(int64_t M, int Cout, int Cin, int taps, int parts, int64_t x_pixels);
 int sln_conv_split_weights_f32(const float *w, int O, int I, int I_pad, int KH, int KW, long s_o,
-                               long s_i, long s_kh, long s_kw, int flip, int parts, uint16_t *out,
-                               const float *q_scale, float *q_amax, int32_t *q_saturated,
-                               sln_stream_t stream);
+                               long s_i, long s_kh, long s_kw, int flip, int parts, int layout,
+                               uint16_t *out, const float *q_scale, float *q_amax,
+                               int32_t *q_saturated, sln_stream_t stream);
 int sln_act_split_f32(const float *x, int64_t M, int C, int C_pad, int parts, uint16_t *out,
                       const float *q_scale, float *q_amax, int32_t *q_saturated, sln_stream_t stream);
 int sln_conv_grad_prep_f32(const float *gy, const float *y, const float *scale, int64_t M, int C,
@@ -233,14 +249,14 @@ int sln_conv_grad_prep_f32(const float *gy, const float *y, const float *scale, 
                            sln_stream_t stream);
 int sln_scale_update_f32(float *amax, float *scale, int n, int target_log2, sln_stream_t stream);
 int sln_conv2d_fwd_f32(const uint16_t *x_parts, int N, int H, int W, int Cin,
-                       const uint16_t *w_parts, int parts, int Cout, int KH, int KW, int stride_h,
+                       const uint16_t *w_parts, int w_layout, int parts, int Cout, int KH, int KW, int stride_h,
                        int stride_w, int dil_h, int dil_w, int pad_top, int pad_left, int OH, int OW,
                        const float *scale, const float *shift, const float *residual, int relu,
                        float *y, uint16_t *y_parts, const float *x_scale, const float *w_scale,
                        const float *y_q_scale, float *y_q_amax, int32_t *y_q_saturated,
                        sln_stream_t stream);
 int sln_conv2d_fwd_ms_f32(const uint16_t *x_parts, int nseg, const int32_t *seg_nhw, int Cin,
-                          const uint16_t *w_parts, int parts, int Cout, int KH, int KW, int stride_h,
+                          const uint16_t *w_parts, int w_layout, int parts, int Cout, int KH, int KW, int stride_h,
                           int stride_w, int dil_h, int dil_w, int pad_top, int pad_left, int pad_bottom,
                           int pad_right, const float *scale, const float *shift, const float *residual,
                           int relu, const float *mask, const float *post_scale, float *y,

@@ -31,14 +31,17 @@ SIGNATURES = {
                                       _f, _p, _i, _i, _p]),
     "sln_pyramid_crop_bwd_f32": (_i, [_p, _i, _i, _p, _p, _p, _i, _i, _i, _i, _i, C.POINTER(_p),
                                       C.POINTER(_i), _p]),
+    "sln_conv_tiled_weight_elems": (C.c_int64, [_i, _i, _i, _i, _i]),
+    "sln_conv_fwd_weights_layout": (_i, [C.c_int64, _i, _i, _i, _i, C.c_int64]),
+    "sln_debug_read_stamps": (_i, [_p]),
     "sln_conv_split_weights_f32": (_i, [_p, _i, _i, _i, _i, _i, C.c_long, C.c_long, C.c_long,
-                                        C.c_long, _i, _i, _p, _p, _p, _p, _p]),
+                                        C.c_long, _i, _i, _i, _p, _p, _p, _p, _p]),
     "sln_act_split_f32": (_i, [_p, C.c_int64, _i, _i, _i, _p, _p, _p, _p, _p]),
     "sln_conv_grad_prep_f32": (_i, [_p, _p, _p, C.c_int64, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
     "sln_scale_update_f32": (_i, [_p, _p, _i, _i, _p]),
-    "sln_conv2d_fwd_f32": (_i, [_p, _i, _i, _i, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
+    "sln_conv2d_fwd_f32": (_i, [_p, _i, _i, _i, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
                                 _i, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
-    "sln_conv2d_fwd_ms_f32": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
+    "sln_conv2d_fwd_ms_f32": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
                                    _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "sln_conv_fwd_tile": (_i, [C.c_int64, _i, C.c_int64, _i]),
     "sln_conv_wgrad_tile": (_i, [C.c_int64, _i, _i, _i, _i]),

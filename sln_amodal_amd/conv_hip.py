@@ -20,8 +20,9 @@ import torch
 
 from . import _lib, ops
 
-# 3 = three bf16 parts (6 MFMA products); 2 = two scaled fp16 parts (3 products)
-PARTS = int(os.environ.get("SLN_CONV_PARTS", "3"))
+# 2 = two scaled fp16 parts (3 MFMA products per fp32 product; the default: same fp64-checked accuracy
+# at half the matrix work); 3 = three bf16 parts (6 products, no scales)
+PARTS = int(os.environ.get("SLN_CONV_PARTS", "2"))
 # parts used while autograd is disabled (the frozen GLM, inference): None = same as PARTS
 PARTS_NOGRAD = int(os.environ["SLN_CONV_PARTS_NOGRAD"]) if os.environ.get("SLN_CONV_PARTS_NOGRAD") else None
 class _NoCache(dict):
@@ -131,10 +132,19 @@ def _pad8(c):
     return (c + 7) // 8 * 8
 
 
-def _split_weights(weight, flip_swap=False, parts=None, owner=None):
-    """-> (wparts [parts][O][KH][KW][I_pad], scale tensor or None).  Cached on the tensor object
-    itself (keyed by its version counter), so the cache dies with the tensor and can never alias a
-    new tensor that happens to reuse the address."""
+ROWS, TILED256, TILED256H = 0, 1, 2     # weight-part layouts (include/sln_amodal.h)
+
+
+def weights_layout(M, Cout, Cin_pad, taps, parts, x_pixels):
+    """The layout the forward kernel for this problem reads (a pure host rule of the library)."""
+    return _lib.lib().sln_conv_fwd_weights_layout(M, Cout, Cin_pad, taps, parts, x_pixels)
+
+
+def _split_weights(weight, flip_swap=False, parts=None, owner=None, layout=ROWS):
+    """-> (wparts, scale tensor or None); wparts [parts][O][KH][KW][I_pad] (layout ROWS) or the flat
+    LDS-image order of the 256x256 kernel (TILED256).  Cached on the tensor object itself (keyed by
+    its version counter), so the cache dies with the tensor and can never alias a new tensor that
+    happens to reuse the address."""
     parts = parts or PARTS
     cache = getattr(weight, "_sln_wparts", None)
     if cache is None:
@@ -143,7 +153,7 @@ def _split_weights(weight, flip_swap=False, parts=None, owner=None):
             weight._sln_wparts = cache
         except Exception:
             pass
-    hit = cache.get((flip_swap, parts))
+    hit = cache.get((flip_swap, parts, layout))
     if hit is not None and hit[0] == weight._version:
         return hit[1], hit[2]
     w = weight.detach()
@@ -154,19 +164,23 @@ def _split_weights(weight, flip_swap=False, parts=None, owner=None):
     else:
         O, I, so, si = Co, Ci, s[0], s[1]
     Ip = _pad8(I)
-    out = torch.empty((parts, O, KH, KW, Ip), dtype=torch.bfloat16, device=w.device)
+    if layout != ROWS:
+        out = torch.empty((parts * _lib.lib().sln_conv_tiled_weight_elems(O, I, KH, KW, layout),),
+                          dtype=torch.bfloat16, device=w.device)
+    else:
+        out = torch.empty((parts, O, KH, KW, Ip), dtype=torch.bfloat16, device=w.device)
     slot = _slot(owner if owner is not None else weight, ("w",)) if parts == 2 else None
 
     def launch(dst):
         _lib.check(_lib.lib().sln_conv_split_weights_f32(
-            ops._ptr(w), O, I, Ip, KH, KW, so, si, s[2], s[3], 1 if flip_swap else 0, parts,
+            ops._ptr(w), O, I, Ip, KH, KW, so, si, s[2], s[3], 1 if flip_swap else 0, parts, layout,
             ops._ptr(dst), *_q3(slot), ops._stream()), "sln_conv_split_weights_f32")
     if slot is not None and slot.fresh:
         launch(None)
         slot.book.settle(slot)
     launch(out)
     q = slot.scale if slot is not None else None
-    cache[(flip_swap, parts)] = (weight._version, out, q)
+    cache[(flip_swap, parts, layout)] = (weight._version, out, q)
     return out, q
 
 
@@ -240,29 +254,36 @@ def _prof_end(e0, flops, name, shape="", rd_bytes=0, wr_bytes=0):
         PROFILE.append((e0, e1, flops, name, shape, rd_bytes, wr_bytes))
 
 
-def _fwd_kernel_name(M, Cout, K, parts):
-    """Name of the kernel sln_conv2d_fwd_ms_f32 launches for this problem (sln_conv_fwd_tile)."""
-    if PROFILE is None:
-        return ""
-    tile = _lib.lib().sln_conv_fwd_tile(M, Cout, K, parts)
-    return ("conv_fwd256_kernel<%d>" if tile == 256 else "conv_fwd_kernel<%d>") % parts
+def _fwd_kernel_name(layout, parts):
+    """Name of the kernel sln_conv2d_fwd_ms_f32 launches for a problem with this weight layout."""
+    if layout == TILED256H:
+        return "conv_fwd256h_kernel"
+    return ("conv_fwd256_kernel<%d>" if layout == TILED256 else "conv_fwd_kernel<%d>") % parts
 
 
 def _nbytes(*tensors):
     return sum(t.numel() * t.element_size() for t in tensors if t is not None)
 
 
-def _fwd(xparts, N, H, W, wparts, Cout, KH, KW, stride, dil, pt, pl, OH, OW, scale, shift, residual,
+def wsrc(weight, parts=None, flip_swap=False, owner=None):
+    """Weight operand of _fwd: split lazily there, in the layout the chosen kernel reads."""
+    return (weight, bool(flip_swap), owner, parts or PARTS)
+
+
+def _fwd(xparts, N, H, W, w, Cout, KH, KW, stride, dil, pt, pl, OH, OW, scale, shift, residual,
          relu, cin=None, out_parts=False, mask=None, want_y=True, want_colsum=False, post_scale=None,
-         xq=None, wq=None, yslot=None):
-    """One launch of the forward kernel.  mask / want_y=False / want_colsum: the epilogue extras of
-    sln_conv2d_fwd_ms_f32 (a data gradient that is consumed only as the previous layer's
-    prepared gradient).  xq / wq: the operands' scale tensors (PARTS = 2); yslot: the scale slot of
-    the output's own parts.  Returns y, or (y_or_None, parts, colsum) when any extra is used; the
-    parts' scale is yslot.scale."""
+         xq=None, yslot=None):
+    """One launch of the forward kernel.  w = wsrc(weight, parts, flip_swap, owner).  mask /
+    want_y=False / want_colsum: the epilogue extras of sln_conv2d_fwd_ms_f32 (a data gradient that
+    is consumed only as the previous layer's prepared gradient).  xq: the activation parts' scale
+    tensor (PARTS = 2); yslot: the scale slot of the output's own parts.  Returns y, or
+    (y_or_None, parts, colsum) when any extra is used; the parts' scale is yslot.scale."""
     import ctypes as C
     dev = xparts.device
-    P = wparts.shape[0]
+    weight, flip, owner, P = w
+    layout = weights_layout(N * OH * OW, Cout, xparts.shape[2], KH * KW, P, xparts.shape[1])
+    wparts, wq = _split_weights(weight, flip, P, owner, layout)
+    cin = cin or xparts.shape[2]
     y = torch.empty((N, OH, OW, Cout), dtype=torch.float32, device=dev).permute(0, 3, 1, 2) if want_y else None
     plain = mask is None and want_y and not want_colsum and post_scale is None
     if out_parts and P == 2:
@@ -282,14 +303,14 @@ def _fwd(xparts, N, H, W, wparts, Cout, KH, KW, stride, dil, pt, pl, OH, OW, sca
     seg = (C.c_int32 * 3)(N, H, W)
     e0 = _prof_begin()
     _lib.check(_lib.lib().sln_conv2d_fwd_ms_f32(
-        ops._ptr(xparts), 1, seg, xparts.shape[2], ops._ptr(wparts), P, Cout, KH, KW,
+        ops._ptr(xparts), 1, seg, xparts.shape[2], ops._ptr(wparts), layout, P, Cout, KH, KW,
         stride[0], stride[1], dil[0], dil[1], pt, pl, pb, pr, ops._ptr(scale), ops._ptr(shift),
         ops._ptr(residual), 1 if relu else 0, ops._ptr(mask), ops._ptr(post_scale), ops._ptr(y),
         ops._ptr(yp), ops._ptr(cs), ops._ptr(xq), ops._ptr(wq), *_q3(yslot if yp is not None and P == 2 else None),
         ops._stream()), "sln_conv2d_fwd_ms_f32")
-    _prof_end(e0, 2.0 * N * OH * OW * Cout * KH * KW * (cin or wparts.shape[4]),
-              _fwd_kernel_name(N * OH * OW, Cout, KH * KW * xparts.shape[2], P),
-              "fwd N%d %dx%d C%d->%d k%d s%d d%d" % (N, H, W, cin or wparts.shape[4], Cout, KH, stride[0], dil[0]),
+    _prof_end(e0, 2.0 * N * OH * OW * Cout * KH * KW * cin,
+              _fwd_kernel_name(layout, P),
+              "fwd N%d %dx%d C%d->%d k%d s%d d%d" % (N, H, W, cin, Cout, KH, stride[0], dil[0]),
               _nbytes(xparts, wparts, residual, mask), _nbytes(y, yp))
     if fresh:   # first use of this output's slot: exact amax pass over y, then the split
         yp = _act_split(_nhwc(y), N * OH * OW, Cout, P, yslot)
@@ -364,7 +385,8 @@ def conv_bn_act_ms(x, conv, bn, relu, residual, pads):
         flops += 2.0 * N * OH * OW * Co * KH * KW * Ci
     M = sum(n * h * w for n, h, w in osegs)
     xp, xq = x.get_parts(parts, owner=conv.weight)
-    wp, wq = _split_weights(conv.weight, parts=parts)
+    layout = weights_layout(M, Co, xp.shape[2], KH * KW, parts, xp.shape[1])
+    wp, wq = _split_weights(conv.weight, parts=parts, layout=layout)
     y = torch.empty((M, Co), dtype=torch.float32, device=x.y.device)
     yslot = _slot(conv.weight, ("y_ms",) + tuple(osegs)) if parts == 2 else None
     fresh = yslot is not None and yslot.fresh
@@ -378,11 +400,11 @@ def conv_bn_act_ms(x, conv, bn, relu, residual, pads):
         raise ValueError("residual does not match the convolution output")
     e0 = _prof_begin()
     _lib.check(_lib.lib().sln_conv2d_fwd_ms_f32(
-        ops._ptr(xp), len(x.segs), seg, xp.shape[2], ops._ptr(wp), parts, Co, KH, KW, sh, sw, dh, dw,
+        ops._ptr(xp), len(x.segs), seg, xp.shape[2], ops._ptr(wp), layout, parts, Co, KH, KW, sh, sw, dh, dw,
         pt, pl, pb, pr, ops._ptr(scale), ops._ptr(shift), ops._ptr(res), 1 if relu else 0, None, None,
         ops._ptr(y), ops._ptr(yp), None, ops._ptr(xq), ops._ptr(wq),
         *_q3(yslot if yp is not None else None), ops._stream()), "sln_conv2d_fwd_ms_f32")
-    _prof_end(e0, flops, _fwd_kernel_name(M, Co, KH * KW * xp.shape[2], parts),
+    _prof_end(e0, flops, _fwd_kernel_name(layout, parts),
               "fwd ms%s C%d->%d k%d s%d d%d" % ("+".join("%dx%d" % (h, w) for _, h, w in x.segs), Ci, Co, KH, sh, dh),
               _nbytes(xp, wp, res), _nbytes(y, yp))
     if fresh:
@@ -442,11 +464,10 @@ class _ConvFn(torch.autograd.Function):
         # passed in is a temporary view of it (Linear / deconv reshapes)
         own = owner if owner is not None else weight
         xp, xq = act_parts(x, parts, owner=own)
-        wp, wq = _split_weights(weight, parts=parts, owner=own)
         yslot = _slot(own, ("y", OH, OW)) if (parts == 2 and FUSE_OUTPUT_SPLIT) else None
         gzslot = _slot(own, ("gz", OH, OW)) if parts == 2 else None
-        y = _fwd(xp, N, H, W, wp, Co, KH, KW, stride, dil, pt, pl, OH, OW, scale, shift, res, relu, cin=Ci,
-                 out_parts=FUSE_OUTPUT_SPLIT, xq=xq, wq=wq, yslot=yslot)
+        y = _fwd(xp, N, H, W, wsrc(weight, parts, False, own), Co, KH, KW, stride, dil, pt, pl, OH, OW, scale,
+                 shift, res, relu, cin=Ci, out_parts=FUSE_OUTPUT_SPLIT, xq=xq, yslot=yslot)
         need_w = ctx.needs_input_grad[1]
         # identity-shortcut link (Bottleneck.forward): the conv that consumes x (head) and the
         # conv that adds the same x as its residual (tail) share a dict, so that the tail's
@@ -560,8 +581,8 @@ class _ConvFn(torch.autograd.Function):
         if id_grad is not None and not need_x:
             raise RuntimeError("identity-shortcut gradient was handed over but dx is not computed")
         if need_x:
-            wt, wtq = _split_weights(weight, flip_swap=True, parts=parts, owner=own)
-            qs = dict(xq=gzq, wq=wtq)
+            wt = wsrc(weight, parts, True, own)
+            qs = dict(xq=gzq)
             two = ctx.chain_in is not None and ctx.chain_in.get("readers") == 2
             if two and ctx.chain_in.get("consumer") != 2:
                 two = False

@@ -277,6 +277,125 @@ __global__ __launch_bounds__(256) void grad_prep_kernel(const float *__restrict_
     if (P == 2) amax_commit(amx, sat, q, s_word);
 }
 
+// K order of conv_fwd256_kernel: stage s <-> (tap, 16-channel chunk cc).  64-channel group major,
+// tap, then the group's chunks -- the four stages of a (group, tap) walk one 128-B line of every
+// pixel, and the KH*KW shifted windows of a group are read within 4*KH*KW consecutive stages, while
+// their lines are still in L2 (tap-major order re-fetched them from beyond L2: 4.7x the algorithmic
+// reads, PMC).  ncc = number of 16-channel chunks.
+#define T2 256
+#define T2K 16
+__host__ __device__ __forceinline__ void fwd256_stage(int s, int ntap, int ncc, int &tap, int &cc) {
+    const int gfull = ncc / 4, nsub_tail = ncc - 4 * gfull;
+    if (s < gfull * ntap * 4) {
+        const int g = s / (ntap * 4), r = s - g * (ntap * 4);
+        tap = r >> 2; cc = 4 * g + (r & 3);
+    } else {
+        const int r = s - gfull * ntap * 4;
+        tap = r / nsub_tail; cc = 4 * gfull + (r - tap * nsub_tail);
+    }
+}
+
+// Weights in the LDS-image order of conv_fwd256_kernel ("tiled" layout): for every 256-row Cout tile
+// nt, stage s and part pp one contiguous 8-KB block = the 256 x 32 B region the kernel's DMA drops into
+// LDS verbatim (row r at 32 r, its two 16-B halves XOR-swizzled with bit 3 of r; rows >= Cout and
+// channels >= Cin are zero), so that a 1-KiB DMA piece reads 8 consecutive 128-B lines instead of 32
+// B from each of 32 lines (tools/micro/dma_patterns.hip: 19 vs 70 cycles per piece and CU, L2-hot).
+__global__ __launch_bounds__(256) void split_weights_tiled_kernel(const float *__restrict__ w, int O, int I,
+                                                                  int KH, int KW, long s_o, long s_i,
+                                                                  long s_kh, long s_kw, int flip, int P,
+                                                                  __bf16 *__restrict__ out, SplitScale q) {
+    __shared__ unsigned s_word[2];
+    const int ntap = KH * KW, ncc = (I + T2K - 1) / T2K, nk = ntap * ncc, gn = (O + T2 - 1) / T2;
+    const long per_part = (long)T2 * T2K;                       // 4096 elements = 8 KB
+    const long total = (long)gn * nk * per_part;                // logical elements (one part)
+    const float qs = (P == 2 && q.scale) ? *q.scale : 1.f;
+    float amx = 0.f;
+    bool sat = false;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int pos = (int)(idx % per_part);
+        const long blk = idx / per_part;                        // nt * nk + s
+        const int st = (int)(blk % nk), nt = (int)(blk / nk);
+        const int r = pos >> 4, j = pos & 15;
+        const int jl = (((j >> 3) ^ ((r >> 3) & 1)) << 3) | (j & 7);   // logical channel within the chunk
+        int tap, cc;
+        fwd256_stage(st, ntap, ncc, tap, cc);
+        const int kh = tap / KW, kw = tap - kh * KW;
+        const int skh = flip ? KH - 1 - kh : kh, skw = flip ? KW - 1 - kw : kw;
+        const int o = nt * T2 + r, i = cc * T2K + jl;
+        float v = (o < O && i < I) ? w[o * s_o + i * s_i + skh * s_kh + skw * s_kw] : 0.f;
+        const long dst = blk * P * per_part + pos;
+        if (P == 2) {
+            amx = fmaxf(amx, fabsf(v));
+            if (!out) continue;
+            float qv = v * qs;
+            if (fabsf(qv) > SLN_F16_MAX) { qv = copysignf(SLN_F16_MAX, qv); sat = true; }
+            const _Float16 h0 = (_Float16)qv;
+            const _Float16 h1 = (_Float16)(qv - (float)h0);
+            out[dst] = __builtin_bit_cast(__bf16, h0);
+            out[dst + per_part] = __builtin_bit_cast(__bf16, h1);
+            continue;
+        }
+        for (int pp = 0; pp < P; ++pp) {
+            const __bf16 h = (__bf16)v;
+            out[dst + pp * per_part] = h;
+            v -= (float)h;
+        }
+    }
+    if (P == 2) amax_commit(amx, sat, q, s_word);
+}
+
+// ---- conv_fwd256h_kernel (two fp16 parts, 32-channel stages) ----
+#define T2H 32
+// stage s <-> (tap, 32-channel chunk cc): 64-channel group major, tap, the group's two chunks (the same
+// L2 argument as fwd256_stage).  ncc = number of 32-channel chunks.
+__host__ __device__ __forceinline__ void fwd256h_stage(int s, int ntap, int ncc, int &tap, int &cc) {
+    const int gfull = ncc / 2;
+    if (s < gfull * ntap * 2) {
+        const int g = s / (ntap * 2), r = s - g * (ntap * 2);
+        tap = r >> 1; cc = 2 * g + (r & 1);
+    } else {
+        tap = s - gfull * ntap * 2; cc = 2 * gfull;
+    }
+}
+
+// Weights in conv_fwd256h_kernel's LDS-image order: per (Cout tile, stage, part) one contiguous 16-KB
+// block of 256 rows x 64 B, the 16-B chunk index of row r XOR-swizzled with bits 2..3 of r.
+__global__ __launch_bounds__(256) void split_weights_tiledh_kernel(const float *__restrict__ w, int O, int I,
+                                                                   int KH, int KW, long s_o, long s_i,
+                                                                   long s_kh, long s_kw, int flip,
+                                                                   __bf16 *__restrict__ out, SplitScale q) {
+    __shared__ unsigned s_word[2];
+    const int ntap = KH * KW, ncc = (I + T2H - 1) / T2H, nk = ntap * ncc, gn = (O + T2 - 1) / T2;
+    const long per_part = (long)T2 * T2H;                       // 8192 elements = 16 KB
+    const long total = (long)gn * nk * per_part;
+    const float qs = q.scale ? *q.scale : 1.f;
+    float amx = 0.f;
+    bool sat = false;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int pos = (int)(idx % per_part);
+        const long blk = idx / per_part;                        // nt * nk + s
+        const int st = (int)(blk % nk), nt = (int)(blk / nk);
+        const int r = pos >> 5, j = pos & 31;
+        const int jl = ((((j >> 3) ^ ((r >> 2) & 3))) << 3) | (j & 7);   // logical channel within the chunk
+        int tap, cc;
+        fwd256h_stage(st, ntap, ncc, tap, cc);
+        const int kh = tap / KW, kw = tap - kh * KW;
+        const int skh = flip ? KH - 1 - kh : kh, skw = flip ? KW - 1 - kw : kw;
+        const int o = nt * T2 + r, i = cc * T2H + jl;
+        const float v = (o < O && i < I) ? w[o * s_o + i * s_i + skh * s_kh + skw * s_kw] : 0.f;
+        amx = fmaxf(amx, fabsf(v));
+        if (!out) continue;
+        float qv = v * qs;
+        if (fabsf(qv) > SLN_F16_MAX) { qv = copysignf(SLN_F16_MAX, qv); sat = true; }
+        const _Float16 h0 = (_Float16)qv;
+        const _Float16 h1 = (_Float16)(qv - (float)h0);
+        const long dst = blk * 2 * per_part + pos;
+        out[dst] = __builtin_bit_cast(__bf16, h0);
+        out[dst + per_part] = __builtin_bit_cast(__bf16, h1);
+    }
+    amax_commit(amx, sat, q, s_word);
+}
+
 // fp32 weights (any strides) -> [P][O][KH][KW][Ip] parts (i >= I zero).
 // flip=1 mirrors the taps (with O/I swapped through the strides this expresses the
 // data-gradient convolution as a forward convolution).  out == NULL: amax only.
@@ -356,6 +475,8 @@ struct ConvParams {
     int Cop;
     int Cin, Cout, KH, KW, sh, sw, dh, dw, pt, pl, relu;
     int M, Ktot, cin_chunks, gm, gn;
+    int w_tiled;   // weights in conv_fwd256_kernel's LDS-image order (split_weights_tiled_kernel)
+    int dbg;   // ablation bits, debug sessions only (SLN_CONV_DBG): 1 no DMA in the k-loop, 2 no MFMA, 4 no fragment reads
     // Up to SLN_MAX_SEG image groups of different sizes share one launch (the GLM's three
     // scales): group s holds segN[s] images of segH x segW, its output rows start at
     // seg_m0[s] and its input pixels at seg_x0[s] of the flat [pixels][C] buffers.
@@ -692,8 +813,6 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvParams p) {
 // the 16-B half is XOR-swizzled with bit 3 of the row, applied on the source side, so that the
 // 16 lanes of a ds_read_b128 group hit 16 distinct 4-bank groups.  Taps outside the image and
 // channel / row tails read a 16-B page of zeros.  One block per CU (144 KB LDS).
-#define T2 256
-#define T2K 16
 __device__ __attribute__((aligned(16))) const unsigned char sln_zero_page[16] = {0};
 
 template <int P>
@@ -743,33 +862,21 @@ __global__ __launch_bounds__(512) void conv_fwd256_kernel(const ConvParams p) {
         a_iw0 = ow * p.sw - p.pl;
         a_nbase = (long)p.seg_x0[sg] + (long)n * a_H * a_W;
     }
-    const bool b_ok = (n0 + drow) < p.Cout;
-    const __bf16 *bptr = p.w + (long)(n0 + (b_ok ? drow : 0)) * p.Ktot;
     const int ncc = (p.Cin + T2K - 1) / T2K;
     const int nk = p.KH * p.KW * ncc;
-
-    // K order: 64-channel group major, tap, then the group's 16-channel chunks -- the four
-    // stages of a (group, tap) walk one 128-B line of every pixel, and the KH*KW shifted windows
-    // of a group are read within 4*KH*KW consecutive stages, while their lines are still in L2
-    // (tap-major order re-fetched them from beyond L2: 4.7x the algorithmic reads, PMC)
+    // weights: tiled layout, this lane's 16 B of every (stage, part) block: contiguous 1-KiB pieces
+    const __bf16 *bptr = p.w + (long)(bid % p.gn) * nk * P * (T2 * T2K) + wave * 512 + lane * 8;
     const int ntap = p.KH * p.KW;
-    const int gfull = ncc / 4, nsub_tail = ncc - 4 * gfull;
     auto issue = [&](int s) {
         int tap, cc;
-        if (s < gfull * ntap * 4) {
-            const int g = s / (ntap * 4), r = s - g * (ntap * 4);
-            tap = r >> 2; cc = 4 * g + (r & 3);
-        } else {
-            const int r = s - gfull * ntap * 4;
-            tap = r / nsub_tail; cc = 4 * gfull + (r - tap * nsub_tail);
-        }
+        fwd256_stage(s, ntap, ncc, tap, cc);
         const int kh = tap / p.KW, kw = tap - kh * p.KW;
         const int ci = cc * T2K + dlog;
         const bool cok = ci < p.Cin;
         const int ih = a_ih0 + kh * p.dh, iw = a_iw0 + kw * p.dw;
         const bool aok = a_ok && cok && ih >= 0 && ih < a_H && iw >= 0 && iw < a_W;
         const long aoff = (a_nbase + (long)ih * a_W + iw) * p.Cin + ci;
-        const long boff = (long)tap * p.Cin + ci;
+        const __bf16 *gbs = bptr + (long)s * P * (T2 * T2K);
         unsigned char *base = smem + (s % 3) * STAGE + wave * 1024;
 #pragma unroll
         for (int pp = 0; pp < P; ++pp) {
@@ -777,11 +884,9 @@ __global__ __launch_bounds__(512) void conv_fwd256_kernel(const ConvParams p) {
             __builtin_amdgcn_global_load_lds((glb_void *)ga, (lds_void *)(base + pp * REGION), 16, 0, 0);
         }
 #pragma unroll
-        for (int pp = 0; pp < P; ++pp) {
-            const void *gb = (b_ok && cok) ? (const void *)(bptr + pp * p.w_part_stride + boff)
-                                           : (const void *)sln_zero_page;
-            __builtin_amdgcn_global_load_lds((glb_void *)gb, (lds_void *)(base + (P + pp) * REGION), 16, 0, 0);
-        }
+        for (int pp = 0; pp < P; ++pp)
+            __builtin_amdgcn_global_load_lds((glb_void *)(gbs + pp * (T2 * T2K)),
+                                             (lds_void *)(base + (P + pp) * REGION), 16, 0, 0);
     };
 
     f32x16 acc[4][2];
@@ -818,26 +923,41 @@ __global__ __launch_bounds__(512) void conv_fwd256_kernel(const ConvParams p) {
         asm volatile("" ::: "memory");
         const unsigned char *st = smem + (s % 3) * STAGE;
         bf16x8 a[4][P], b[2][P];
+        if (!(p.dbg & 4) || s == 0) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int pp = 0; pp < P; ++pp) b[j][pp] = *(const bf16x8 *)(st + (P + pp) * REGION + b_off[j]);
+                for (int pp = 0; pp < P; ++pp) b[j][pp] = *(const bf16x8 *)(st + (P + pp) * REGION + b_off[j]);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int pp = 0; pp < P; ++pp) a[i][pp] = *(const bf16x8 *)(st + pp * REGION + a_off[i]);
+                for (int pp = 0; pp < P; ++pp) a[i][pp] = *(const bf16x8 *)(st + pp * REGION + a_off[i]);
+        }
         // fragment reads first, then the first quarter of the MFMAs, and only then the DMA of
         // stage s+2 (its buffer is free since the barrier): the DMA issue no longer delays the
         // reads this stage's MFMAs wait for
+        if (!(p.dbg & 2)) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) mfma_products<P>(a[0], b[j], acc[0][j]);
+            for (int j = 0; j < 2; ++j) mfma_products<P>(a[0], b[j], acc[0][j]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int pp = 0; pp < P; ++pp) asm volatile("" ::"v"(a[i][pp]));
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int pp = 0; pp < P; ++pp) asm volatile("" ::"v"(b[j][pp]));
+        }
         __builtin_amdgcn_sched_barrier(0);
-        if (s + 2 < nk) issue(s + 2);
+        if (s + 2 < nk && !((p.dbg & 1) && s > 0)) issue(s + 2);
         __builtin_amdgcn_sched_barrier(0);
+        if (!(p.dbg & 2)) {
 #pragma unroll
-        for (int i = 1; i < 4; ++i)
+            for (int i = 1; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) mfma_products<P>(a[i], b[j], acc[i][j]);
+                for (int j = 0; j < 2; ++j) mfma_products<P>(a[i], b[j], acc[i][j]);
+        }
     }
     __syncthreads();
 
@@ -862,6 +982,290 @@ __global__ __launch_bounds__(512) void conv_fwd256_kernel(const ConvParams p) {
     }
     if (p.colsum && t < T2 && n0 + t < p.Cout && s_colsum[t] != 0.f) atomicAdd(p.colsum + n0 + t, s_colsum[t]);
     if (P == 2 && p.yparts) amax_commit(amx, sat, p.yq, s_word);
+}
+
+// ---------------------------------------------------------------- 256x256 forward tile, fp16 x 2
+// conv_fwd256_kernel rebuilt around what limits it with three part products per fp32 product
+// (tools/conv_dbg.py ablations, tools/micro/dma_patterns.hip):
+//  * the LDS-DMA path costs ~2.2 cycles per distinct 128-B line a 1-KiB piece touches (L2-hot): a
+//    16-channel stage row is 32 B, i.e. 32 lines per piece = 70 cycles, and the k-loop was DMA-bound
+//    (DMA alone 1.9 ms, MFMA alone 2.0 ms, together 4.0 ms on the 256^2 FPN layer).  Here a stage is
+//    32 channels (64-B rows, 16 rows per piece: 35 cycles) and the weights come pre-arranged in the
+//    LDS image order (contiguous pieces: 19 cycles);
+//  * all eight waves used to read fragments, issue their DMA pieces and run their MFMAs at the same
+//    time, so that DMA issue (which blocks a wave while the queue is full) and MFMA never overlapped.
+//    The two wave groups (waves 0-3 / 4-7: one of each per SIMD) now run half a phase apart, the
+//    guide's 8-phase arrangement: while one group's 12-MFMA cluster owns the matrix pipes the other
+//    reads its next fragments and issues DMA.
+// A stage = 4 phases of (fragment reads [+ DMA of the next stage] | barrier | 12 MFMAs | barrier); two
+// 64-KB stage buffers; the DMA of stage s+1 is issued during phases 0..2 of stage s (its buffer was
+// last read in stage s-1: every wave has waited for those reads before the barrier that precedes the
+// first issue), and every wave waits for its own pieces (vmcnt(0)) before the middle barrier of
+// phase 3, which the first reads of stage s+1 lie behind for both groups.
+// Diagnostic build (STAMP = true, SLN_CONV_STAMP knob): s_memtime stamps around the four segments of
+// every phase, summed per wave in scalar registers and stored after the loop -- read the SHARES, not
+// the run time (the stamps' fences forbid overlaps the real kernel has).
+__device__ unsigned long long sln_stamp_sums[8 * 16];     // [wave][phase * 4 + segment], block 0 only
+#define SLN_STAMP(var)                                                                        \
+    do {                                                                                      \
+        if (STAMP) {                                                                          \
+            __builtin_amdgcn_sched_barrier(0);                                                \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");       \
+            __builtin_amdgcn_sched_barrier(0);                                                \
+        }                                                                                     \
+    } while (0)
+
+template <bool STAMP, int NPH>
+__global__ __launch_bounds__(512) void conv_fwd256h_kernel(const ConvParams p) {
+    constexpr int P = 2;
+    unsigned long long sums[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+    constexpr int REGION = T2 * T2H * 2;      // one part of one operand: 256 rows x 64 B = 16 KB
+    constexpr int STAGE = 2 * P * REGION;     // A parts then B parts: 64 KB
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE + T2 * 4 + 16];   // ONE LDS object
+    float *s_colsum = (float *)(smem + 2 * STAGE);
+    unsigned *s_word = (unsigned *)(smem + 2 * STAGE + T2 * 4);
+    const float alpha = operand_unscale(p.x_scale, p.w_scale);
+    const float yqs = p.yq.scale ? *p.yq.scale : 1.f;
+    float amx = 0.f;
+    bool sat = false;
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef __attribute__((address_space(1))) const void glb_void;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int wr = wave >> 2, wc = wave & 3;
+    if (t < T2) s_colsum[t] = 0.f;
+    const int bid = xcd_remap(blockIdx.x, p.gm * p.gn);
+    const int m0 = (bid / p.gn) * T2;
+    const int n0 = (bid % p.gn) * T2;
+
+    // ---- DMA slots of this lane: rows 32*wave + 16*q + lane/4 (q = 0, 1), 16-B chunk lane&3 of the
+    //      64-B row; the chunk it FETCHES is the swizzled one.  Pieces are buffer loads to LDS: a lane
+    //      whose tap falls outside the image (or whose row / channel is a tail) gets the offset
+    //      0xFFFFFFFF, which the buffer range check turns into zeros in LDS -- no per-lane pointer
+    //      select, no branches; per stage a lane computes two 32-bit offsets (q = 0, 1), the parts
+    //      differ by a scalar offset. ----
+    int a_ih0[2], a_iw0[2], a_H[2], a_W[2];
+    unsigned a_base[2], a_c0[2];      // byte offset of (image base pixel, channel 0) / of the lane's chunk
+    bool a_ok[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int drow = 32 * wave + 16 * q + (lane >> 2);
+        a_c0[q] = (unsigned)(((lane & 3) ^ ((drow >> 2) & 3)) * 8);       // logical channel offset in the chunk
+        const int m = m0 + drow;
+        a_ok[q] = m < p.M;
+        int mm = a_ok[q] ? m : 0;
+        int sg = 0;
+        for (int k = 1; k < p.nseg; ++k)
+            if (mm >= p.seg_m0[k]) sg = k;
+        mm -= p.seg_m0[sg];
+        const int OHs = p.segOH[sg], OWs = p.segOW[sg];
+        a_H[q] = p.segH[sg]; a_W[q] = p.segW[sg];
+        const int n = mm / (OHs * OWs);
+        const int rem = mm - n * (OHs * OWs);
+        const int oh = rem / OWs, ow = rem - oh * OWs;
+        a_ih0[q] = oh * p.sh - p.pt;
+        a_iw0[q] = ow * p.sw - p.pl;
+        a_base[q] = (unsigned)(p.seg_x0[sg] + n * a_H[q] * a_W[q]);      // pixels (< 2^31 / Cin: launcher)
+    }
+    const int ncc = (p.Cin + T2H - 1) / T2H;
+    const int ntap = p.KH * p.KW;
+    const int nk = ntap * ncc;
+    const int gfull = ncc / 2;
+    // one buffer resource per part (each part < 4 GiB: the launcher checks)
+    const unsigned x_part_bytes = (unsigned)(p.x_part_stride * 2);
+    const __amdgpu_buffer_rsrc_t rsrc_a0 = __builtin_amdgcn_make_buffer_rsrc((void *)p.x, 0, (int)x_part_bytes,
+                                                                             0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_a1 = __builtin_amdgcn_make_buffer_rsrc((void *)(p.x + p.x_part_stride), 0,
+                                                                             (int)x_part_bytes, 0x00020000);
+    // weights: the tiled image of this Cout tile; this lane's 16 B of the wave's 2-KiB slice of a block
+    const unsigned w_tile_bytes = (unsigned)nk * P * (T2 * T2H * 2);
+    const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(p.w + (long)(bid % p.gn) * nk * P * (T2 * T2H)), 0, (int)w_tile_bytes, 0x00020000);
+    const unsigned b_voff = (unsigned)(wave * 2048 + lane * 16);
+
+    // the stage whose DMA is being issued: (group of 64 channels, tap, half) walked incrementally
+    int n_g = 0, n_tap = 0, n_half = 0, n_kh = 0, n_kw = 0, n_s = 0;
+    unsigned a_voff[2];
+    auto stage_offsets = [&]() {          // per-lane byte offsets of the two A rows for stage n_s
+        const int cc = 2 * n_g + n_half;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int ih = a_ih0[q] + n_kh * p.dh, iw = a_iw0[q] + n_kw * p.dw;
+            const unsigned ci = (unsigned)(cc * T2H) + a_c0[q];
+            const bool ok = a_ok[q] && (unsigned)ih < (unsigned)a_H[q] && (unsigned)iw < (unsigned)a_W[q] &&
+                            ci < (unsigned)p.Cin;
+            const unsigned off = ((a_base[q] + (unsigned)(ih * a_W[q] + iw)) * (unsigned)p.Cin + ci) * 2u;
+            a_voff[q] = ok ? off : 0xFFFFFFFFu;
+        }
+    };
+    auto stage_advance = [&]() {
+        ++n_s;
+        if (++n_half == (n_g < gfull ? 2 : 1)) {
+            n_half = 0;
+            ++n_tap;
+            if (++n_kw == p.KW) { n_kw = 0; ++n_kh; }
+            if (n_tap == ntap) { n_tap = 0; n_kh = 0; n_kw = 0; ++n_g; }
+        }
+    };
+    // piece g (0..7) of stage n_s: g&3 -> {A part 0 rows q=0, A part 0 q=1, A part 1 q=0, A part 1 q=1},
+    // g >= 4 the same for B.  Issued three per phase in phases 0 and 1, two in phase 2.
+    auto issue_piece = [&](int g) {
+        unsigned char *base = smem + (n_s & 1) * STAGE + wave * 2048;
+        const int pp = (g >> 1) & 1, q = g & 1;
+        if (g < 4) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(pp ? rsrc_a1 : rsrc_a0,
+                                                     (lds_void *)(base + pp * REGION + q * 1024), 16, a_voff[q], 0,
+                                                     0, 0);
+        } else {
+            const unsigned soff = (unsigned)(n_s * P + pp) * (T2 * T2H * 2) + q * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)(base + (P + pp) * REGION + q * 1024), 16,
+                                                     b_voff, soff, 0, 0);
+        }
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragment addresses (bytes inside a region) of k16 sub-step 0: row*64 + ((half) ^ swz(row))*16;
+    // sub-step 1 flips bit 1 of the chunk index: address ^ 32
+    const int frow = lane & 31, fhalf = lane >> 5;
+    int a_off[4], b_off[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = 128 * wr + 32 * i + frow;
+        a_off[i] = row * 64 + ((fhalf ^ ((row >> 2) & 3)) * 16);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = 64 * wc + 32 * j + frow;
+        b_off[j] = row * 64 + ((fhalf ^ ((row >> 2) & 3)) * 16);
+    }
+
+    stage_offsets();
+#pragma unroll
+    for (int g = 0; g < 8; ++g) issue_piece(g);
+    stage_advance();
+    if (nk > 1) stage_offsets();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const bool stagger = !(p.dbg & 8);
+    if (wr == 1 && stagger) __builtin_amdgcn_s_barrier();      // the second wave group runs one barrier behind
+    asm volatile("" ::: "memory");
+
+    bf16x8 b[2][P];
+    for (int s = 0; s < nk; ++s) {
+        const unsigned char *st = smem + (s & 1) * STAGE;
+        const bool more = s + 1 < nk;
+#pragma unroll
+        for (int ph = 0; ph < NPH; ++ph) {
+            // NPH = 4: phase = (k16 sub-step, half of the wave's 128 rows), 12 MFMAs; NPH = 2: phase =
+            // k16 sub-step, 24 MFMAs
+            constexpr int NA = NPH == 4 ? 2 : 4;
+            const int sub = NPH == 4 ? ph >> 1 : ph, hi = NPH == 4 ? ph & 1 : 0;
+            bf16x8 a[NA][P];
+            SLN_STAMP(t0);
+            if (!hi) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int pp = 0; pp < P; ++pp)
+                        b[j][pp] = *(const bf16x8 *)(st + (P + pp) * REGION + (b_off[j] ^ (sub * 32)));
+            }
+#pragma unroll
+            for (int i = 0; i < NA; ++i)
+#pragma unroll
+                for (int pp = 0; pp < P; ++pp)
+                    a[i][pp] = *(const bf16x8 *)(st + pp * REGION + (a_off[NA * hi + i] ^ (sub * 32)));
+            __builtin_amdgcn_sched_barrier(0);
+            if (more && !(p.dbg & 1)) {    // n_s == s + 1 here; its offsets were computed in the last phase of stage s - 1
+                if (NPH == 4) {
+                    if (ph == 0) { issue_piece(0); issue_piece(4); issue_piece(1); }
+                    if (ph == 1) { issue_piece(5); issue_piece(2); issue_piece(6); }
+                    if (ph == 2) { issue_piece(3); issue_piece(7); }
+                } else if (ph == 0) {
+#pragma unroll
+                    for (int g = 0; g < 8; ++g) issue_piece((g >> 1) | ((g & 1) << 2));   // A, B alternating
+                }
+            }
+            if (ph == NPH - 1) {
+                // own DMA pieces landed before the middle barrier of the last phase, which the first
+                // reads of the next stage lie behind for both groups; then the offsets of the stage
+                // after that (cheap VALU in the shortest read segment)
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                stage_advance();
+                if (s + 2 < nk) stage_offsets();
+            } else {
+                // own fragment reads returned BEFORE the barrier: the other group may re-stage this
+                // buffer right behind it (phase 0 of the next stage)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            SLN_STAMP(t1);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            SLN_STAMP(t2);
+            __builtin_amdgcn_s_setprio(1);
+            if (!(p.dbg & 2)) {
+#pragma unroll
+                for (int i = 0; i < NA; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) mfma_products<P>(a[i], b[j], acc[NA * hi + i][j]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < NA; ++i)
+#pragma unroll
+                    for (int pp = 0; pp < P; ++pp) asm volatile("" ::"v"(a[i][pp]), "v"(b[i & 1][pp]));
+            }
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (STAMP) {   // the MFMAs' results must exist before the stamp: tie them to a scalar wait
+                asm volatile("s_nop 0" ::"v"(acc[NA * hi][0][0]), "v"(acc[NA * hi + NA - 1][1][15]));
+            }
+            SLN_STAMP(t3);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            SLN_STAMP(t4);
+            if (STAMP) {
+                sums[ph * 4 + 0] += t1 - t0; sums[ph * 4 + 1] += t2 - t1;
+                sums[ph * 4 + 2] += t3 - t2; sums[ph * 4 + 3] += t4 - t3;
+            }
+        }
+    }
+    if (STAMP && blockIdx.x == 0 && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sln_stamp_sums[wave * 16 + i] = sums[i];
+    }
+    if (wr == 0 && stagger) __builtin_amdgcn_s_barrier();      // re-align the two groups
+    __syncthreads();
+
+    // ---- epilogue: four 64-row slabs through LDS ([64][260] floats), as in conv_fwd256_kernel ----
+    float *stage = (float *)smem;
+    static_assert(64 * 260 * 4 <= 2 * STAGE, "staging slab must fit");
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        if (wr == (h >> 1)) {
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        stage[(ii * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 260 + wc * 64 + j * 32 +
+                              (lane & 31)] = acc[2 * (h & 1) + ii][j][r];
+        }
+        __syncthreads();
+        epilogue_slab<P, 64, 260, 512>(p, stage, m0 + h * 64, n0, t, s_colsum, alpha, yqs, amx, sat);
+        __syncthreads();
+    }
+    if (p.colsum && t < T2 && n0 + t < p.Cout && s_colsum[t] != 0.f) atomicAdd(p.colsum + n0 + t, s_colsum[t]);
+    if (p.yparts) amax_commit(amx, sat, p.yq, s_word);
 }
 
 // ------------------------------------------------------------ weight gradient
@@ -1223,16 +1627,56 @@ static inline int ew_grid(long total) {
     return (int)(g < 1 ? 1 : g);
 }
 
+// Debug sessions only: the stamp sums of the last conv_fwd256h_kernel<true> launch (block 0), host copy.
+extern "C" int sln_debug_read_stamps(uint64_t *out128) {
+    return hipMemcpyFromSymbol(out128, HIP_SYMBOL(sln_stamp_sums), sizeof(unsigned long long) * 128) == hipSuccess
+               ? SLN_OK : SLN_ERR_LAUNCH;
+}
+
+extern "C" int64_t sln_conv_tiled_weight_elems(int O, int I, int KH, int KW, int layout) {
+    if (O < 1 || I < 1 || KH < 1 || KW < 1) return 0;
+    const int kc = layout == SLN_WEIGHTS_TILED256H ? T2H : T2K;
+    return (int64_t)sln_div_up(O, T2) * KH * KW * sln_div_up(I, kc) * (T2 * kc);
+}
+
+// Layout of the weight parts sln_conv2d_fwd(_ms)_f32 reads for this problem (host-side rule).
+// conv_fwd256h_kernel addresses its operands with 32-bit byte offsets (buffer loads): one part of the
+// activations (<= the output rows' worth of input pixels x Cin here: stride 1) and one Cout tile of the
+// tiled weights must stay below 4 GiB each.
+static inline bool fwd256h_fits(long x_part_elems, long w_tile_elems) {
+    return x_part_elems * 2 < 4294967295L && w_tile_elems * 2 < 4294967295L;
+}
+extern "C" int sln_conv_fwd_weights_layout(int64_t M, int Cout, int Cin, int taps, int parts, int64_t x_pixels) {
+    if (Cin < 1 || taps < 1) return SLN_WEIGHTS_ROWS;
+    if (sln_conv_fwd_tile(M, Cout, (int64_t)taps * Cin, parts) != T2) return SLN_WEIGHTS_ROWS;
+    const bool h = parts == 2 && sln_knob("SLN_CONV_F16_KERNEL", 1) &&
+                   fwd256h_fits(x_pixels * Cin, (long)taps * sln_div_up(Cin, T2H) * 2 * (T2 * T2H));
+    return h ? SLN_WEIGHTS_TILED256H : SLN_WEIGHTS_TILED256;
+}
+
 extern "C" int sln_conv_split_weights_f32(const float *w, int O, int I, int I_pad, int KH, int KW,
                                           long s_o, long s_i, long s_kh, long s_kw, int flip, int parts,
-                                          uint16_t *out, const float *q_scale, float *q_amax,
+                                          int layout, uint16_t *out, const float *q_scale, float *q_amax,
                                           int32_t *q_saturated, sln_stream_t stream) {
     sln_enter();
-    if (!w || O < 1 || I < 1 || I_pad < I || KH < 1 || KW < 1 || parts < 2 || parts > 3)
+    if (!w || O < 1 || I < 1 || I_pad < I || KH < 1 || KW < 1 || parts < 2 || parts > 3 || layout < 0 ||
+        layout > 2 || (layout == SLN_WEIGHTS_TILED256H && parts != 2))
         return SLN_ERR_INVALID_ARG;
     if (!out && !(parts == 2 && q_amax)) return SLN_ERR_INVALID_ARG;   // out == NULL: amax-only pass
-    const long total = (long)O * KH * KW * I_pad;
     const SplitScale q = {q_scale, q_amax, q_saturated};
+    if (layout == SLN_WEIGHTS_TILED256H) {
+        const long total = sln_conv_tiled_weight_elems(O, I, KH, KW, layout);
+        hipLaunchKernelGGL(split_weights_tiledh_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                           w, O, I, KH, KW, s_o, s_i, s_kh, s_kw, flip, (__bf16 *)out, q);
+        return sln_launch_status();
+    }
+    if (layout == SLN_WEIGHTS_TILED256) {
+        const long total = sln_conv_tiled_weight_elems(O, I, KH, KW, layout);
+        hipLaunchKernelGGL(split_weights_tiled_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                           w, O, I, KH, KW, s_o, s_i, s_kh, s_kw, flip, parts, (__bf16 *)out, q);
+        return sln_launch_status();
+    }
+    const long total = (long)O * KH * KW * I_pad;
     hipLaunchKernelGGL(split_weights_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, w, O,
                        I, I_pad, KH, KW, s_o, s_i, s_kh, s_kw, flip, parts, (__bf16 *)out, q);
     return sln_launch_status();
@@ -1308,8 +1752,8 @@ extern "C" int sln_conv_fwd_tile(int64_t M, int Cout, int64_t K, int parts) {
 }
 
 extern "C" int sln_conv2d_fwd_ms_f32(const uint16_t *x_parts, int nseg, const int32_t *seg_nhw, int Cin,
-                                     const uint16_t *w_parts, int parts, int Cout, int KH, int KW,
-                                     int stride_h, int stride_w, int dil_h, int dil_w, int pad_top,
+                                     const uint16_t *w_parts, int w_layout, int parts, int Cout, int KH,
+                                     int KW, int stride_h, int stride_w, int dil_h, int dil_w, int pad_top,
                                      int pad_left, int pad_bottom, int pad_right, const float *scale,
                                      const float *shift, const float *residual, int relu,
                                      const float *mask, const float *post_scale, float *y,
@@ -1355,17 +1799,29 @@ extern "C" int sln_conv2d_fwd_ms_f32(const uint16_t *x_parts, int nseg, const in
     p.sh = stride_h; p.sw = stride_w; p.dh = dil_h; p.dw = dil_w; p.pt = pad_top; p.pl = pad_left;
     p.relu = relu;
     p.M = (int)M;
+    p.dbg = sln_knob("SLN_CONV_DBG", 0);
     p.Ktot = KH * KW * Cin;
     p.x_part_stride = Min * Cin;
     p.w_part_stride = (long)Cout * p.Ktot;
     p.y_part_stride = M * p.Cop;
     p.cin_chunks = sln_div_up(Cin, BK);
     const bool use256 = sln_conv_fwd_tile(M, Cout, KH * KW * Cin, parts) == T2;
+    // the 256x256 kernel DMAs the weights in its own LDS-image order, the 128x128 kernel reads rows
+    if (w_layout != sln_conv_fwd_weights_layout(M, Cout, Cin, KH * KW, parts, Min)) return SLN_ERR_INVALID_ARG;
+    p.w_tiled = w_layout;
     const long gm2 = sln_div_up(M, T2), gn2 = sln_div_up(Cout, T2);
     const long nb2 = gm2 * gn2;
     if (use256) {
         p.gm = (int)gm2; p.gn = (int)gn2;
-        if (parts == 2)
+        if (w_layout == SLN_WEIGHTS_TILED256H) {
+            const bool stamp = sln_knob("SLN_CONV_STAMP", 0), four = sln_knob("SLN_CONV_PHASES", 2) == 4;
+            const dim3 g2((unsigned)nb2), b2(512);
+            if (stamp && four) hipLaunchKernelGGL((conv_fwd256h_kernel<true, 4>), g2, b2, 0, (hipStream_t)stream, p);
+            else if (stamp) hipLaunchKernelGGL((conv_fwd256h_kernel<true, 2>), g2, b2, 0, (hipStream_t)stream, p);
+            else if (four) hipLaunchKernelGGL((conv_fwd256h_kernel<false, 4>), g2, b2, 0, (hipStream_t)stream, p);
+            else hipLaunchKernelGGL((conv_fwd256h_kernel<false, 2>), g2, b2, 0, (hipStream_t)stream, p);
+        }
+        else if (parts == 2)
             hipLaunchKernelGGL(conv_fwd256_kernel<2>, dim3((unsigned)nb2), dim3(512), 0, (hipStream_t)stream, p);
         else
             hipLaunchKernelGGL(conv_fwd256_kernel<3>, dim3((unsigned)nb2), dim3(512), 0, (hipStream_t)stream, p);
@@ -1386,7 +1842,7 @@ extern "C" int sln_conv2d_fwd_ms_f32(const uint16_t *x_parts, int nseg, const in
 }
 
 extern "C" int sln_conv2d_fwd_f32(const uint16_t *x_parts, int N, int H, int W, int Cin,
-                                  const uint16_t *w_parts, int parts, int Cout, int KH, int KW,
+                                  const uint16_t *w_parts, int w_layout, int parts, int Cout, int KH, int KW,
                                   int stride_h, int stride_w, int dil_h, int dil_w, int pad_top,
                                   int pad_left, int OH, int OW, const float *scale, const float *shift,
                                   const float *residual, int relu, float *y, uint16_t *y_parts,
@@ -1401,7 +1857,7 @@ extern "C" int sln_conv2d_fwd_f32(const uint16_t *x_parts, int N, int H, int W, 
     const int32_t seg[3] = {N, H, W};
     const int pad_bottom = (OH - 1) * stride_h + dil_h * (KH - 1) + 1 - H - pad_top;
     const int pad_right = (OW - 1) * stride_w + dil_w * (KW - 1) + 1 - W - pad_left;
-    return sln_conv2d_fwd_ms_f32(x_parts, 1, seg, Cin, w_parts, parts, Cout, KH, KW, stride_h, stride_w,
+    return sln_conv2d_fwd_ms_f32(x_parts, 1, seg, Cin, w_parts, w_layout, parts, Cout, KH, KW, stride_h, stride_w,
                                  dil_h, dil_w, pad_top, pad_left, pad_bottom, pad_right, scale, shift,
                                  residual, relu, nullptr, nullptr, y, y_parts, nullptr, x_scale, w_scale,
                                  y_q_scale, y_q_amax, y_q_saturated, stream);

@@ -357,7 +357,7 @@ def test_tile256_kernel_is_deterministic_and_agrees_with_tile128(shape, tile_mod
     w = torch.randn(Cout, Cin, k, k, device="cuda", generator=g) / (Cin * k * k) ** 0.5
     pad = dil * (k - 1) // 2
     xp, _ = conv_hip.act_parts(x, 3)
-    wp, _ = conv_hip._split_weights(w, parts=3)
+    wp = conv_hip.wsrc(w, 3)
 
     def run():
         return conv_hip._fwd(xp, N, H, W, wp, Cout, k, k, (1, 1), (dil, dil), pad, pad, H, W, None, None,

@@ -43,14 +43,14 @@ for parts in (2, 3):
         x = torch.randn(N, Cin, H, W, device="cuda").contiguous(memory_format=torch.channels_last)
         w = torch.randn(Cout, Cin, k, k, device="cuda") * 0.05
         pad = d * (k - 1) // 2
-        wp, wq = conv_hip._split_weights(w)
+        wp = conv_hip.wsrc(w)
         OH = (H + 2 * pad - d * (k - 1) - 1) // s + 1
         fl = 2.0 * N * OH * OH * Cout * Cin * k * k
         xp, xq = conv_hip.act_parts(x)
         t_split = timeit(lambda: conv_hip._lib.check(conv_hip._lib.lib().sln_act_split_f32(
             conv_hip.ops._ptr(x), N * H * W, Cin, Cin, parts, conv_hip.ops._ptr(xp), conv_hip.ops._ptr(xq), None, None,
             conv_hip.ops._stream()), "s"))
-        t_hip = timeit(lambda: conv_hip._fwd(xp, N, H, W, wp, Cout, k, k, (s, s), (d, d), pad, pad, OH, OH, None, None, None, False, xq=xq, wq=wq))
+        t_hip = timeit(lambda: conv_hip._fwd(xp, N, H, W, wp, Cout, k, k, (s, s), (d, d), pad, pad, OH, OH, None, None, None, False, xq=xq))
         wcl = w.contiguous(memory_format=torch.channels_last)
         t_ref = timeit(lambda: F.conv2d(x, wcl, None, s, pad, d))
         gy = torch.randn(N, Cout, OH, OH, device="cuda").contiguous(memory_format=torch.channels_last)
