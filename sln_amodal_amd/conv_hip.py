@@ -68,8 +68,14 @@ class ScaleBook(object):
         return _Slot(self, self.n - 1)
 
     def update(self):
-        """Delayed scaling: every slot's next scale from the amax it recorded since the last call."""
+        """Delayed scaling: every slot's next scale from the amax it recorded since the last call.
+        Data-parallel replicas take the maximum over all ranks first (one small MAX all-reduce per
+        step), so that every rank derives the same scales and the replicas keep computing the same
+        function bit for bit (a rank-local power of two would round the fp16 parts differently)."""
         if self.n:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                dist.all_reduce(self.amax[:self.n], op=dist.ReduceOp.MAX)
             _lib.check(_lib.lib().sln_scale_update_f32(ops._ptr(self.amax), ops._ptr(self.scale), self.n,
                                                        SCALE_TARGET_LOG2, ops._stream()), "sln_scale_update_f32")
 

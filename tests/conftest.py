@@ -18,9 +18,14 @@ def pytest_configure(config):
 
 def pytest_collection_modifyitems(config, items):
     import torch
+    # a hard limit per test (pytest-timeout): a hung rank or kernel must not eat the GPU box
+    for item in items:
+        if item.get_closest_marker("timeout") is None:
+            item.add_marker(pytest.mark.timeout(900))
     if torch.cuda.is_available():
         return
     skip = pytest.mark.skip(reason="no GPU in this container")
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+

@@ -197,16 +197,27 @@ def test_multiscale_conv_is_bit_identical_to_per_scale_launches(case):
     for a, b in zip(out.tensors(), outs_seq):
         assert a.shape == b.shape
         assert torch.equal(a, b)
-    # the fused output parts feed the next layer: they must equal a fresh split of y
-    fresh, _ = conv_hip.MultiScale(out.segs, out.y).get_parts(out.parts.shape[0], owner=conv.weight)
-    assert torch.equal(out.parts[:, :, :Cout], fresh[:, :, :Cout])
-    assert not out.parts[:, :, Cout:].any()
+    # the fused output parts feed the next layer: they must encode y (3 x bf16: exactly a fresh split;
+    # 2 x fp16: sum of the parts / scale == y to 22 bits, whatever power of two the slot holds)
+    P = out.parts.shape[0]
+    if P == 3:
+        fresh, _ = conv_hip.MultiScale(out.segs, out.y).get_parts(3, owner=conv.weight)
+        assert torch.equal(out.parts[:, :, :Cout], fresh[:, :, :Cout])
+    else:
+        val = out.parts.view(torch.float16).double().sum(dim=0)[:, :Cout] / float(out.q)
+        assert ((val - out.y.double()).abs().max() / out.y.abs().max()).item() < 2 ** -20
+    assert not out.parts[:, :, Cout:].view(torch.int16).any()
 
 
-def test_msc_packed_forward_equals_sequential_scales():
-    """The GLM wrapper with all scales packed per layer returns exactly what the
-    reference-order loop over the scales returns (modal/msc_deeplab.py:29-45)."""
+@pytest.mark.parametrize("parts", [3, 2])
+def test_msc_packed_forward_equals_sequential_scales(parts, monkeypatch):
+    """The GLM wrapper with all scales packed per layer returns what the reference-order loop over
+    the scales returns (modal/msc_deeplab.py:29-45): bit for bit with 3 x bf16 operands; with 2 x fp16
+    the packed launch shares ONE power-of-two scale per tensor across the three image scales where
+    the sequential launches hold one each, so the parts round differently (2e-6 of the output)."""
+    from sln_amodal_amd import conv_hip
     from sln_amodal_amd.modal import msc_deeplab
+    monkeypatch.setattr(conv_hip, "PARTS", parts)
     from sln_amodal_amd.modal.deeplabv2 import DeepLabV2
     from tests._util import key_init_
     net = msc_deeplab.MSC(DeepLabV2(n_classes=21, n_blocks=[1, 2, 2, 1], atrous_rates=[2, 4, 6, 8]),
@@ -228,7 +239,11 @@ def test_msc_packed_forward_equals_sequential_scales():
             msc_deeplab.PACK_SCALES = True
     assert len(packed) == len(seq) == 4
     for a, b in zip(packed, seq):
-        assert a.shape == b.shape and torch.equal(a, b)
+        assert a.shape == b.shape
+        if parts == 3:
+            assert torch.equal(a, b)
+        else:
+            assert ((a - b).abs().max() / b.abs().max()).item() < 2e-6
 
 
 def test_identity_shortcut_gradient_link_matches_autograd_accumulation():
@@ -303,7 +318,8 @@ def test_chained_gradient_preparation_matches_separate_grad_prep(knob):
               ("CHAIN_BLOCK_OUTPUT", True): 10, ("CHAIN_BLOCK_OUTPUT", False): 8}
     res = {}
     saved = getattr(conv_hip, knob)
-    try:
+    net(x0.clone().requires_grad_(True)).backward(up)    # (2 x fp16: the gradient slots get their scales;
+    try:                                                 #  a chain needs its slot's history)
         for mode in (True, False):
             setattr(conv_hip, knob, mode)
             conv_hip.CHAIN_STATS[:] = [0, 0]
@@ -336,6 +352,7 @@ def test_chained_block_output_with_a_second_reader_fails_loudly():
             m.eval()
             m.weight.requires_grad = m.bias.requires_grad = False
     x = torch.randn(1, 128, 9, 9).cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    net(x).sum().backward()          # (2 x fp16: first pass bootstraps the gradient scales, chains start after)
     mid = net[0](x)
     out = net[1](mid)
     with pytest.raises(RuntimeError, match="second consumer"):
@@ -392,6 +409,8 @@ def test_two_reader_chain_of_the_rpn_heads_matches_autograd_accumulation():
     up_b = torch.randn(2, 19 * 23 * 3, 4, generator=g).cuda()
     res = {}
     saved = conv_hip.CHAIN_GRAD_PREP
+    lg0, _, bb0 = rpn(x0.clone().requires_grad_(True))
+    ((lg0 * up_l).sum() + (bb0 * up_b).sum()).backward()     # (2 x fp16: scale bootstrap pass)
     try:
         for mode in (True, False):
             conv_hip.CHAIN_GRAD_PREP = mode

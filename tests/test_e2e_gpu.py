@@ -284,7 +284,7 @@ def test_head_gradients_match_reference_modules():
         deep = n.startswith(("conv1", "bn1"))
         _grad_close(cp[n].grad, g["cls_g/" + n], float(g["cls_gn/" + n]), "classifier." + n, 5e-3 if deep else 1e-4)
     for n in [str(s) for s in g["mask_names"]]:
-        deep = n.startswith(("conv1", "conv2", "conv3", "conv4"))
+        deep = n.startswith(("conv1", "conv2", "conv3", "conv4", "deconv"))
         _grad_close(mpar[n].grad, g["mask_g/" + n], float(g["mask_gn/" + n]), "mask." + n, 5e-3 if deep else 1e-4)
 
 

@@ -65,7 +65,8 @@ def _worker(rank, world, port, out):
     dist.all_gather(gathered, digest)
     print("rank", rank, "digests", [g.tolist() for g in gathered], flush=True)
     assert torch.equal(gathered[0][:3], gathered[1][:3]), (rank, gathered)            # state: bit-identical
-    # forward: equal up to the stem's aten/MIOpen convolution, whose algorithm choice is per process
+    # forward: equal up to the stem's aten/MIOpen convolution, whose algorithm choice is per process (the
+    # operand scales are the same on every rank: ScaleBook.update takes the maximum over the ranks)
     assert torch.allclose(gathered[0][3:], gathered[1][3:], rtol=1e-4, atol=0), (rank, gathered)   # stale caches: O(1) off
     dist.destroy_process_group()
     out.put(rank)
@@ -79,7 +80,7 @@ def test_two_rank_train_steps_keep_replicas_identical():
     for p in procs:
         p.start()
     for p in procs:
-        p.join(600)
+        p.join(300)
     for p in procs:
         if p.is_alive():
             p.terminate()
