@@ -202,7 +202,8 @@ int sln_pyramid_crop_bwd_f32(const float *grads, int g_cstride, int g_coffset, c
  *     fp32 gradient itself is still needed (it is that layer's shortcut gradient).
  * sln_conv2d_wgrad_f32        gw [Cout][KH][KW][Cin] fp32 (zeroed by the callee) =
  *     sum over output pixels of gz[pix][co] * x[pix @ tap][ci]; split-K over pixel
- *     ranges with fp32 atomics (summation order not deterministic).
+ *     ranges, summed in range order through a caller-lent workspace (or with fp32
+ *     atomics when none is given).
  *
  * Operand formats.  parts = 3: three bf16 parts per fp32 value, six part products per
  * fp32 product.  parts = 2 ("scaled split-fp16"): two fp16 parts of v*s, s a per-tensor
@@ -268,11 +269,15 @@ int sln_conv2d_fwd_ms_f32(const uint16_t *x_parts, int nseg, const int32_t *seg_
 int sln_conv_fwd_tile(int64_t M, int Cout, int64_t K, int parts);
 /* Tile edge (128 or 256) of the weight-gradient kernel sln_conv2d_wgrad_f32 uses (host-side rule). */
 int sln_conv_wgrad_tile(int64_t M, int Cout, int Cin, int taps, int parts);
+/* workspace (optional): sln_conv_wgrad_workspace_bytes() bytes lent by the caller make the split-K
+ * sum two-phase -- every pixel range stores its partial gradient, a second kernel adds the ranges in
+ * order: bit-reproducible, no atomics.  NULL: fp32 atomics (summation order not deterministic). */
+size_t sln_conv_wgrad_workspace_bytes(int64_t M, int Cout, int Cin, int taps, int parts);
 int sln_conv2d_wgrad_f32(const uint16_t *gz_parts, int Cout, int Cout_pad, const uint16_t *x_parts,
                          int N, int H, int W, int Cin, int Cin_pad, int parts, int KH, int KW,
                          int stride_h, int stride_w, int dil_h, int dil_w, int pad_top, int pad_left,
                          int OH, int OW, float *gw, const float *gz_scale, const float *x_scale,
-                         sln_stream_t stream);
+                         void *workspace, size_t workspace_bytes, sln_stream_t stream);
 
 #ifdef __cplusplus
 }

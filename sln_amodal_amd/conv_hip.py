@@ -35,6 +35,9 @@ CHAIN_BLOCK_OUTPUT = os.environ.get("SLN_CHAIN_BLOCK_OUTPUT", "1") != "0"      #
 CHAIN_STATS = [0, 0]  # prepared gradients handed over by consumers / used by producers
 LINK_STATS = [0, 0]   # shortcut gradients handed over by tails / consumed by heads
 FUSE_OUTPUT_SPLIT = True   # conv epilogue writes the output's parts (skips the next act_split)
+# weight gradients: split-K partial sums through a workspace + ordered reduce (bit-reproducible) instead of
+# fp32 atomics; "0" restores the atomics for A/B runs
+DETERMINISTIC_WGRAD = os.environ.get("SLN_DETERMINISTIC_WGRAD", "1") != "0"
 _cache = _NoCache()   # kept for tools that call _cache.clear(); caches live on the tensors
 
 
@@ -646,14 +649,19 @@ class _ConvFn(torch.autograd.Function):
                 raise NotImplementedError("data gradient of a strided %dx%d conv" % (KH, KW))
         if need_w:
             gw_t = torch.empty((Co, KH, KW, Ci), dtype=torch.float32, device=weight.device)
+            ws, ws_bytes = None, 0
+            if DETERMINISTIC_WGRAD:     # two-phase split-K through a lent workspace: no atomics
+                ws_bytes = _lib.lib().sln_conv_wgrad_workspace_bytes(N * OH * OW, Co, Ci, KH * KW, parts)
+                ws = ops._workspace(max(ws_bytes, 16), weight.device)
             e0 = _prof_begin()
             _lib.check(_lib.lib().sln_conv2d_wgrad_f32(
                 ops._ptr(gz), Co, gz.shape[2], ops._ptr(xp), N, H, W, Ci, xp.shape[2], parts, KH, KW,
                 stride[0], stride[1], dil[0], dil[1], pt, pl, OH, OW, ops._ptr(gw_t), ops._ptr(gzq),
-                ops._ptr(xq), ops._stream()), "sln_conv2d_wgrad_f32")
+                ops._ptr(xq), ops._ptr(ws), ws_bytes, ops._stream()), "sln_conv2d_wgrad_f32")
             wt_ = _lib.lib().sln_conv_wgrad_tile(N * OH * OW, Co, Ci, KH * KW, parts) if e0 is not None else 128
             _prof_end(e0, 2.0 * N * OH * OW * Co * KH * KW * Ci,
-                      ("conv_wgrad256_kernel<%d>" if wt_ == 256 else "conv_wgrad_kernel<%d>") % parts,
+                      ("conv_wgrad256h_kernel" if (wt_ == 256 and parts == 2) else
+                       ("conv_wgrad256_kernel<%d>" if wt_ == 256 else "conv_wgrad_kernel<%d>") % parts),
                       "wgrad N%d %dx%d C%d->%d k%d s%d d%d" % (N, H, W, Ci, Co, KH, stride[0], dil[0]),
                       _nbytes(gz, xp), _nbytes(gw_t))
             gw = gw_t.permute(0, 3, 1, 2)  # logical [Co,Ci,KH,KW]

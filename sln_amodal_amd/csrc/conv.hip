@@ -1285,6 +1285,8 @@ struct WgradParams {
     int N, H, W, Cin, Cip, Cout, Cop, KH, KW, sh, sw, dh, dw, pt, pl, OH, OW;
     int M, gm, gn_per_tap, ksplit, pix_per_split, xcd_wgrad;
     const float *gz_scale, *x_scale;   // P = 2: operand scales (device scalars, NULL = 1)
+    float *partial;   // two-phase split-K: [ksplit][Cout][KH*KW][Cin] slabs, one per pixel range, plain
+                      // stores (every element of a slab is written by exactly one block); NULL = atomics
 };
 
 template <int LD>
@@ -1423,7 +1425,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
                 const int co = m0 + wr * (TM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (co >= p.Cout) continue;
                 const float v = acc[i][j][r] * alpha;
-                if (v != 0.f) atomicAdd(p.gw + ((long)co * p.KH * p.KW + tap) * p.Cin + ci, v);
+                const long e = ((long)co * p.KH * p.KW + tap) * p.Cin + ci;
+                if (p.partial) p.partial[(long)split * ((long)p.Cout * p.KH * p.KW * p.Cin) + e] = v;
+                else if (v != 0.f) atomicAdd(p.gw + e, v);
             }
     }
 }
@@ -1605,9 +1609,283 @@ __global__ __launch_bounds__(512) void conv_wgrad256_kernel(const WgradParams p)
                 const int co = m0 + wr * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (co >= p.Cout) continue;
                 const float v = acc[i][j][r] * alpha;
-                if (v != 0.f) atomicAdd(p.gw + ((long)co * p.KH * p.KW + tap) * p.Cin + ci, v);
+                const long e = ((long)co * p.KH * p.KW + tap) * p.Cin + ci;
+                if (p.partial) p.partial[(long)split * ((long)p.Cout * p.KH * p.KW * p.Cin) + e] = v;
+                else if (v != 0.f) atomicAdd(p.gw + e, v);
             }
     }
+}
+
+// ---------------------------------------------------------------- 256x256 weight-gradient tile, fp16 x 2
+// conv_wgrad256_kernel on the structure of conv_fwd256h_kernel: 32-pixel stages (two 64-KB buffers),
+// buffer-load DMA with range-check zero fill and 32-bit offsets computed once per stage (exact integer
+// division by float reciprocal instead of two 64-bit divisions per piece), two wave groups half a
+// phase apart.  A phase = one 16-pixel sub-block: 24 transposing fragment reads, 24 MFMAs.
+__device__ __forceinline__ int div_small(int a, int d, float rd) {   // a < 2^24, exact
+    int q = (int)((float)a * rd);
+    const int r = a - q * d;
+    q += (r >= d) - (r < 0);
+    return q;
+}
+
+__global__ __launch_bounds__(512) void conv_wgrad256h_kernel(const WgradParams p) {
+    constexpr int P = 2;
+    constexpr int KS = 32;                       // pixels per stage
+    constexpr int REGION = KS * T2 * 2;          // one part of one operand: 32 pixel rows x 512 B = 16 KB
+    constexpr int STAGE = 2 * P * REGION;        // 64 KB
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];   // ONE LDS object
+    typedef __attribute__((address_space(3))) void lds_void;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int wr = wave >> 2, wc = wave & 3;
+    const int ntile = p.gm * p.gn_per_tap * p.KH * p.KW;
+    int bid = p.xcd_wgrad ? xcd_remap(blockIdx.x, ntile * p.ksplit) : (int)blockIdx.x;
+    const int split = bid / ntile;
+    bid -= split * ntile;
+    const int mt = bid % p.gm;
+    int rest = bid / p.gm;
+    const int nt = rest % p.gn_per_tap;
+    const int tap = rest / p.gn_per_tap;
+    const int kh = tap / p.KW, kw = tap - kh * p.KW;
+    const int m0 = mt * T2, n0 = nt * T2;
+    const int pix_begin = split * p.pix_per_split;
+    const int pix_end = min(p.M, pix_begin + p.pix_per_split);
+    const int nk = (pix_end - pix_begin + KS - 1) / KS;
+
+    // DMA slots: pixel rows 4*wave + 2*j + lane/32 (j = 0, 1) of every region, 16-B chunk lane%32; the
+    // chunk FETCHED is swizzled with the row's low two bits (= 2j + lane/32)
+    const int hrow = lane >> 5;
+    unsigned a_col[2], b_col[2];       // byte offset of the fetched channels inside a gz / x pixel row, or OOB
+    int drow[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        drow[j] = 4 * wave + 2 * j + hrow;
+        const int ch = ((lane & 31) ^ ((2 * j + hrow) << 2)) * 8;
+        a_col[j] = (m0 + ch) < p.Cop ? (unsigned)(m0 + ch) * 2u : 0xFFFFFFFFu;
+        b_col[j] = (n0 + ch) < p.Cip ? (unsigned)(n0 + ch) * 2u : 0xFFFFFFFFu;
+    }
+    const unsigned gz_bytes = (unsigned)(p.gz_part_stride * 2), x_bytes = (unsigned)(p.x_part_stride * 2);
+    const __amdgpu_buffer_rsrc_t ra0 = __builtin_amdgcn_make_buffer_rsrc((void *)p.gz, 0, (int)gz_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ra1 = __builtin_amdgcn_make_buffer_rsrc((void *)(p.gz + p.gz_part_stride), 0,
+                                                                         (int)gz_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb0 = __builtin_amdgcn_make_buffer_rsrc((void *)p.x, 0, (int)x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb1 = __builtin_amdgcn_make_buffer_rsrc((void *)(p.x + p.x_part_stride), 0,
+                                                                         (int)x_bytes, 0x00020000);
+    const int ohw = p.OH * p.OW;
+    const float r_ohw = 1.0f / (float)ohw, r_ow = 1.0f / (float)p.OW;
+
+    int n_s = 0;                       // the stage whose DMA is issued next
+    unsigned a_voff[2], b_voff[2];
+    auto stage_offsets = [&]() {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int pix = pix_begin + n_s * KS + drow[j];
+            const bool pok = pix < pix_end;
+            const int pp_ = pok ? pix : 0;
+            const int n = div_small(pp_, ohw, r_ohw);
+            const int rem = pp_ - n * ohw;
+            const int oh = div_small(rem, p.OW, r_ow), ow = rem - oh * p.OW;
+            const int ih = oh * p.sh - p.pt + kh * p.dh, iw = ow * p.sw - p.pl + kw * p.dw;
+            const bool xok = pok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+            a_voff[j] = (pok && a_col[j] != 0xFFFFFFFFu) ? (unsigned)pix * (unsigned)(p.Cop * 2) + a_col[j] : 0xFFFFFFFFu;
+            b_voff[j] = (xok && b_col[j] != 0xFFFFFFFFu)
+                            ? (unsigned)((n * p.H + ih) * p.W + iw) * (unsigned)(p.Cip * 2) + b_col[j] : 0xFFFFFFFFu;
+        }
+    };
+    // piece g (0..7): bit 2 = operand (0 gz, 1 x), bit 1 = part, bit 0 = row pair j
+    auto issue_piece = [&](int g) {
+        unsigned char *dst = smem + (n_s & 1) * STAGE + ((g >> 1) & 3) * REGION + (4 * wave + 2 * (g & 1)) * 512;
+        const int pp = (g >> 1) & 1, j = g & 1;
+        if (g < 4)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(pp ? ra1 : ra0, (lds_void *)dst, 16, a_voff[j], 0, 0, 0);
+        else
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(pp ? rb1 : rb0, (lds_void *)dst, 16, b_voff[j], 0, 0, 0);
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int g4 = lane >> 4;
+    const int k0 = 8 * (g4 >> 1);
+    const int cb = 64 * wc + 16 * (g4 & 1), ca = 128 * wr + 16 * (g4 & 1);
+    if (nk > 0) {
+        stage_offsets();
+#pragma unroll
+        for (int g = 0; g < 8; ++g) issue_piece(g);
+        n_s = 1;
+        if (nk > 1) stage_offsets();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();      // the second wave group runs one barrier behind
+    asm volatile("" ::: "memory");
+
+    typedef __attribute__((address_space(3))) unsigned char lds_u8;
+    for (int s = 0; s < nk; ++s) {
+        const unsigned st = (unsigned)(size_t)(lds_u8 *)(smem + (s & 1) * STAGE);
+        const bool more = s + 1 < nk;
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph) {
+            TrFrag fa[4][P], fb[2][P];
+            const int kk = 16 * ph + k0;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int pp = 0; pp < P; ++pp) tr_issue(fb[j][pp], st + (P + pp) * REGION, kk, cb + 32 * j, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int pp = 0; pp < P; ++pp) tr_issue(fa[i][pp], st + pp * REGION, kk, ca + 32 * i, lane);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more && ph == 0) {
+#pragma unroll
+                for (int g = 0; g < 8; ++g) issue_piece((g >> 1) | ((g & 1) << 2));
+            }
+            if (ph == 1) {
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                ++n_s;
+                if (s + 2 < nk) stage_offsets();
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            bf16x8 a[4][P], b[2][P];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int pp = 0; pp < P; ++pp) b[j][pp] = tr_value(fb[j][pp]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int pp = 0; pp < P; ++pp) a[i][pp] = tr_value(fa[i][pp]);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) mfma_products<P>(a[i], b[j], acc[i][j]);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();      // re-align the two groups
+
+    // epilogue: row = co, col = ci; partial slab (two-phase split-K) or atomics
+    const float alpha = operand_unscale(p.gz_scale, p.x_scale);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int ci = n0 + wc * 64 + j * 32 + (lane & 31);
+        if (ci >= p.Cin) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = m0 + wr * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (co >= p.Cout) continue;
+                const float v = acc[i][j][r] * alpha;
+                const long e = ((long)co * p.KH * p.KW + tap) * p.Cin + ci;
+                if (p.partial) p.partial[(long)split * ((long)p.Cout * p.KH * p.KW * p.Cin) + e] = v;
+                else if (v != 0.f) atomicAdd(p.gw + e, v);
+            }
+    }
+}
+
+// Second phase of the split-K weight gradient: gw[e] = sum over the pixel ranges, in range order --
+// the same sum on every run (fp32 atomics arrive in any order), and plain stores instead of ~8 GB of
+// atomic traffic per step.  One thread per 4 elements when the count allows.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ partial, int ksplit,
+                                                           long n, float *__restrict__ gw) {
+    // 32 element quads x 8 range lanes per block: lane kl adds the ranges kl, kl+8, ... in order, the
+    // eight sums are then added in lane order -- a fixed summation tree, whatever the launch timing
+    __shared__ float4 s_part[8][32];
+    const int q = threadIdx.x & 31, kl = threadIdx.x >> 5;
+    const long i4 = ((long)blockIdx.x * 32 + q) * 4;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i4 < n) {
+        if (i4 + 3 < n && (n & 3) == 0) {
+            int sidx = kl;
+            for (; sidx + 24 < ksplit; sidx += 32) {       // four loads in flight
+                const float4 b0 = *(const float4 *)(partial + (long)sidx * n + i4);
+                const float4 b1 = *(const float4 *)(partial + (long)(sidx + 8) * n + i4);
+                const float4 b2 = *(const float4 *)(partial + (long)(sidx + 16) * n + i4);
+                const float4 b3 = *(const float4 *)(partial + (long)(sidx + 24) * n + i4);
+                a.x += b0.x; a.y += b0.y; a.z += b0.z; a.w += b0.w;
+                a.x += b1.x; a.y += b1.y; a.z += b1.z; a.w += b1.w;
+                a.x += b2.x; a.y += b2.y; a.z += b2.z; a.w += b2.w;
+                a.x += b3.x; a.y += b3.y; a.z += b3.z; a.w += b3.w;
+            }
+            for (; sidx < ksplit; sidx += 8) {
+                const float4 b = *(const float4 *)(partial + (long)sidx * n + i4);
+                a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+            }
+        } else {
+            float t4[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int sidx = kl; sidx < ksplit; sidx += 8)
+                for (int e = 0; e < 4; ++e)
+                    if (i4 + e < n) t4[e] += partial[(long)sidx * n + i4 + e];
+            a = make_float4(t4[0], t4[1], t4[2], t4[3]);
+        }
+    }
+    s_part[kl][q] = a;
+    __syncthreads();
+    if (kl == 0 && i4 < n) {
+        float4 r = s_part[0][q];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) {
+            const float4 b = s_part[k][q];
+            r.x += b.x; r.y += b.y; r.z += b.z; r.w += b.w;
+        }
+        if (i4 + 3 < n) *(float4 *)(gw + i4) = r;
+        else {
+            const float t4[4] = {r.x, r.y, r.z, r.w};
+            for (int e = 0; e < 4 && i4 + e < n; ++e) gw[i4 + e] = t4[e];
+        }
+    }
+}
+
+static inline int sln_knob(const char *name, int dflt);
+// Split-K plan of sln_conv2d_wgrad_f32 (pure host function of the problem).
+struct WgradPlan { int tile, gm, gn, ksplit, pps, tm, tn; };
+static WgradPlan wgrad_plan(long M, int Cout, int Cin, int taps, int parts) {
+    WgradPlan w;
+    w.tile = sln_conv_wgrad_tile(M, Cout, Cin, taps, parts);
+    if (w.tile == T2) {
+        const long gm2 = sln_div_up(Cout, T2), gn2 = sln_div_up(Cin, T2), nt2 = gm2 * gn2 * taps;
+        long ks2 = 256 / nt2;                         // one round of the 256 CUs
+        const long cap = (M + 255) / 256;             // >= 16 stages per block
+        if (ks2 > cap) ks2 = cap;
+        if (ks2 < 1) ks2 = 1;
+        long pps2 = (M + ks2 - 1) / ks2;
+        pps2 = ((pps2 + 31) / 32) * 32;
+        ks2 = (M + pps2 - 1) / pps2;
+        w.gm = (int)gm2; w.gn = (int)gn2; w.ksplit = (int)ks2; w.pps = (int)pps2; w.tm = w.tn = T2;
+        return w;
+    }
+    const bool t64 = sln_knob("SLN_WGRAD_T64", 1) != 0;        // 0 disables the 64-wide sides
+    w.tm = (t64 && Cout <= 64) ? 64 : BM; w.tn = (t64 && Cin <= 64) ? 64 : BN;
+    w.gm = sln_div_up(Cout, w.tm);
+    w.gn = sln_div_up(Cin, w.tn);
+    const long ntile = (long)w.gm * w.gn * taps;
+    // split the pixel range: ~24 blocks per CU (short blocks balance the tail; swept 2..32
+    // on the train step), but at least 1024 pixels (32 k-steps) per block
+    long ks = (256L * 24 + ntile - 1) / ntile;
+    const long max_ks = (M + 1023) / 1024;
+    if (ks > max_ks) ks = max_ks;
+    if (ks < 1) ks = 1;
+    long pps = (M + ks - 1) / ks;
+    pps = ((pps + BK - 1) / BK) * BK;
+    ks = (M + pps - 1) / pps;
+    w.ksplit = (int)ks; w.pps = (int)pps;
+    return w;
 }
 
 // ---------------------------------------------------------------- C ABI
@@ -1878,79 +2156,76 @@ extern "C" int sln_conv_wgrad_tile(int64_t M, int Cout, int Cin, int taps, int p
     return (wide && nt2 <= 256 && M >= 256L * 64) ? T2 : BM;
 }
 
+extern "C" size_t sln_conv_wgrad_workspace_bytes(int64_t M, int Cout, int Cin, int taps, int parts) {
+    if (M < 1 || Cout < 1 || Cin < 1 || taps < 1) return 0;
+    const WgradPlan w = wgrad_plan(M, Cout, Cin, taps, parts);
+    return w.ksplit > 1 ? sizeof(float) * (size_t)w.ksplit * Cout * taps * Cin : 0;
+}
+
 extern "C" int sln_conv2d_wgrad_f32(const uint16_t *gz_parts, int Cout, int Cout_pad,
                                     const uint16_t *x_parts, int N, int H, int W, int Cin, int Cin_pad,
                                     int parts, int KH, int KW, int stride_h, int stride_w, int dil_h,
                                     int dil_w, int pad_top, int pad_left, int OH, int OW, float *gw,
-                                    const float *gz_scale, const float *x_scale, sln_stream_t stream) {
+                                    const float *gz_scale, const float *x_scale, void *workspace,
+                                    size_t workspace_bytes, sln_stream_t stream) {
     sln_enter();
     if (!gz_parts || !x_parts || !gw || N < 0 || H < 1 || W < 1 || Cin < 1 || Cout < 1 || KH < 1 || KW < 1 ||
         OH < 1 || OW < 1 || Cin_pad < Cin || Cout_pad < Cout || (Cin_pad & 7) || (Cout_pad & 7))
         return SLN_ERR_INVALID_ARG;
     if (parts != 2 && parts != 3) return SLN_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(gw, 0, sizeof(float) * (size_t)Cout * KH * KW * Cin, st) != hipSuccess)
+    const long M = (long)N * OH * OW;
+    const size_t gw_elems = (size_t)Cout * KH * KW * Cin;
+    if (N == 0) return hipMemsetAsync(gw, 0, sizeof(float) * gw_elems, st) == hipSuccess ? SLN_OK : SLN_ERR_LAUNCH;
+    if (M > 2147483647L - BK) return SLN_ERR_UNSUPPORTED;
+    const WgradPlan w = wgrad_plan(M, Cout, Cin, KH * KW, parts);
+    // two-phase (deterministic) when the caller lends a workspace; fp32 atomics into the zeroed gw else
+    const size_t need = w.ksplit > 1 ? sizeof(float) * (size_t)w.ksplit * gw_elems : 0;
+    const bool two_phase = workspace != nullptr && w.ksplit > 1;
+    if (two_phase && workspace_bytes < need) return SLN_ERR_WORKSPACE;
+    const bool direct = w.ksplit == 1 && workspace != nullptr;     // a single pixel range: plain stores into gw
+    if (!two_phase && !direct &&
+        hipMemsetAsync(gw, 0, sizeof(float) * gw_elems, st) != hipSuccess)
         return SLN_ERR_LAUNCH;
-    if (N == 0) return SLN_OK;
     WgradParams p;
     p.gz = (const __bf16 *)gz_parts; p.x = (const __bf16 *)x_parts; p.gw = gw;
     p.gz_scale = gz_scale; p.x_scale = x_scale;
+    p.partial = two_phase ? (float *)workspace : (direct ? gw : nullptr);
     p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cip = Cin_pad; p.Cout = Cout; p.Cop = Cout_pad;
     p.KH = KH; p.KW = KW; p.sh = stride_h; p.sw = stride_w; p.dh = dil_h; p.dw = dil_w;
     p.pt = pad_top; p.pl = pad_left; p.OH = OH; p.OW = OW;
-    const long M = (long)N * OH * OW;
-    if (M > 2147483647L - BK) return SLN_ERR_UNSUPPORTED;
     p.M = (int)M;
     p.gz_part_stride = M * Cout_pad;
     p.x_part_stride = (long)N * H * W * Cin_pad;
-    {
-        const long gm2 = sln_div_up(Cout, T2), gn2 = sln_div_up(Cin, T2);
-        const long nt2 = gm2 * gn2 * KH * KW;
-        if (sln_conv_wgrad_tile(M, Cout, Cin, KH * KW, parts) == T2) {
-            long ks2 = 256 / nt2;                         // one round of the 256 CUs
-            const long cap = (M + 255) / 256;             // >= 16 stages per block
-            if (ks2 > cap) ks2 = cap;
-            if (ks2 < 1) ks2 = 1;
-            long pps2 = (M + ks2 - 1) / ks2;
-            pps2 = ((pps2 + T2K - 1) / T2K) * T2K;
-            ks2 = (M + pps2 - 1) / pps2;
-            p.gm = (int)gm2; p.gn_per_tap = (int)gn2; p.ksplit = (int)ks2; p.pix_per_split = (int)pps2;
-            p.xcd_wgrad = sln_knob("SLN_WGRAD_XCD", 1);
-            const long nb2 = nt2 * ks2;
-            if (parts == 2)
-                hipLaunchKernelGGL(conv_wgrad256_kernel<2>, dim3((unsigned)nb2), dim3(512), 0, st, p);
-            else
-                hipLaunchKernelGGL(conv_wgrad256_kernel<3>, dim3((unsigned)nb2), dim3(512), 0, st, p);
-            return sln_launch_status();
-        }
-    }
-    const bool t64 = sln_knob("SLN_WGRAD_T64", 1) != 0;        // 0 disables the 64-wide sides
-    const int TMs = (t64 && Cout <= 64) ? 64 : BM, TNs = (t64 && Cin <= 64) ? 64 : BN;
-    p.gm = sln_div_up(Cout, TMs);
-    p.gn_per_tap = sln_div_up(Cin, TNs);
-    const long ntile = (long)p.gm * p.gn_per_tap * KH * KW;
-    // split the pixel range: ~24 blocks per CU (short blocks balance the tail; swept 2..32
-    // on the train step), but at least 1024 pixels (32 k-steps) per block
-    long ks = (256L * 24 + ntile - 1) / ntile;
-    const long max_ks = (M + 1023) / 1024;
-    if (ks > max_ks) ks = max_ks;
-    if (ks < 1) ks = 1;
-    long pps = (M + ks - 1) / ks;
-    pps = ((pps + BK - 1) / BK) * BK;
-    ks = (M + pps - 1) / pps;
-    p.ksplit = (int)ks;
-    p.pix_per_split = (int)pps;
-    const long nblk = ntile * ks;
+    p.gm = w.gm; p.gn_per_tap = w.gn; p.ksplit = w.ksplit; p.pix_per_split = w.pps;
+    p.xcd_wgrad = sln_knob("SLN_WGRAD_XCD", 1);
+    const long nblk = (long)w.gm * w.gn * KH * KW * w.ksplit;
     if (nblk > 2147483647L) return SLN_ERR_UNSUPPORTED;
-    const dim3 g((unsigned)nblk), b(256);
-#define SLN_WG(PP, A, B) hipLaunchKernelGGL((conv_wgrad_kernel<PP, A, B>), g, b, 0, st, p)
-    if (parts == 2) {
-        if (TMs == 64 && TNs == 64) SLN_WG(2, 64, 64); else if (TMs == 64) SLN_WG(2, 64, 128);
-        else if (TNs == 64) SLN_WG(2, 128, 64); else SLN_WG(2, 128, 128);
+    if (w.tile == T2) {
+        // the fp16 kernel addresses with 32-bit byte offsets and divides pixel indices in fp32
+        const bool h = parts == 2 && sln_knob("SLN_WGRAD_F16_KERNEL", 1) && M < (1L << 24) &&
+                       p.gz_part_stride * 2 < 4294967295L && p.x_part_stride * 2 < 4294967295L;
+        if (h)
+            hipLaunchKernelGGL(conv_wgrad256h_kernel, dim3((unsigned)nblk), dim3(512), 0, st, p);
+        else if (parts == 2)
+            hipLaunchKernelGGL(conv_wgrad256_kernel<2>, dim3((unsigned)nblk), dim3(512), 0, st, p);
+        else
+            hipLaunchKernelGGL(conv_wgrad256_kernel<3>, dim3((unsigned)nblk), dim3(512), 0, st, p);
     } else {
-        if (TMs == 64 && TNs == 64) SLN_WG(3, 64, 64); else if (TMs == 64) SLN_WG(3, 64, 128);
-        else if (TNs == 64) SLN_WG(3, 128, 64); else SLN_WG(3, 128, 128);
-    }
+        const dim3 g((unsigned)nblk), b(256);
+        const int TMs = w.tm, TNs = w.tn;
+#define SLN_WG(PP, A, B) hipLaunchKernelGGL((conv_wgrad_kernel<PP, A, B>), g, b, 0, st, p)
+        if (parts == 2) {
+            if (TMs == 64 && TNs == 64) SLN_WG(2, 64, 64); else if (TMs == 64) SLN_WG(2, 64, 128);
+            else if (TNs == 64) SLN_WG(2, 128, 64); else SLN_WG(2, 128, 128);
+        } else {
+            if (TMs == 64 && TNs == 64) SLN_WG(3, 64, 64); else if (TMs == 64) SLN_WG(3, 64, 128);
+            else if (TNs == 64) SLN_WG(3, 128, 64); else SLN_WG(3, 128, 128);
+        }
 #undef SLN_WG
+    }
+    if (two_phase)
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((gw_elems + 127) / 128)), dim3(256), 0, st,
+                           (const float *)workspace, w.ksplit, (long)gw_elems, gw);
     return sln_launch_status();
 }

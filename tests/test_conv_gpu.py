@@ -592,3 +592,33 @@ def test_bottleneck_stack_gradients_match_fp64_in_both_formats(parts, monkeypatc
     for k, p in ref.named_parameters():
         if p.grad is not None:
             assert rl2(got[k], p.grad) < 2e-5, (k, rl2(got[k], p.grad))
+
+
+@pytest.mark.parametrize("parts", [2, 3])
+@pytest.mark.parametrize("shape", [(4, 64, 64, 48, 48, 3), (2, 256, 256, 72, 72, 3), (3, 64, 256, 56, 56, 1)])
+def test_weight_gradient_is_bit_reproducible(parts, shape, monkeypatch):
+    """Two-phase split-K (per-range partial sums through a workspace, added in range order): the same
+    bits on every run for both tile sizes -- fp32 atomics gave run-to-run differences -- and equal to
+    the atomic path up to summation order."""
+    from sln_amodal_amd import conv_hip
+    monkeypatch.setattr(conv_hip, "PARTS", parts)
+    N, Cin, Cout, H, W, k = shape
+    g = torch.Generator(device="cuda").manual_seed(Cin + Cout + k)
+    x = torch.randn(N, Cin, H, W, device="cuda", generator=g).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(Cout, Cin, k, k, device="cuda", generator=g) / (Cin * k * k) ** 0.5).requires_grad_(True)
+    up = torch.randn(N, Cout, H, W, device="cuda", generator=g).contiguous(memory_format=torch.channels_last)
+
+    def grad():
+        w.grad = None
+        y = conv_hip._ConvFn.apply(x, w, None, None, None, None, False, (1, 1), (1, 1), (k // 2,) * 4)
+        y.backward(up)
+        return w.grad.clone()
+
+    grad()                                   # (2 x fp16: scale bootstrap)
+    monkeypatch.setattr(conv_hip, "DETERMINISTIC_WGRAD", True)
+    first = grad()
+    for _ in range(10):
+        assert torch.equal(grad(), first)
+    monkeypatch.setattr(conv_hip, "DETERMINISTIC_WGRAD", False)
+    atomic = grad()
+    assert torch.allclose(atomic, first, rtol=1e-4, atol=1e-5 * float(first.abs().max()))
