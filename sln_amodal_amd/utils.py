@@ -57,20 +57,34 @@ def compute_overlaps(boxes1, boxes2):
     return inter / (a2[None, :] + a1[:, None] - inter)
 
 
-def reLayerMask(mask_amodal, mask_invis):
-    """Encoder of the on-disk uint64 'layer' label (utils.py:531-557, without the
-    skimage small-component pruning): low word bit i = object i visible, high word
-    bit i = object i present but occluded.  At most 32 objects."""
+def reLayerMask(mask_amodal, mask_invis, min_size=64):
+    """Encoder of the on-disk uint64 'layer' label (utils.py:531-547): low word bit i = object i
+    visible, high word bit i = object i present but occluded; at most 32 objects; followed by the
+    reference's small-region pruning (remove_small_path).  mask_invis[i] may be empty (no occlusion)."""
     label = np.zeros(np.asarray(mask_amodal[0]).shape, dtype=np.uint64)
     for i in range(min(len(mask_amodal), 32)):
-        am = np.asarray(mask_amodal[i]) > 0
+        am = np.asarray(mask_amodal[i])
         if len(mask_invis[i]):
-            inv = np.asarray(mask_invis[i]) > 0
-            label[inv] |= np.uint64(1) << np.uint64(i + 32)
-            vis = am & ~inv
+            inv = np.asarray(mask_invis[i])
+            label[inv > 0] |= np.uint64(1) << np.uint64(i + 32)
+            vis = (am - inv) > 0           # arithmetic difference, like the reference (utils.py:540)
         else:
-            vis = am
+            vis = am > 0
         label[vis] |= np.uint64(1) << np.uint64(i)
+    return remove_small_path(label, min_size=min_size)
+
+
+def remove_small_path(label, min_size=64):
+    """utils.py:550-557: a label VALUE whose regions are all smaller than min_size pixels
+    (4-connected components, skimage.morphology.remove_small_objects semantics) is erased everywhere;
+    values with at least one large enough region are kept whole."""
+    from scipy import ndimage
+    for color in np.unique(label):
+        mask = label == color
+        comp, n = ndimage.label(mask)                      # connectivity 1, like skimage's default
+        sizes = np.bincount(comp.ravel())[1:]
+        if n == 0 or not (sizes >= min_size).any():
+            label[mask] = 0
     return label
 
 

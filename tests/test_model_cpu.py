@@ -138,3 +138,67 @@ def test_same_pad_and_set_trainable():
     m.set_trainable(".*", exclusive_off=False)
     assert m.fpn.C2[0].conv1.weight.requires_grad and not m.fpn.C2[0].bn1.weight.requires_grad
     assert not m.mask.bn2.weight.requires_grad
+
+
+def test_relayer_mask_encoder_matches_reference():
+    """utils.reLayerMask (+ small-region pruning) against the reference's encoder (utils.py:531-557)."""
+    from sln_amodal_amd import utils
+    g = golden("relayer_mask")
+    for ci in range(int(g["n_cases"])):
+        am = [a for a in g["amodal_%d" % ci]]
+        inv = [v if h else np.zeros((0,), np.uint8) for v, h in zip(g["invis_%d" % ci], g["has_invis_%d" % ci])]
+        got = utils.reLayerMask(am, inv)
+        assert got.dtype == np.uint64 and np.array_equal(got, g["label_%d" % ci]), ci
+
+
+def test_label_codec_round_trip_through_the_npz_layer_file(tmp_path):
+    """On-disk format (amodal_train.py:238): <name>.npz['layer'] uint64 -> decode -> planes; encoding the
+    decoded visible / invisible masks again gives the file's label back (closed loop of the codec)."""
+    from oracle import oracle as orc
+    from sln_amodal_amd import utils
+    g = golden("relayer_mask")
+    lab = g["label_1"]
+    path = tmp_path / "img.npz"
+    np.savez(path, layer=lab)
+    back = np.load(path)["layer"]
+    assert back.dtype == np.uint64 and np.array_equal(back, lab)
+    n = int(orc.label_num_objects(lab)) if hasattr(orc, "label_num_objects") else 6
+    amodal, invis = [], []
+    for i in range(n):
+        vis = (lab >> np.uint64(i)) & np.uint64(1)
+        inv = (lab >> np.uint64(32 + i)) & np.uint64(1)
+        amodal.append(((vis | inv) > 0).astype(np.uint8))
+        invis.append(inv.astype(np.uint8) if inv.any() else np.zeros((0,), np.uint8))
+    assert np.array_equal(utils.reLayerMask(amodal, invis, min_size=1), lab)
+
+
+def test_checkpoint_round_trip_and_find_last(tmp_path):
+    """save_checkpoint -> find_last -> load_weights: the reference's checkpoint layout (a plain
+    state_dict under <logs>/<name>/mask_rcnn_<name>_<epoch>.pth, model.py:287-302, 366) loads back
+    bit for bit, atomically written, epoch parsed from the file name."""
+    from sln_amodal_amd.config import Config
+    from sln_amodal_amd.model import MaskRCNN
+
+    class C(Config):
+        NAME = "ckpt"
+        IMAGE_MAX_DIM = 128
+        ARCHITECTURE = "resnet50"
+
+    torch.manual_seed(1)
+    a = MaskRCNN(C(), str(tmp_path)).apply_amodal_heads(glm=False)
+    a.epoch = 3
+    path = a.checkpoint_path.format(a.epoch)
+    a.save_checkpoint(path)
+    assert os.path.exists(path) and not [f for f in os.listdir(os.path.dirname(path)) if ".tmp." in f]
+    torch.manual_seed(2)
+    b = MaskRCNN(C(), str(tmp_path)).apply_amodal_heads(glm=False)
+    d, last = b.find_last()
+    assert last == path
+    b.load_weights(last)
+    sa, sb = a.state_dict(), b.state_dict()
+    assert sa.keys() == sb.keys() and all(torch.equal(sa[k], sb[k]) for k in sa)
+    # the epoch is parsed only from the dated directory layout of the reference's regex (model.py:246;
+    # its own undated log_dir never matches -- and its m.group(6) of 4 groups would raise if it did)
+    assert b.epoch == 0
+    b.set_log_dir("/logs/coco20171029/mask_rcnn_coco_0007.pth")
+    assert b.epoch == 7

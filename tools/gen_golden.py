@@ -273,7 +273,7 @@ def main():
          g_pmask=pmask.grad.numpy())
 
 
-if __name__ == "__main__" and "--modules" not in sys.argv and "--module-grads" not in sys.argv:
+if __name__ == "__main__" and not any(a in sys.argv for a in ("--modules", "--module-grads", "--relayer")):
     main()
 
 
@@ -434,3 +434,51 @@ def module_grad_goldens():
 
 if __name__ == "__main__" and "--module-grads" in sys.argv:
     module_grad_goldens()
+
+
+def relayer_goldens():
+    """utils.reLayerMask (+ remove_small_path) of the reference on synthetic amodal / invisible masks.
+    skimage is absent: the harness supplies morphology.remove_small_objects restated from skimage's
+    documented behaviour with scipy.ndimage (connectivity 1, components smaller than min_size removed)."""
+    ref_harness.install()
+    import sys as _sys
+    from scipy import ndimage
+
+    def remove_small_objects(ar, min_size=64, connectivity=1, **_):
+        comp, n = ndimage.label(ar)
+        sizes = np.bincount(comp.ravel())
+        small = sizes < min_size
+        small[0] = False
+        out = ar.copy()
+        out[small[comp]] = False
+        return out
+
+    _sys.modules["skimage.morphology"].remove_small_objects = remove_small_objects
+    import utils as ref_utils
+    ref_utils.morphology.remove_small_objects = remove_small_objects
+    rng = np.random.RandomState(13)
+    cases = {}
+    for ci, (H, W, n) in enumerate([(64, 80, 4), (96, 96, 6), (48, 48, 3)]):
+        yy, xx = np.mgrid[0:H, 0:W]
+        amodal, invis = [], []
+        covered = np.zeros((H, W), bool)
+        for i in range(n):
+            cy, cx = rng.uniform(0.2, 0.8) * H, rng.uniform(0.2, 0.8) * W
+            ry, rx = rng.uniform(0.08, 0.3) * H, rng.uniform(0.08, 0.3) * W
+            m = ((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 <= 1.0
+            if i == n - 1:                      # a speck smaller than min_size: its colour must vanish
+                m = np.zeros((H, W), bool); m[2:6, 3:8] = True
+            amodal.append(m.astype(np.uint8))
+            inv = (m & covered).astype(np.uint8)
+            invis.append(inv if inv.any() else np.zeros((0,), np.uint8))
+            covered |= m
+        lab = ref_utils.reLayerMask([a.copy() for a in amodal], [v.copy() for v in invis])
+        cases["amodal_%d" % ci] = np.stack(amodal)
+        cases["invis_%d" % ci] = np.stack([v if v.size else np.zeros((H, W), np.uint8) for v in invis])
+        cases["has_invis_%d" % ci] = np.array([v.size > 0 for v in invis])
+        cases["label_%d" % ci] = lab
+    save("relayer_mask", n_cases=np.array(3), **cases)
+
+
+if __name__ == "__main__" and "--relayer" in sys.argv:
+    relayer_goldens()
