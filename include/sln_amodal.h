@@ -163,6 +163,19 @@ int sln_pyramid_crop_bwd_f32(const float *grads, int g_cstride, int g_coffset, c
                              sln_stream_t stream);
 
 /* ---------------------------------------------------------------------------
+ * Top-k selection in visiting order (proposal front end).
+ * Replaces: scores.sort(descending=True) over all A anchors followed by [:6000]
+ *           (modal/Functions.py:133-147).
+ * scores    B rows of A floats; element (b, a) at scores[b*stride_b + a*stride_a]
+ *           (strides in elements, so the foreground column of [B,A,2] is read in place).
+ * order     [B,k] int64: indices of the k largest scores, score descending, ties by the lower
+ *           index (== a stable descending sort; NaN sorts first, like torch).  k <= min(A, 8192).
+ * One 1024-thread block per image: radix select, ordered tie collection, LDS bitonic sort.
+ * ------------------------------------------------------------------------- */
+int sln_topk_order_f32(const float *scores, int B, int A, long stride_b, long stride_a, int k,
+                       int64_t *order, sln_stream_t stream);
+
+/* ---------------------------------------------------------------------------
  * Convolution stacks (modal/modals.py:203-499 backbone / FPN / RPN / heads,
  * modal/resnet_deeplab.py + modal/deeplabv2.py GLM): implicit-GEMM on the bf16
  * matrix cores with split-bf16 operands (fp32-class accuracy, see csrc/conv.hip).

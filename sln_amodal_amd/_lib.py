@@ -26,6 +26,7 @@ SIGNATURES = {
     "sln_label_decode_u64": (_i, [_p, _i, _i, _i, _i, _i, _p, _p]),
     "sln_mask_targets_u64": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _i, _i, _i, _p, _p]),
     "sln_proposal_decode_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, C.POINTER(_f), _f, _f, _p, _p]),
+    "sln_topk_order_f32": (_i, [_p, _i, _i, C.c_long, C.c_long, _i, _p, _p]),
     "sln_gather_rois_f32": (_i, [_p, _p, _p, _i, _i, _i, _f, _f, _p, _p]),
     "sln_pyramid_crop_fwd_f32": (_i, [C.POINTER(_p), C.POINTER(_i), _i, _i, _p, _p, _p, _i, _i, _i,
                                       _f, _p, _i, _i, _p]),

@@ -88,9 +88,14 @@ def proposal_layer(inputs, proposal_count, nms_threshold, anchors, config=None,
         probs, deltas = probs.unsqueeze(0), deltas.unsqueeze(0)
     A = anchors.shape[0]
     n = min(getattr(config, "PRE_NMS_LIMIT", 6000), A)
-    # Full stable sort == the reference's scores.sort(descending=True)[:6000] with a
-    # defined tie-break (lower anchor index first).
-    order = torch.sort(probs[:, :, 1], dim=1, descending=True, stable=True)[1][:, :n].contiguous()
+    # the reference's scores.sort(descending=True)[:6000] (Functions.py:133-147) with a defined
+    # tie-break (lower anchor index first): a batched select + sort of the 6000 survivors only,
+    # reading the foreground column in place
+    fg = probs.detach()[:, :, 1]
+    if fg.is_cuda and n <= 8192:
+        order = ops.topk_order(fg, n)
+    else:
+        order = torch.sort(fg, dim=1, descending=True, stable=True)[1][:, :n].contiguous()
     height, width = config.IMAGE_SHAPE[:2]
     dets = ops.proposal_decode(probs.detach(), deltas.detach(), anchors, order,
                                config.RPN_BBOX_STD_DEV, float(height), float(width))

@@ -162,6 +162,20 @@ def mask_targets(label, L, rois, roi_img, roi_obj, mh, mw):
 
 
 # --------------------------------------------------------------------- proposals
+def topk_order(scores, k):
+    """scores [B,A] f32 (any strides) -> order [B,k] int64: the k best per row, score descending, ties
+    by the lower index -- torch.sort(scores, 1, descending=True, stable=True)[1][:, :k] without
+    sorting the other A - k elements."""
+    _need(scores, torch.float32, "scores")
+    if scores.dim() != 2:
+        raise ValueError("scores must be [B,A]")
+    B, A = scores.shape
+    order = torch.empty((B, k), dtype=torch.int64, device=scores.device)
+    _lib.check(_lib.lib().sln_topk_order_f32(_ptr(scores), B, A, scores.stride(0), scores.stride(1), int(k),
+                                             _ptr(order), _stream()), "sln_topk_order_f32")
+    return order
+
+
 def proposal_decode(probs, deltas, anchors, order, std_dev, win_h, win_w):
     """probs [B,A,2], deltas [B,A,4], anchors [A,4], order [B,n] int64 ->
     dets [B,n,5] (y1,x1,y2,x2,score) decoded + clipped."""

@@ -327,3 +327,43 @@ def test_proposal_pipeline_matches_reference_golden(dim):
     assert k == want.shape[0]
     assert np.allclose(rois[0, :k].cpu().numpy(), want, rtol=0, atol=1e-6)
     assert (rois[0, k:] == 0).all()
+
+
+@pytest.mark.parametrize("case", ["random", "ties", "all_equal", "negative", "small", "nan_inf"])
+def test_topk_order_equals_a_stable_descending_sort(case):
+    """sln_topk_order_f32 == torch.sort(descending, stable)[:k], index for index: distinct scores,
+    heavy ties at the cut (quantised scores), all-equal rows, negative values, A < 1024, NaN / inf."""
+    from sln_amodal_amd import ops
+    g = torch.Generator().manual_seed(len(case))
+    B, A, k = 5, 70000, 6000
+    if case == "random":
+        s = torch.rand(B, A, generator=g)
+    elif case == "ties":
+        s = torch.round(torch.rand(B, A, generator=g) * 50) / 50        # ~1400 ties per value
+    elif case == "all_equal":
+        s = torch.full((B, A), 0.25)
+    elif case == "negative":
+        s = torch.randn(B, A, generator=g) - 3.0
+    elif case == "small":
+        B, A, k = 3, 700, 700
+        s = torch.round(torch.randn(B, A, generator=g) * 4) / 4
+    else:
+        s = torch.randn(B, A, generator=g)
+        s[:, ::97] = float("inf"); s[:, 5::1013] = float("-inf"); s[0, 3::5000] = float("nan")
+    probs = torch.stack([1 - s, s], dim=2).cuda()                      # the strided foreground column
+    got = ops.topk_order(probs[:, :, 1], k).cpu()
+    want = torch.sort(s, dim=1, descending=True, stable=True)[1][:, :k]
+    if case == "nan_inf":      # torch puts NaN first in a descending sort; so does the key order
+        assert torch.equal(got, want)
+    else:
+        assert torch.equal(got, want)
+
+
+def test_topk_order_full_size_batch():
+    from sln_amodal_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(3)
+    s = torch.rand(16, 261888, device="cuda", generator=g)
+    s[:, 1000:3000] = 0.999          # a plateau across the head of the ranking
+    got = ops.topk_order(s, 6000)
+    want = torch.sort(s, dim=1, descending=True, stable=True)[1][:, :6000]
+    assert torch.equal(got, want)
