@@ -176,6 +176,40 @@ int sln_topk_order_f32(const float *scores, int B, int A, long stride_b, long st
                        int64_t *order, sln_stream_t stream);
 
 /* ---------------------------------------------------------------------------
+ * Inference tail: full-size masks and their COCO run-length encoding.
+ *
+ * sln_unmold_masks_u8
+ * Replaces: the per-detection host loop utils.unmold_mask (utils.py:447-465) called from
+ *           MaskRCNN.unmold_detections (model.py:796-803): scipy.misc.imresize(mask, (y2-y1, x2-x1),
+ *           interp='bilinear') / 255 >= 0.5, pasted into a zero image at the box.
+ * masks     [N,C,mh,mw] float32 head outputs (mh, mw <= 64); class_ids [N] int32 picks the plane of
+ *           each detection (NULL: plane 0).
+ * boxes     [N,4] int32 (y1,x1,y2,x2) in image pixels; an empty or out-of-image box gives a zero
+ *           mask (the reference drops such detections beforehand, model.py:786-793).
+ * full      [N,W,H] uint8 in {0,1}, COLUMN-major per mask (y fastest): the np.asfortranarray layout
+ *           the reference hands to pycocotools (amodal_train.py:397); fully written, no memset needed.
+ * Bit-identical to scipy<=1.2 bytescale (float32) + Pillow's 8-bit BILINEAR resample.
+ *
+ * sln_rle_encode_u8
+ * Replaces: rleEncode (cocoapi/common/maskApi.c:33-42) behind pycocotools.mask.encode.
+ * masks     [N,a] uint8, a = h*w bytes per mask in column-major order.
+ * counts    [N,max_runs] uint32 run lengths, starting with a (possibly empty) run of zeros;
+ * num_runs  [N] int32, always the true run count.  If num_runs[n] > max_runs, row n of counts is
+ *           unspecified: call again with a larger capacity (a + 1 always suffices).
+ *
+ * sln_rle_to_string / sln_rle_from_string  (host memory, no device work)
+ * Replace:  rleToString / rleFrString (maskApi.c:204-231), the "counts" bytes of a COCO RLE dict.
+ *           Return the length written (>= 0), or -SLN_ERR_INVALID_ARG when cap is too small (6 characters per
+ *           count, resp. one count per character, always suffice).
+ * ------------------------------------------------------------------------- */
+int sln_unmold_masks_u8(const float *masks, const int32_t *class_ids, const int32_t *boxes, int N, int C,
+                        int mh, int mw, int H, int W, uint8_t *full, sln_stream_t stream);
+int sln_rle_encode_u8(const uint8_t *masks, int N, int64_t a, int max_runs, uint32_t *counts,
+                      int32_t *num_runs, sln_stream_t stream);
+int64_t sln_rle_to_string(const uint32_t *counts, int64_t m, char *out, int64_t cap);
+int64_t sln_rle_from_string(const char *s, int64_t len, uint32_t *counts, int64_t cap);
+
+/* ---------------------------------------------------------------------------
  * Convolution stacks (modal/modals.py:203-499 backbone / FPN / RPN / heads,
  * modal/resnet_deeplab.py + modal/deeplabv2.py GLM): implicit-GEMM on the bf16
  * matrix cores with split-bf16 operands (fp32-class accuracy, see csrc/conv.hip).

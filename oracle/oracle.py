@@ -348,3 +348,128 @@ def encode_labels(amodal_masks):
         label[m & covered] |= np.uint64(1) << np.uint64(32 + i)
         covered |= m
     return label
+
+
+# --------------------------------------------------------------------------
+# inference tail
+# --------------------------------------------------------------------------
+def build_ref(reference="/root/reference"):
+    """oracle/_ref/libmaskapi_ref.so from the reference's own maskApi.c (plain C); returns the
+    path, or None when neither the sources nor a prebuilt library are present."""
+    so = os.path.join(_HERE, "_ref", "libmaskapi_ref.so")
+    src = os.path.join(reference, "cocoapi", "common", "maskApi.c")
+    if os.path.exists(src) and (not os.path.exists(so)
+                                or os.path.getmtime(so) < os.path.getmtime(src)):
+        subprocess.check_call(["make", "-C", _HERE, "REFERENCE=" + reference, "ref"],
+                              stdout=subprocess.DEVNULL)
+    return so if os.path.exists(so) else None
+
+
+class _RefRLE(C.Structure):
+    # maskApi.h:13  typedef struct { siz h, w, m; uint *cnts; } RLE;
+    _fields_ = [("h", C.c_ulong), ("w", C.c_ulong), ("m", C.c_ulong),
+                ("cnts", C.POINTER(C.c_uint))]
+
+
+_REF = None
+
+
+def ref_maskapi():
+    """ctypes handle of the compiled reference maskApi.c (None if unavailable)."""
+    global _REF
+    if _REF is None:
+        so = build_ref()
+        if so is None:
+            return None
+        _REF = C.CDLL(so)
+        _REF.rleToString.restype = C.c_void_p
+    return _REF
+
+
+def ref_rle_encode(mask_hw):
+    """The reference itself: rleEncode + rleToString on one [h,w] uint8 mask, through the same
+    np.asfortranarray hand-off as amodal_train.py:397.  Returns (counts uint32[m], bytes)."""
+    ref = ref_maskapi()
+    m = np.asfortranarray(mask_hw.astype(np.uint8))
+    h, w = m.shape
+    R = _RefRLE()
+    ref.rleEncode(C.byref(R), m.ctypes.data_as(C.POINTER(C.c_ubyte)), C.c_ulong(h),
+                  C.c_ulong(w), C.c_ulong(1))
+    cnts = np.ctypeslib.as_array(R.cnts, shape=(R.m,)).astype(np.uint32).copy() if R.m else \
+        np.zeros(0, np.uint32)
+    sp = ref.rleToString(C.byref(R))
+    s = C.string_at(sp)
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+    libc.free(sp)
+    ref.rleFree(C.byref(R))
+    return cnts, s
+
+
+def rle_encode(mask_hw):
+    """[h,w] mask -> run counts uint32[m], column-major scan (maskApi.c:33-42)."""
+    m = np.asfortranarray(np.asarray(mask_hw).astype(np.uint8))
+    flat = m.reshape(-1, order="F")
+    cnts = np.empty(flat.size + 1, np.uint32)
+    k = lib().orc_rle_encode_u8
+    k.restype = C.c_int64
+    n = k(_p(np.ascontiguousarray(flat), C.c_uint8), C.c_int64(flat.size), _p(cnts, C.c_uint32))
+    return cnts[:n].copy()
+
+
+def rle_decode(cnts, h, w):
+    cnts = np.ascontiguousarray(cnts, np.uint32)
+    assert int(cnts.astype(np.int64).sum()) == h * w
+    flat = np.empty(h * w, np.uint8)
+    lib().orc_rle_decode_u8(_p(cnts, C.c_uint32), C.c_int64(cnts.size), _p(flat, C.c_uint8))
+    return flat.reshape(h, w, order="F")
+
+
+def rle_to_string(cnts):
+    """maskApi.c:204-216."""
+    cnts = np.ascontiguousarray(cnts, np.uint32)
+    buf = C.create_string_buffer(6 * cnts.size + 1)
+    k = lib().orc_rle_to_string
+    k.restype = C.c_int64
+    n = k(_p(cnts, C.c_uint32), C.c_int64(cnts.size), buf)
+    return buf.raw[:n]
+
+
+def rle_from_string(s):
+    """maskApi.c:218-231."""
+    cnts = np.empty(max(len(s), 1), np.uint32)
+    k = lib().orc_rle_from_string
+    k.restype = C.c_int64
+    n = k(C.c_char_p(bytes(s)), _p(cnts, C.c_uint32))
+    return cnts[:n].copy()
+
+
+def bytescale(data):
+    """scipy.misc.bytescale of a float32 array (pilutil.py; float32 arithmetic)."""
+    d = np.ascontiguousarray(data, np.float32)
+    out = np.empty(d.shape, np.uint8)
+    lib().orc_bytescale_f32(_p(d, C.c_float), C.c_int64(d.size), _p(out, C.c_uint8))
+    return out
+
+
+def pil_resize_bilinear(img_u8, oh, ow):
+    """PIL Image.fromarray(img).resize((ow, oh), BILINEAR) restated (Resample.c)."""
+    a = np.ascontiguousarray(img_u8, np.uint8)
+    out = np.empty((oh, ow), np.uint8)
+    lib().orc_pil_resize_bilinear_u8(_p(a, C.c_uint8), C.c_int(a.shape[0]), C.c_int(a.shape[1]),
+                                     C.c_int(oh), C.c_int(ow), _p(out, C.c_uint8))
+    return out
+
+
+def unmold_mask(mask, bbox, image_shape):
+    """utils.py:447-465.  mask [mh,mw] f32, bbox (y1,x1,y2,x2) ints -> [H,W] uint8."""
+    m = np.ascontiguousarray(mask, np.float32)
+    H, W = int(image_shape[0]), int(image_shape[1])
+    full = np.empty((H, W), np.uint8)
+    y1, x1, y2, x2 = (int(v) for v in bbox)
+    rc = lib().orc_unmold_mask_f32(_p(m, C.c_float), C.c_int(m.shape[0]), C.c_int(m.shape[1]),
+                                   C.c_int(y1), C.c_int(x1), C.c_int(y2), C.c_int(x2),
+                                   C.c_int(H), C.c_int(W), _p(full, C.c_uint8))
+    if rc != 0:
+        raise ValueError("box outside the image")
+    return full

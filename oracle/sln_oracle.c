@@ -16,6 +16,12 @@
  *     (tests/test_oracle_cpu.py: numpy greedy NMS, torch grid_sample).
  *   - orc_label_decode_u64, orc_box_*: pinned against outputs of the reference's
  *     own Python (tools/gen_golden.py -> tests/golden/).
+ *   - orc_rle_*: pinned against oracle/_ref/libmaskapi_ref.so, the reference's own
+ *     cocoapi/common/maskApi.c compiled by oracle/Makefile (target `ref`), and
+ *     against tests/golden/rle.npz generated from it.
+ *   - orc_bytescale_f32 / orc_pil_resize_bilinear_u8 / orc_unmold_mask_f32: the
+ *     algorithm lives in third-party scipy.misc + Pillow (not vendored by the
+ *     reference); pinned against the installed Pillow and tests/golden/unmold.npz.
  *
  * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off, no -ffast-math, so
  * every float expression rounds exactly once per operation like the
@@ -303,5 +309,221 @@ int orc_bbox_overlaps_f32(const float *b1, int64_t n1, const float *b2, int64_t 
             const float a2 = (q[2] - q[0]) * (q[3] - q[1]);
             iou[i * n2 + j] = inter / ((a1 + a2) - inter);
         }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------ */
+/* Inference tail.                                    */
+/* ------------------------------------------------------------------------ */
+
+/* Run-length encoding of one binary mask stored column-major (the layout
+ * np.asfortranarray hands to pycocotools at amodal_train.py:397).
+ * Follows /root/reference/cocoapi/common/maskApi.c:33-42 (rleEncode): runs
+ * alternate starting with a run of zeros (possibly empty); a run ends wherever
+ * the byte value changes.  cnts: caller-sized [a+1].  Returns the run count.
+ * Pinned against oracle/_ref/libmaskapi_ref.so (the reference's own maskApi.c
+ * compiled here) by tests/test_tail_cpu.py and tests/golden/rle.npz. */
+int64_t orc_rle_encode_u8(const uint8_t *mask, int64_t a, uint32_t *cnts) {
+    int64_t k = 0;
+    uint32_t run = 0;
+    uint8_t prev = 0;
+    for (int64_t j = 0; j < a; ++j) {
+        if (mask[j] != prev) { cnts[k++] = run; run = 0; prev = mask[j]; }
+        ++run;
+    }
+    cnts[k++] = run;
+    return k;
+}
+
+/* maskApi.c:44-49 (rleDecode) for one mask. */
+int orc_rle_decode_u8(const uint32_t *cnts, int64_t m, uint8_t *mask) {
+    uint8_t v = 0;
+    for (int64_t j = 0; j < m; ++j) {
+        for (uint32_t k = 0; k < cnts[j]; ++k) *(mask++) = v;
+        v = !v;
+    }
+    return 0;
+}
+
+/* Compressed string of the counts: maskApi.c:204-216 (rleToString).  Counts
+ * from the fourth on are stored as the difference to the count two places
+ * back; each value is cut into 5-bit groups, low group first, bit 0x20 marks
+ * "more groups follow", and 48 is added to land in printable ASCII.
+ * s: caller-sized [6*m+1].  Returns the string length (without the NUL). */
+int64_t orc_rle_to_string(const uint32_t *cnts, int64_t m, char *s) {
+    int64_t p = 0;
+    for (int64_t i = 0; i < m; ++i) {
+        long x = (long)cnts[i];
+        if (i > 2) x -= (long)cnts[i - 2];
+        int more = 1;
+        while (more) {
+            char c = (char)(x & 0x1f);
+            x >>= 5;
+            more = (c & 0x10) ? (x != -1) : (x != 0);
+            if (more) c |= 0x20;
+            c += 48;
+            s[p++] = c;
+        }
+    }
+    s[p] = 0;
+    return p;
+}
+
+/* maskApi.c:218-231 (rleFrString).  cnts: caller-sized [strlen(s)]. */
+int64_t orc_rle_from_string(const char *s, uint32_t *cnts) {
+    int64_t m = 0, p = 0;
+    while (s[p]) {
+        long x = 0;
+        int k = 0, more = 1;
+        while (more) {
+            const char c = (char)(s[p] - 48);
+            x |= (long)(c & 0x1f) << (5 * k);
+            more = c & 0x20;
+            ++p; ++k;
+            if (!more && (c & 0x10)) x |= (long)(~0UL << (5 * k));
+        }
+        if (m > 2) x += (long)cnts[m - 2];
+        cnts[m++] = (uint32_t)x;
+    }
+    return m;
+}
+
+/* ---- unmold_mask: /root/reference/utils.py:447-465 ------------------------
+ * scipy.misc.imresize(mask, (h, w), interp='bilinear') / 255 >= 0.5, pasted
+ * into a zero image at the box.  imresize is scipy <= 1.2's pilutil:
+ * toimage() min-max "bytescale"s the float mask to uint8 (float32 arithmetic
+ * on a float32 input: (data - cmin) * f32(255.0 / (cmax - cmin)), clip to
+ * [0,255], + 0.5, truncate), PIL Image.resize(BILINEAR), fromimage().
+ * Neither scipy.misc.imresize nor Pillow's source is part of /root/reference
+ * (requirements: scipy, Pillow, no pins); the resize below restates Pillow's
+ * published ImagingResample for 8-bit single-band images (libImaging/
+ * Resample.c: precompute_coeffs, normalize_coeffs_8bpc, the horizontal pass
+ * into a uint8 temporary, then the vertical pass; PRECISION_BITS = 32-8-2) and
+ * is pinned against the installed Pillow (12.2) by tests/test_tail_cpu.py and
+ * tests/golden/unmold.npz.
+ * -------------------------------------------------------------------------- */
+#define ORC_PIL_PRECISION_BITS (32 - 8 - 2)
+
+static inline double orc_pil_bilinear(double x) {
+    if (x < 0.0) x = -x;
+    if (x < 1.0) return 1.0 - x;
+    return 0.0;
+}
+
+/* Resample.c precompute_coeffs + normalize_coeffs_8bpc for box (0, in_size).
+ * bounds: [out_size,2] (first tap, tap count); kk: [out_size, ksize] int32.
+ * Returns ksize. */
+static int orc_pil_coeffs(int in_size, int out_size, int **bounds_out, int32_t **kk_out) {
+    const float in0 = 0.0f, in1 = (float)in_size;
+    double scale = (double)(in1 - in0) / out_size, filterscale = scale;
+    if (filterscale < 1.0) filterscale = 1.0;
+    const double support = 1.0 * filterscale;   /* BILINEAR support = 1.0 */
+    const int ksize = (int)ceil(support) * 2 + 1;
+    int *bounds = (int *)malloc(sizeof(int) * 2 * (size_t)out_size);
+    int32_t *kk = (int32_t *)malloc(sizeof(int32_t) * (size_t)out_size * ksize);
+    double *k = (double *)malloc(sizeof(double) * ksize);
+    for (int xx = 0; xx < out_size; ++xx) {
+        const double center = in0 + (xx + 0.5) * scale;
+        const double ss = 1.0 / filterscale;
+        double ww = 0.0;
+        int xmin = (int)(center - support + 0.5);
+        if (xmin < 0) xmin = 0;
+        int xmax = (int)(center + support + 0.5);
+        if (xmax > in_size) xmax = in_size;
+        xmax -= xmin;
+        for (int x = 0; x < xmax; ++x) {
+            const double w = orc_pil_bilinear((x + xmin - center + 0.5) * ss);
+            k[x] = w;
+            ww += w;
+        }
+        for (int x = 0; x < xmax; ++x)
+            if (ww != 0.0) k[x] /= ww;
+        for (int x = 0; x < ksize; ++x) {
+            const double v = x < xmax ? k[x] : 0.0;
+            kk[(size_t)xx * ksize + x] = v < 0
+                ? (int32_t)(-0.5 + v * (1 << ORC_PIL_PRECISION_BITS))
+                : (int32_t)(0.5 + v * (1 << ORC_PIL_PRECISION_BITS));
+        }
+        bounds[xx * 2 + 0] = xmin;
+        bounds[xx * 2 + 1] = xmax;
+    }
+    free(k);
+    *bounds_out = bounds;
+    *kk_out = kk;
+    return ksize;
+}
+
+static inline uint8_t orc_pil_clip8(int32_t v) {
+    v >>= ORC_PIL_PRECISION_BITS;     /* arithmetic shift, like Resample.c's clip8 lookup */
+    return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+}
+
+/* PIL Image.resize((ow, oh), BILINEAR) of an 8-bit image [ih, iw]. */
+int orc_pil_resize_bilinear_u8(const uint8_t *in, int ih, int iw, int oh, int ow,
+                               uint8_t *out) {
+    if (oh <= 0 || ow <= 0) return 0;
+    int *bh, *bv;
+    int32_t *kh, *kv;
+    const int ksh = orc_pil_coeffs(iw, ow, &bh, &kh);
+    const int ksv = orc_pil_coeffs(ih, oh, &bv, &kv);
+    uint8_t *tmp = (uint8_t *)malloc((size_t)ih * ow);
+    for (int y = 0; y < ih; ++y)
+        for (int xx = 0; xx < ow; ++xx) {
+            int32_t ss = 1 << (ORC_PIL_PRECISION_BITS - 1);
+            const int xmin = bh[xx * 2], xmax = bh[xx * 2 + 1];
+            for (int x = 0; x < xmax; ++x)
+                ss += in[(size_t)y * iw + x + xmin] * kh[(size_t)xx * ksh + x];
+            tmp[(size_t)y * ow + xx] = orc_pil_clip8(ss);
+        }
+    for (int yy = 0; yy < oh; ++yy) {
+        const int ymin = bv[yy * 2], ymax = bv[yy * 2 + 1];
+        for (int xx = 0; xx < ow; ++xx) {
+            int32_t ss = 1 << (ORC_PIL_PRECISION_BITS - 1);
+            for (int y = 0; y < ymax; ++y)
+                ss += tmp[(size_t)(y + ymin) * ow + xx] * kv[(size_t)yy * ksv + y];
+            out[(size_t)yy * ow + xx] = orc_pil_clip8(ss);
+        }
+    }
+    free(tmp); free(bh); free(bv); free(kh); free(kv);
+    return 0;
+}
+
+/* scipy.misc.bytescale (pilutil.py) of a float32 array, defaults low=0 high=255. */
+int orc_bytescale_f32(const float *data, int64_t n, uint8_t *out) {
+    if (n <= 0) return 0;
+    float cmin = data[0], cmax = data[0];
+    for (int64_t i = 1; i < n; ++i) {
+        if (data[i] < cmin) cmin = data[i];
+        if (data[i] > cmax) cmax = data[i];
+    }
+    float cscale = cmax - cmin;
+    if (cscale == 0.0f) cscale = 1.0f;
+    const float scale = (float)(255.0 / (double)cscale);
+    for (int64_t i = 0; i < n; ++i) {
+        float v = (data[i] - cmin) * scale;
+        v = v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v);
+        out[i] = (uint8_t)(v + 0.5f);
+    }
+    return 0;
+}
+
+/* utils.py:447-465 (unmold_mask): mask [mh,mw] f32, box (y1,x1,y2,x2) in image
+ * pixels -> full [H,W] uint8 (row-major).  The box must lie inside the image
+ * (refine_detections clips to the window, model.py:791 scales into the image). */
+int orc_unmold_mask_f32(const float *mask, int mh, int mw, int y1, int x1, int y2, int x2,
+                        int H, int W, uint8_t *full) {
+    memset(full, 0, (size_t)H * W);
+    const int oh = y2 - y1, ow = x2 - x1;
+    if (oh <= 0 || ow <= 0) return 0;
+    if (y1 < 0 || x1 < 0 || y2 > H || x2 > W) return -1;
+    uint8_t *byt = (uint8_t *)malloc((size_t)mh * mw);
+    uint8_t *res = (uint8_t *)malloc((size_t)oh * ow);
+    orc_bytescale_f32(mask, (int64_t)mh * mw, byt);
+    orc_pil_resize_bilinear_u8(byt, mh, mw, oh, ow, res);
+    for (int y = 0; y < oh; ++y)
+        for (int x = 0; x < ow; ++x)
+            /* (r.astype(f32) / 255.0) >= 0.5  <=>  r >= 128 */
+            full[(size_t)(y1 + y) * W + x1 + x] = ((float)res[(size_t)y * ow + x] / 255.0f) >= 0.5f;
+    free(byt); free(res);
     return 0;
 }

@@ -95,6 +95,33 @@ class AmodalDataset(object):
             step += 1
 
 
+def build_coco_results(dataset, image_ids, rois, class_ids, scores, masks):
+    """Detections of one image in COCO result format (amodal_train.py:370-400): bbox rounded to one
+    decimal and reordered to (x, y, w, h), class ids folded to {0, 1}, masks as COCO RLE dicts.
+    masks: device uint8 [N,W,H] (detect(..., keep_device=True)["masks_device"]) or the host array
+    [H,W,N] detect() returns by default (uploaded once); either way the run-length encoding happens
+    on the GPU (mask_rle.encode replaces maskUtils.encode(np.asfortranarray(mask)))."""
+    from . import mask_rle
+    if rois is None:
+        return []
+    if not torch.is_tensor(masks):
+        masks = torch.from_numpy(np.ascontiguousarray(np.transpose(masks, (2, 1, 0)))).to(
+            torch.uint8).cuda()
+    rles = mask_rle.encode(masks)
+    results = []
+    for image_id in image_ids:
+        for i in range(rois.shape[0]):
+            bbox = np.around(rois[i], 1)
+            results.append({
+                "image_id": image_id,
+                "category_id": 1 if class_ids[i] > 0 else 0,
+                "bbox": [bbox[1], bbox[0], bbox[3] - bbox[1], bbox[2] - bbox[0]],
+                "score": scores[i],
+                "segmentation": rles[i],
+            })
+    return results
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(description="Train / evaluate SLN-Amodal on MI355X.")
     ap.add_argument("command", metavar="<command>", help="'train' or 'evaluate'")
@@ -173,10 +200,13 @@ def main(argv=None):
         n = 0
         for batch in data:
             img = (batch["images"][0].permute(1, 2, 0).cpu().numpy() + config.MEAN_PIXEL).clip(0, 255)
-            res = model.detect([img.astype(np.uint8)])
+            res = model.detect([img.astype(np.uint8)], keep_device=True)
             k = res[0]["rois"].shape[0] if res else 0
+            coco = build_coco_results(None, [n], res[0]["rois"], res[0]["class_ids"], res[0]["scores"],
+                                      res[0]["masks_device"]) if k else []
             if rank == 0:
-                print("image %d: %d detections" % (n, k))
+                print("image %d: %d detections, %d RLE bytes" % (
+                    n, k, sum(len(r["segmentation"]["counts"]) for r in coco)))
             n += 1
             if n >= max(1, min(args.limit, 2 if args.synthetic else args.limit)):
                 break

@@ -390,10 +390,13 @@ class MaskRCNN(nn.Module):
                                             np.zeros([cfg.NUM_CLASSES], dtype=np.int32)))
         return np.stack(molded), np.stack(metas), np.stack(windows)
 
-    def detect(self, images, mode="inference", priorities=None):
+    def detect(self, images, mode="inference", priorities=None, keep_device=False):
         """List of HxWx3 images -> list of dicts(rois, class_ids, scores, masks)
         (model.py:464-514).  priorities: per-image list of predict() overrides (parity tests feed the
-        reference's proposals)."""
+        reference's proposals).  On the GPU the tail (box transform, zero-area filter, mask resize +
+        threshold + paste) runs on the device; keep_device=True additionally returns the masks as the
+        device tensor "masks_device" [N,W,H] (column-major per mask, ready for mask_rle.encode) and
+        skips the [H,W,N] host copy ("masks" is None)."""
         results = []
         with torch.no_grad():
             for i, image in enumerate(images):
@@ -403,6 +406,10 @@ class MaskRCNN(nn.Module):
                                                       priorities=priorities[i] if priorities else None)
                 if len(detections) == 0:
                     continue
+                if detections.is_cuda:
+                    results.append(self.unmold_detections_device(detections[0], mrcnn_mask[0], image.shape,
+                                                                 windows[0], keep_device))
+                    continue
                 det = detections[0].cpu().numpy()
                 msk = mrcnn_mask[0].permute(0, 2, 3, 1).cpu().numpy()
                 rois, class_ids, scores, masks = self.unmold_detections(det, msk, image.shape,
@@ -410,6 +417,40 @@ class MaskRCNN(nn.Module):
                 results.append({"rois": rois, "class_ids": class_ids, "scores": scores,
                                 "masks": masks})
         return results
+
+    def unmold_detections_device(self, detections, mrcnn_mask, image_shape, window, keep_device=False):
+        """unmold_detections (model.py:747-806) without leaving the GPU: detections [M,6] and
+        mrcnn_mask [M,C,h,w] device tensors -> dict like detect()'s.  The box arithmetic is the
+        reference's numpy float64 (boxes - shifts) * scales truncated to int32; the masks come from
+        ops.unmold_masks (bit-identical to utils.unmold_mask)."""
+        from . import ops
+        dev = detections.device
+        cls_f = detections[:, 4]
+        zero = torch.nonzero(cls_f == 0)
+        N = int(zero[0, 0]) if zero.numel() else detections.shape[0]
+        class_ids = cls_f[:N].to(torch.int32)
+        class_ids = torch.where(class_ids > 0, torch.ones_like(class_ids), class_ids)
+        scores = detections[:N, 5]
+        h_scale = image_shape[0] / (window[2] - window[0])
+        w_scale = image_shape[1] / (window[3] - window[1])
+        scales = torch.tensor([h_scale, w_scale, h_scale, w_scale], dtype=torch.float64, device=dev)
+        shifts = torch.tensor([window[0], window[1], window[0], window[1]], dtype=torch.float64, device=dev)
+        boxes = ((detections[:N, :4].double() - shifts) * scales).to(torch.int32)
+        ok = (boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1]) > 0
+        boxes, class_ids, scores = boxes[ok], class_ids[ok], scores[ok]
+        planes = mrcnn_mask[:N][ok].float()
+        H, W = int(image_shape[0]), int(image_shape[1])
+        full = ops.unmold_masks(planes, class_ids, boxes, H, W)            # [n, W, H]
+        out = {"rois": boxes.cpu().numpy(), "class_ids": class_ids.cpu().numpy(),
+               "scores": scores.cpu().numpy()}
+        if keep_device:
+            out["masks"] = None
+            out["masks_device"] = full
+        elif full.shape[0]:
+            out["masks"] = full.permute(2, 1, 0).cpu().numpy()             # [H, W, n] view, F-ordered planes
+        else:
+            out["masks"] = np.empty((0,) + tuple(mrcnn_mask.shape[2:4]))
+        return out
 
     def unmold_detections(self, detections, mrcnn_mask, image_shape, window):
         """Network outputs -> image-space boxes and full-size binary masks
@@ -432,12 +473,15 @@ class MaskRCNN(nn.Module):
         for i in range(boxes.shape[0]):
             y1, x1, y2, x2 = boxes[i]
             # utils.py:447-465 -> scipy.misc.imresize(mask, (h, w), interp='bilinear'):
-            # min-max bytescale to uint8, PIL bilinear resize, then /255 >= 0.5
+            # min-max bytescale to uint8 (float32 arithmetic on the float32 head output), PIL
+            # bilinear resize, then /255 >= 0.5.  CPU-resident models only; cuda goes through
+            # unmold_detections_device.
             from PIL import Image
-            m = masks[i].astype(np.float64)
+            m = masks[i].astype(np.float32)
             lo, hi = m.min(), m.max()
-            byt = np.zeros(m.shape, np.uint8) if hi == lo else \
-                ((m - lo) * (255.0 / (hi - lo)) + 0.5).clip(0, 255).astype(np.uint8)
+            cscale = np.float32(hi - lo) if hi != lo else np.float32(1.0)
+            byt = ((m - lo) * np.float32(255.0 / np.float64(cscale))).clip(0, 255)
+            byt = (byt + np.float32(0.5)).astype(np.uint8)
             r = np.asarray(Image.fromarray(byt).resize((int(x2 - x1), int(y2 - y1)), Image.BILINEAR),
                            dtype=np.float32)
             fm = np.zeros(image_shape[:2], dtype=np.uint8)

@@ -202,3 +202,34 @@ def gather_rois(dets, keep, num_keep, norm_h, norm_w):
                                               max_out, float(norm_h), float(norm_w), _ptr(rois),
                                               _stream()), "sln_gather_rois_f32")
     return rois
+
+
+# ------------------------------------------------------------------ inference tail
+def unmold_masks(masks, class_ids, boxes, H, W):
+    """masks [N,C,mh,mw] f32, class_ids [N] int32 (or None), boxes [N,4] int32 image pixels ->
+    full [N,W,H] uint8 in {0,1}, column-major per mask (utils.py:447-465 for all detections)."""
+    masks = _need(masks, torch.float32, "masks").contiguous()
+    boxes = _need(boxes, torch.int32, "boxes").contiguous()
+    if class_ids is not None:
+        class_ids = _need(class_ids, torch.int32, "class_ids").contiguous()
+    if masks.dim() != 4 or boxes.shape != (masks.shape[0], 4):
+        raise ValueError("masks must be [N,C,mh,mw] and boxes [N,4]")
+    N, Cc, mh, mw = masks.shape
+    full = torch.empty((N, int(W), int(H)), dtype=torch.uint8, device=masks.device)
+    _lib.check(_lib.lib().sln_unmold_masks_u8(_ptr(masks), _ptr(class_ids), _ptr(boxes), N, Cc, mh, mw,
+                                              int(H), int(W), _ptr(full), _stream()), "sln_unmold_masks_u8")
+    return full
+
+
+def rle_encode(masks, max_runs):
+    """masks [N,a] (or [N,W,H]) uint8, column-major bytes of each mask -> counts [N,max_runs] uint32
+    (as int32 storage) and num_runs [N] int32 (maskApi.c:33-42).  Rows whose num_runs exceeds
+    max_runs are unspecified."""
+    masks = _need(masks, torch.uint8, "masks").contiguous()
+    N = masks.shape[0]
+    a = masks[0].numel() if N else 0
+    counts = torch.empty((N, int(max_runs)), dtype=torch.int32, device=masks.device)
+    num = torch.empty((N,), dtype=torch.int32, device=masks.device)
+    _lib.check(_lib.lib().sln_rle_encode_u8(_ptr(masks), N, a, int(max_runs), _ptr(counts), _ptr(num),
+                                            _stream()), "sln_rle_encode_u8")
+    return counts, num

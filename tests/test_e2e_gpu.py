@@ -240,6 +240,24 @@ def test_detect_matches_reference(scene):
     assert r["masks"].shape == shape
     # a 1e-5 difference in a mask logit can move a bytescaled pixel across the 0.5 threshold
     assert (r["masks"] != want_masks).mean() < 1e-4
+    # the device tail alone, fed the reference's own detections and mask logits, is bit-exact, and its
+    # RLE hand-off decodes back to the reference's masks
+    from sln_amodal_amd import mask_rle
+    from sln_amodal_amd.amodal_train import build_coco_results
+    dim = g["image_u8"].shape[0]
+    out = m.unmold_detections_device(torch.from_numpy(want).cuda(), torch.from_numpy(g["mrcnn_mask"]).cuda(),
+                                     g["image_u8"].shape, (0, 0, dim, dim), keep_device=True)
+    assert out["masks"] is None and np.array_equal(out["rois"], g["final_rois"])
+    assert np.array_equal(out["masks_device"].permute(2, 1, 0).cpu().numpy(), want_masks)
+    coco = build_coco_results(None, [7], out["rois"], out["class_ids"], out["scores"], out["masks_device"])
+    assert len(coco) == shape[2] and coco[0]["image_id"] == 7 and coco[0]["category_id"] == 1
+    for i, c in enumerate(coco):
+        seg = c["segmentation"]
+        assert seg["size"] == [shape[0], shape[1]]
+        assert np.array_equal(mask_rle.decode_counts(mask_rle.from_string(seg["counts"]), shape[0], shape[1]),
+                              want_masks[:, :, i])
+        y1, x1, y2, x2 = g["final_rois"][i]
+        assert c["bbox"] == [x1, y1, x2 - x1, y2 - y1]
 
 
 # ------------------------------------------------------------------ module-level gradients

@@ -273,7 +273,7 @@ def main():
          g_pmask=pmask.grad.numpy())
 
 
-if __name__ == "__main__" and not any(a in sys.argv for a in ("--modules", "--module-grads", "--relayer")):
+if __name__ == "__main__" and not any(a in sys.argv for a in ("--modules", "--module-grads", "--relayer", "--tail")):
     main()
 
 
@@ -482,3 +482,69 @@ def relayer_goldens():
 
 if __name__ == "__main__" and "--relayer" in sys.argv:
     relayer_goldens()
+
+
+def tail_goldens():
+    """Inference tail.
+    rle.npz: the reference's own cocoapi/common/maskApi.c (compiled as oracle/_ref/libmaskapi_ref.so by
+    oracle/Makefile) run on masks handed over exactly like amodal_train.py:397 (np.asfortranarray) ->
+    run counts + compressed strings.
+    unmold.npz: the reference's utils.unmold_mask (utils.py:447-465) on float32 head outputs; its
+    scipy.misc.imresize (removed from scipy >= 1.3) is the harness stand-in of tools/gen_golden_e2e.py
+    (scipy 1.0's published bytescale -> PIL resize), so the resampling itself is the installed Pillow's."""
+    from oracle import oracle as orc
+    assert orc.ref_maskapi() is not None, "oracle/_ref/libmaskapi_ref.so missing"
+    rng = np.random.RandomState(77)
+    yy, xx = np.mgrid[0:96, 0:128]
+    masks = {
+        "empty": np.zeros((6, 9), np.uint8),
+        "full": np.ones((6, 9), np.uint8),                       # first run (zeros) is empty
+        "one_pixel": np.eye(1, 40, 17, dtype=np.uint8).reshape(5, 8),
+        "ellipse": (((yy - 40) / 30.0) ** 2 + ((xx - 70) / 45.0) ** 2 <= 1).astype(np.uint8),
+        "noise": (rng.rand(37, 23) > 0.5).astype(np.uint8),
+        "checker": ((yy[:16, :16] + xx[:16, :16]) & 1).astype(np.uint8),
+        "sparse": (rng.rand(64, 64) > 0.98).astype(np.uint8),
+        "last_pixel": np.eye(1, 35, 34, dtype=np.uint8).reshape(5, 7),
+    }
+    big = np.zeros((300, 400), np.uint8)
+    big[:, :250] = 1                                              # 75000-long run: 4-char groups
+    big[10:20, 300:310] = 1
+    masks["long_runs"] = big
+    shr = np.zeros((200, 3), np.uint8)                            # shrinking runs: negative deltas
+    shr[:150, 0] = 1; shr[100:, 1] = 1; shr[5:8, 2] = 1
+    masks["negative_delta"] = shr
+    arrs = {"names": np.array(sorted(masks))}
+    for name in sorted(masks):
+        cnts, s = orc.ref_rle_encode(masks[name])
+        arrs["mask/" + name] = masks[name]
+        arrs["counts/" + name] = cnts
+        arrs["string/" + name] = np.frombuffer(s, np.uint8)
+    save("rle", **arrs)
+
+    ref_harness.install()
+    import scipy.misc
+    from tools.gen_golden_e2e import imresize
+    scipy.misc.imresize = imresize
+    import utils as ref_utils
+    ref_utils.scipy.misc.imresize = imresize
+    H, W = 160, 192
+    boxes = [(10, 20, 100, 150), (0, 0, 160, 192), (50, 60, 82, 92), (30, 40, 37, 190), (5, 5, 6, 6),
+             (100, 3, 159, 20), (20, 100, 140, 111), (64, 64, 96, 160), (0, 170, 33, 192), (90, 90, 93, 95)]
+    ms, fulls = [], []
+    for i, b in enumerate(boxes):
+        m = rng.randn(32, 32).astype(np.float32)
+        if i % 3 == 0:
+            m = (1 / (1 + np.exp(-3 * m))).astype(np.float32)     # sigmoid-like head output
+        if i == 4:
+            m[:] = 0.25                                            # constant mask: cscale == 0 branch
+        if i % 3 == 1:                                             # smooth blob like a trained head
+            gy, gx = np.mgrid[0:32, 0:32]
+            m = np.exp(-(((gy - 15.5) / 9.0) ** 2 + ((gx - 14) / 11.0) ** 2)).astype(np.float32)
+        ms.append(m)
+        fulls.append(ref_utils.unmold_mask(m.copy(), np.array(b, np.int32), (H, W, 3)))
+    save("unmold", masks=np.stack(ms), boxes=np.array(boxes, np.int32), image_shape=np.array([H, W, 3]),
+         full=np.packbits(np.stack(fulls), axis=-1), pillow=np.array(__import__("PIL").__version__))
+
+
+if __name__ == "__main__" and "--tail" in sys.argv:
+    tail_goldens()
