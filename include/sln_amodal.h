@@ -176,6 +176,30 @@ int sln_topk_order_f32(const float *scores, int B, int A, long stride_b, long st
                        int64_t *order, sln_stream_t stream);
 
 /* ---------------------------------------------------------------------------
+ * Optimiser step: global-norm clip + momentum SGD over the whole parameter set.
+ * Replaces: torch.nn.utils.clip_grad_norm(params, 5.0) followed by torch.optim.SGD.step()
+ *           (model.py:441-444, optimizer built at model.py:352-358): one norm kernel per tensor,
+ *           a host-side sum, then 4-5 elementwise kernels per tensor.
+ * The n tensors are cut into chunks of chunk_elems elements; every table below lives in DEVICE
+ * memory:  params/grads/bufs [n] pointers, numel [n], weight_decay [n] (per tensor: the reference's
+ * two parameter groups), chunk_tensor [n_chunks] (tensor index), chunk_offset [n_chunks] (first
+ * element).  Momentum buffers start at zero (the first step then stores d, like SGD's clone).
+ *
+ * sln_grad_sqnorm_f32   partial [n_chunks] float64 scratch; sqnorm [1] float64 = sum of squares of
+ *                       every gradient element (float64 accumulation, fixed order: reproducible).
+ * sln_sgd_clip_step_f32 c = max_norm / (sqrt(sqnorm) + 1e-6), applied when < 1 (clip_grad_norm);
+ *                       d = g*c + wd*p;  buf = momentum*buf + d;  p = p - lr*buf  (dampening 0,
+ *                       no nesterov).  Gradients are read, not rewritten.
+ * ------------------------------------------------------------------------- */
+int sln_grad_sqnorm_f32(const float *const *grads, const int64_t *numel, const int32_t *chunk_tensor,
+                        const int64_t *chunk_offset, int n_chunks, int chunk_elems, double *partial,
+                        double *sqnorm, sln_stream_t stream);
+int sln_sgd_clip_step_f32(float *const *params, const float *const *grads, float *const *bufs,
+                          const int64_t *numel, const float *weight_decay, const int32_t *chunk_tensor,
+                          const int64_t *chunk_offset, int n_chunks, int chunk_elems, const double *sqnorm,
+                          float max_norm, float lr, float momentum, sln_stream_t stream);
+
+/* ---------------------------------------------------------------------------
  * Inference tail: full-size masks and their COCO run-length encoding.
  *
  * sln_unmold_masks_u8

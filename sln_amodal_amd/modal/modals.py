@@ -197,8 +197,10 @@ def pyramid_roi_align_image(inputs, pool_size, image_shape, istrain=False, box_i
         # (allocated and sliced with grad mode as it is: autograd forbids the later in-place fill of a
         # view that was created under no_grad; the crop itself is not an autograd op)
         K, Cc = boxes.shape[0], image.shape[1]
-        wide = torch.empty((K, pool_size, pool_size, Cc + cat_extra), dtype=torch.float32,
-                           device=image.device).permute(0, 3, 1, 2)
+        # (not a permuted view: marking a VIEW dirty in _PyramidCropInto makes autograd wrap it in
+        # CopySlices, whose backward clones the [K, C+E, pool, pool] gradient three times)
+        wide = torch.empty((K, Cc + cat_extra, pool_size, pool_size), dtype=torch.float32,
+                           device=image.device, memory_format=torch.channels_last)
         ptrs = (C.c_void_p * 4)(*[image.data_ptr()] * 4)
         hw = (C.c_int * 8)(*[image.shape[2], image.shape[3]] * 4)
         level = torch.full((K,), 2, dtype=torch.int32, device=image.device)

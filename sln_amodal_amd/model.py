@@ -22,7 +22,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import utils
+from . import nn_ops, utils
 from .modal import loss as L
 from .modal.Functions import (build_rpn_targets, compose_image_meta, detection_layer,  # noqa: F401
                               detection_target_layer, log, mold_image, proposal_layer)
@@ -288,9 +288,11 @@ class MaskRCNN(nn.Module):
         (model.py:352-358)."""
         wd = [p for n, p in self.named_parameters() if p.requires_grad and "bn" not in n]
         no_wd = [p for n, p in self.named_parameters() if p.requires_grad and "bn" in n]
-        return torch.optim.SGD([{"params": wd, "weight_decay": self.config.WEIGHT_DECAY},
-                                {"params": no_wd}], lr=learning_rate,
-                               momentum=self.config.LEARNING_MOMENTUM)
+        groups = [{"params": wd, "weight_decay": self.config.WEIGHT_DECAY}, {"params": no_wd}]
+        if self.anchors.is_cuda and nn_ops.BACKEND != "torch":
+            from .optim import ClippedSGD         # clip + SGD fused over device-side tables
+            return ClippedSGD(groups, lr=learning_rate, momentum=self.config.LEARNING_MOMENTUM)
+        return torch.optim.SGD(groups, lr=learning_rate, momentum=self.config.LEARNING_MOMENTUM)
 
     def train_step(self, batch, optimizer, grad_sync=None, priorities=None):
         """One optimisation step on a batch: predict -> six losses -> backward ->
@@ -316,6 +318,10 @@ class MaskRCNN(nn.Module):
         non-'bn' parameters (model.py:441-444, 352-358).  Runs after the all-reduce: a parameter
         without a local gradient may have received one from a peer, and every rank must clip over
         the same set."""
+        from .optim import ClippedSGD
+        if isinstance(optimizer, ClippedSGD):
+            self.last_grad_norm = optimizer.step(self.config.GRADIENT_CLIP_NORM)
+            return
         params = [p for p in self.parameters() if p.requires_grad and p.grad is not None]
         self.last_grad_norm = torch.nn.utils.clip_grad_norm_(params, self.config.GRADIENT_CLIP_NORM)
         optimizer.step()

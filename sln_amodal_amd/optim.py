@@ -1,0 +1,107 @@
+"""Clip + SGD for the train step, one pass over device-resident tables instead of ~3000 small aten
+launches: the reference's torch.nn.utils.clip_grad_norm(params, 5.0) followed by
+torch.optim.SGD(momentum, weight decay on the non-'bn' group).step() (model.py:352-358, 441-444)."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+CHUNK = 1 << 16
+
+
+class ClippedSGD(object):
+    """param_groups like torch.optim.SGD's ([{'params': [...], 'weight_decay': w}, ...]).  step(max_norm)
+    clips over every parameter that holds a gradient and applies momentum SGD; the total gradient norm
+    is left in `last_norm` (0-d float32 device tensor, no host sync)."""
+
+    def __init__(self, param_groups, lr, momentum=0.0):
+        self.param_groups = []
+        for g in param_groups:
+            g = dict(g)
+            g["params"] = list(g["params"])
+            g.setdefault("weight_decay", 0.0)
+            g.setdefault("lr", lr)
+            g.setdefault("momentum", momentum)
+            self.param_groups.append(g)
+        self.lr, self.momentum = float(lr), float(momentum)
+        self.state = {}                      # param -> momentum buffer
+        self._plan_key, self._plan = None, None
+        self.last_norm = None
+
+    def zero_grad(self, set_to_none=True):
+        for g in self.param_groups:
+            for p in g["params"]:
+                if set_to_none:
+                    p.grad = None
+                elif p.grad is not None:
+                    p.grad.zero_()
+
+    def _active(self):
+        out = []
+        for g in self.param_groups:
+            for p in g["params"]:
+                if p.grad is not None:
+                    out.append((p, float(g["weight_decay"])))
+        return out
+
+    def _chunks(self, numels, wds, device):
+        key = (tuple(numels), tuple(wds))
+        if key != self._plan_key:
+            ct, co = [], []
+            for i, n in enumerate(numels):
+                for off in range(0, n, CHUNK):
+                    ct.append(i)
+                    co.append(off)
+            self._plan = (torch.tensor(ct, dtype=torch.int32, device=device),
+                          torch.tensor(co, dtype=torch.int64, device=device),
+                          torch.tensor(numels, dtype=torch.int64, device=device),
+                          torch.empty(max(len(ct), 1), dtype=torch.float64, device=device),
+                          torch.tensor(wds, dtype=torch.float32, device=device))
+            self._plan_key = key
+        return self._plan
+
+    @torch.no_grad()
+    def step(self, max_norm):
+        act = self._active()
+        if not act:
+            return None
+        dev = act[0][0].device
+        if dev.type != "cuda":
+            raise RuntimeError("ClippedSGD runs on the GPU only (no CPU fallback in sln_amodal_amd)")
+        ps, gs, bs = [], [], []
+        for p, _ in act:
+            g = p.grad
+            if p.dtype != torch.float32 or g.dtype != torch.float32:
+                raise TypeError("ClippedSGD needs float32 parameters and gradients")
+            if not (p.is_contiguous() or (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last))):
+                raise ValueError("parameters must be dense")
+            if g.stride() != p.stride():       # element i of the gradient must be element i of the weight
+                g = torch.empty_like(p).copy_(g)
+            b = self.state.get(p)
+            if b is None:
+                b = self.state[p] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            ps.append(p); gs.append(g); bs.append(b)
+        n = len(ps)
+        ct, co, numel, partial, wd = self._chunks([p.numel() for p in ps], [w for _, w in act], dev)
+        host = np.empty((3, n), np.int64)
+        host[0] = [p.data_ptr() for p in ps]
+        host[1] = [g.data_ptr() for g in gs]
+        host[2] = [b.data_ptr() for b in bs]
+        tab = torch.from_numpy(host).to(dev)
+        sq = torch.empty(1, dtype=torch.float64, device=dev)
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        L = _lib.lib()
+        vp = lambda t: C.c_void_p(t.data_ptr())
+        nch = ct.numel() if sum(p.numel() for p in ps) else 0
+        _lib.check(L.sln_grad_sqnorm_f32(vp(tab[1]), vp(numel), vp(ct), vp(co), nch, CHUNK, vp(partial), vp(sq),
+                                         st), "sln_grad_sqnorm_f32")
+        _lib.check(L.sln_sgd_clip_step_f32(vp(tab[0]), vp(tab[1]), vp(tab[2]), vp(numel), vp(wd), vp(ct), vp(co),
+                                           nch, CHUNK, vp(sq), float(max_norm), self.lr, self.momentum, st),
+                   "sln_sgd_clip_step_f32")
+        # caches keyed by the weights' version counters (split weight parts) must see the update
+        torch._C._autograd._unsafe_set_version_counter(ps, [p._version + 1 for p in ps])
+        self._keep = (tab, gs)                # alive until the next step: the launches above are asynchronous
+        self.last_norm = sq.sqrt().to(torch.float32)[0]
+        return self.last_norm
