@@ -245,6 +245,14 @@ int64_t sln_rle_from_string(const char *s, int64_t len, uint32_t *counts, int64_
  * sln_conv_split_weights_f32  fp32 weights with element strides (s_o,s_i,s_kh,s_kw)
  *     -> out [parts][O][KH][KW][I_pad] bf16.  flip=1 mirrors the taps (data grad).
  * sln_act_split_f32           x [M][C] fp32 -> out [parts][M][C_pad] bf16.
+ * sln_im2col_split_f32        patch matrix of a small-Cin convolution as operand parts: x
+ *     [N,H,W,C] fp32 -> rows [row0, row0 + N*OH*OW) of out [parts][out_rows][K_pad], column
+ *     k = (kh, kw, c), K = KH*KW*C zero-padded to K_pad (% 8 == 0); taps outside the image are zero.
+ *     The 3-channel 7x7/2 stems (modal/modals.py:311, modal/resnet_deeplab.py conv1) then run as a
+ *     1x1 convolution over K_pad channels on sln_conv2d_fwd_f32 / sln_conv2d_wgrad_f32 (weights
+ *     reordered to [Cout][KH][KW][C]); replaces the cuDNN 7x7 calls.  out == NULL: amax only.
+ * sln_col2im_f32              adjoint of the patch matrix: cols [N*OH*OW][K_pad] fp32 (a 1x1 data
+ *     gradient over the K_pad channels) -> gx [N,H,W,C]; only needed when the image carries a gradient.
  * sln_conv_grad_prep_f32      gz = gy * (y > 0) * scale[c] (y, scale optional):
  *     writes gu = gy*(y>0) fp32 [M][C] (optional), gz parts [parts][M][C_pad] and
  *     the per-channel sum of gz into gbias [C] (optional, zeroed by the callee).
@@ -313,6 +321,12 @@ int sln_conv_split_weights_f32(const float *w, int O, int I, int I_pad, int KH, 
                                long s_i, long s_kh, long s_kw, int flip, int parts, int layout,
                                uint16_t *out, const float *q_scale, float *q_amax,
                                int32_t *q_saturated, sln_stream_t stream);
+int sln_im2col_split_f32(const float *x, int N, int H, int W, int C, int KH, int KW, int stride_h,
+                         int stride_w, int pad_top, int pad_left, int OH, int OW, int K_pad, int parts,
+                         uint16_t *out, int64_t out_rows, int64_t row0, const float *q_scale, float *q_amax,
+                         int32_t *q_saturated, sln_stream_t stream);
+int sln_col2im_f32(const float *cols, int N, int H, int W, int C, int KH, int KW, int stride_h, int stride_w,
+                   int pad_top, int pad_left, int OH, int OW, int K_pad, float *gx, sln_stream_t stream);
 int sln_act_split_f32(const float *x, int64_t M, int C, int C_pad, int parts, uint16_t *out,
                       const float *q_scale, float *q_amax, int32_t *q_saturated, sln_stream_t stream);
 int sln_conv_grad_prep_f32(const float *gy, const float *y, const float *scale, int64_t M, int C,

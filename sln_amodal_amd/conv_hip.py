@@ -131,8 +131,9 @@ def _q3(slot):
 
 
 def supports(conv, x):
-    """The 3-channel stems (K = 7*7*3) stay on aten: padded to 8 channels the implicit
-    GEMM wastes 5/8 of K and, in the weight gradient, 125/128 of the N tile."""
+    """Convolutions the implicit-GEMM kernels take directly.  The 3-channel stems (K = 7*7*3) go
+    through _StemFn instead (im2col to K = 160 + 1x1 convolution): padded to 8 channels per tap the
+    implicit GEMM would waste 5/8 of K."""
     return (x.dtype == torch.float32 and conv.groups == 1 and conv.weight.dtype == torch.float32 and
             conv.padding_mode == "zeros" and conv.in_channels >= 8)
 
@@ -666,6 +667,114 @@ class _ConvFn(torch.autograd.Function):
                       _nbytes(gz, xp), _nbytes(gw_t))
             gw = gw_t.permute(0, 3, 1, 2)  # logical [Co,Ci,KH,KW]
         return gx, gw, g_bias, None, None, g_res, None, None, None, None, None, None, None, None
+
+
+class _StemFn(torch.autograd.Function):
+    """The 3-channel 7x7/2 input convolutions (modal/modals.py:311 C1, modal/resnet_deeplab.py conv1) on
+    the HIP stack: sln_im2col_split_f32 writes the patch matrix [N*OH*OW, 160] (K = 7*7*3 = 147, zero
+    padded) directly as operand parts, and the layer runs as a 1x1 convolution over those 160 channels --
+    forward with the fused bias / frozen-BN / ReLU epilogue, weight gradient on the ordinary wgrad
+    kernels (the image needs no data gradient).  Replaces the MIOpen calls, the separate bias / BN /
+    ReLU passes and the NCHW -> NHWC copy of their output."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, bn_scale, bn_shift, relu, stride, pads):
+        parts = PARTS
+        if PARTS_NOGRAD and not any(ctx.needs_input_grad):
+            parts = PARTS_NOGRAD
+        Co, Ci, KH, KW = weight.shape
+        xc = _nhwc(x.detach())
+        N, _, H, W = xc.shape
+        pt, pb, pl, pr = pads
+        OH = (H + pt + pb - KH) // stride[0] + 1
+        OW = (W + pl + pr - KW) // stride[1] + 1
+        K = Ci * KH * KW
+        Kp = (K + 31) // 32 * 32
+        M = N * OH * OW
+        xslot = _slot(weight, ("x", H, W)) if parts == 2 else None
+        xp = torch.empty((parts, M, Kp), dtype=torch.bfloat16, device=xc.device)
+
+        def launch(dst):
+            _lib.check(_lib.lib().sln_im2col_split_f32(
+                ops._ptr(xc), N, H, W, Ci, KH, KW, stride[0], stride[1], pt, pl, OH, OW, Kp, parts,
+                ops._ptr(dst), M, 0, *_q3(xslot), ops._stream()), "sln_im2col_split_f32")
+        if xslot is not None and xslot.fresh:
+            launch(None)
+            xslot.book.settle(xslot)
+        launch(xp)
+        xq = xslot.scale if xslot is not None else None
+        hit = getattr(weight, "_sln_stem_w", None)
+        if hit is None or hit[0] != weight._version:      # [Co, (kh, kw, c)] zero padded, as a 1x1 kernel
+            w2 = torch.zeros((Co, Kp), dtype=torch.float32, device=weight.device)
+            w2[:, :K] = weight.detach().permute(0, 2, 3, 1).reshape(Co, K)
+            hit = weight._sln_stem_w = (weight._version, w2.view(Co, Kp, 1, 1))
+        w2 = hit[1]
+        scale, shift = bn_scale, bn_shift
+        if bias is not None:
+            shift = bias * bn_scale + bn_shift if bn_scale is not None else bias
+        if shift is not None:
+            shift = shift.detach().contiguous()
+        if scale is not None:
+            scale = scale.detach().contiguous()
+        y = _fwd(xp, N, OH, OW, wsrc(w2, parts, False, weight), Co, 1, 1, (1, 1), (1, 1), 0, 0, OH, OW, scale,
+                 shift, None, relu, cin=K, xq=xq)
+        need_w = ctx.needs_input_grad[1]
+        ctx.save_for_backward(xp if need_w else None, scale, y if relu else None, xq if need_w else None)
+        ctx.cfg = (N, OH, OW, Co, Ci, KH, KW, K, Kp, parts, relu, bias is not None)
+        ctx.geom = (H, W, stride, pt, pl)
+        ctx.w2 = w2 if ctx.needs_input_grad[0] else None
+        ctx.own = weight
+        ctx.gzslot = _slot(weight, ("gz", OH, OW)) if parts == 2 else None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        xp, scale, y, xq = ctx.saved_tensors
+        N, OH, OW, Co, Ci, KH, KW, K, Kp, parts, relu, has_bias = ctx.cfg
+        need_w = ctx.needs_input_grad[1]
+        want_bias = has_bias and ctx.needs_input_grad[2]
+        gx = gw = g_bias = None
+        need_x = ctx.needs_input_grad[0]
+        if need_w or want_bias or need_x:
+            gz, _, g_bias = _grad_prep(gy, y, scale, False, want_bias, parts, slot=ctx.gzslot)
+            gzq = ctx.gzslot.scale if parts == 2 else None
+        if need_x:     # (module-level use only: the model's image carries no gradient)
+            H, W, stride, pt, pl = ctx.geom
+            gcols = _fwd(gz, N, OH, OW, wsrc(ctx.w2, parts, True, ctx.own), Kp, 1, 1, (1, 1), (1, 1), 0, 0, OH, OW,
+                         None, None, None, False, cin=Co, xq=gzq)
+            gx = torch.empty((N, H, W, Ci), dtype=torch.float32, device=gy.device).permute(0, 3, 1, 2)
+            _lib.check(_lib.lib().sln_col2im_f32(ops._ptr(_nhwc(gcols)), N, H, W, Ci, KH, KW, stride[0], stride[1],
+                                                 pt, pl, OH, OW, Kp, ops._ptr(gx), ops._stream()), "sln_col2im_f32")
+        if need_w:
+            gw_t = torch.empty((Co, 1, 1, Kp), dtype=torch.float32, device=gy.device)
+            ws, ws_bytes = None, 0
+            if DETERMINISTIC_WGRAD:
+                ws_bytes = _lib.lib().sln_conv_wgrad_workspace_bytes(N * OH * OW, Co, Kp, 1, parts)
+                ws = ops._workspace(max(ws_bytes, 16), gy.device)
+            e0 = _prof_begin()
+            _lib.check(_lib.lib().sln_conv2d_wgrad_f32(
+                ops._ptr(gz), Co, gz.shape[2], ops._ptr(xp), N, OH, OW, Kp, Kp, parts, 1, 1, 1, 1, 1, 1, 0, 0,
+                OH, OW, ops._ptr(gw_t), ops._ptr(gzq), ops._ptr(xq), ops._ptr(ws), ws_bytes, ops._stream()),
+                "sln_conv2d_wgrad_f32")
+            _prof_end(e0, 2.0 * N * OH * OW * Co * K, "conv_wgrad_kernel<%d>" % parts,
+                      "wgrad stem N%d %dx%d K%d->%d" % (N, OH, OW, K, Co), _nbytes(gz, xp), _nbytes(gw_t))
+            gw = gw_t.view(Co, Kp)[:, :K].reshape(Co, KH, KW, Ci).permute(0, 3, 1, 2)
+        return gx, gw, g_bias, None, None, None, None, None
+
+
+def is_stem(conv, x):
+    """The small-Cin input convolutions _StemFn covers."""
+    return (x.is_cuda and x.dtype == torch.float32 and conv.groups == 1 and tuple(conv.dilation) == (1, 1) and
+            conv.in_channels * conv.kernel_size[0] * conv.kernel_size[1] <= 256 and conv.in_channels < 8 and
+            conv.out_channels % 8 == 0)
+
+
+def stem_conv_bn_act(x, conv, bn, relu, pads):
+    from .nn_ops import bn_affine
+    scale = shift = None
+    if bn is not None:
+        scale, shift = bn_affine(bn)
+    return _StemFn.apply(x, conv.weight, conv.bias, scale, shift, bool(relu), tuple(conv.stride), tuple(pads))
 
 
 _DUMMY = {}

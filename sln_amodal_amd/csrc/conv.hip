@@ -165,6 +165,90 @@ __global__ __launch_bounds__(256) void act_split_kernel(const float *__restrict_
     if (P == 2) amax_commit(amx, sat, q, s_word);
 }
 
+// Patch matrix of a small-Cin convolution (the 3-channel 7x7/2 stems, modals.py:311 and
+// resnet_deeplab.py's conv1), emitted directly as operand parts: row m = output pixel (n, oh, ow),
+// column k = (kh, kw, c), K = KH*KW*C padded with zeros to K_pad; taps outside the image are zero.
+// The stem then IS a 1x1 convolution over K_pad channels and runs on the ordinary forward / weight-
+// gradient kernels.  Lanes run along k, so a wave writes 512 contiguous bytes per part; the tap ->
+// (input offset, kh, kw) table is built once per block in LDS.  parts == NULL: amax only.
+template <int P>
+__global__ __launch_bounds__(256) void im2col_split_kernel(const float *__restrict__ x, int N, int H, int W,
+                                                           int C, int KH, int KW, int sh, int sw, int pt, int pl,
+                                                           int OH, int OW, int Kp, long pstride, long row0,
+                                                           __bf16 *__restrict__ parts, SplitScale q) {
+    extern __shared__ int s_tab[];            // [Kp] input offset, [Kp] kh | kw << 8 | valid << 16
+    __shared__ unsigned s_word[2];
+    int *s_off = s_tab, *s_pos = s_tab + Kp;
+    const int K = KH * KW * C;
+    for (int k = threadIdx.x; k < Kp; k += 256) {
+        const int kh = k / (KW * C), r = k - kh * KW * C;
+        const int kw = r / C;
+        s_off[k] = (kh * W + kw) * C + (r - kw * C);
+        s_pos[k] = k < K ? (kh | (kw << 8) | (1 << 16)) : 0;
+    }
+    __syncthreads();
+    const int q4 = Kp / 4;
+    const long M = (long)N * OH * OW, total = M * q4;
+    const float qs = (P == 2 && q.scale) ? *q.scale : 1.f;
+    float amx = 0.f;
+    bool sat = false;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long m = e / q4;
+        const int kq = (int)(e - m * q4) * 4;
+        const int ow = (int)(m % OW);
+        const long t = m / OW;
+        const int oh = (int)(t % OH), n = (int)(t / OH);
+        const int ih0 = oh * sh - pt, iw0 = ow * sw - pl;
+        const float *px = x + (((long)n * H + ih0) * W + iw0) * C;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int pos = s_pos[kq + j];
+            const int ih = ih0 + (pos & 255), iw = iw0 + ((pos >> 8) & 255);
+            const bool ok = (pos >> 16) && ih >= 0 && ih < H && iw >= 0 && iw < W;
+            v[j] = ok ? px[s_off[kq + j]] : 0.f;
+        }
+        if (P == 2) amx = amax4(amx, v);
+        if (!parts) continue;
+        bf16x4 ps[P];
+        sat |= split4<P>(make_float4(v[0], v[1], v[2], v[3]), ps, qs);
+#pragma unroll
+        for (int p = 0; p < P; ++p) *(bf16x4 *)(parts + p * pstride + (row0 + m) * Kp + kq) = ps[p];
+    }
+    if (P == 2) amax_commit(amx, sat, q, s_word);
+}
+
+// Adjoint of the patch matrix (data gradient of a stem, needed only when the image itself carries a
+// gradient): gx[n, ih, iw, c] = sum over the taps (kh, kw) whose output pixel exists of
+// cols[(n, oh, ow), (kh, kw, c)].  Gather form: one thread per input element, no atomics.
+__global__ __launch_bounds__(256) void col2im_kernel(const float *__restrict__ cols, int N, int H, int W, int C,
+                                                     int KH, int KW, int sh, int sw, int pt, int pl, int OH,
+                                                     int OW, int Kp, float *__restrict__ gx) {
+    const long total = (long)N * H * W * C;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int c = (int)(e % C);
+        long t = e / C;
+        const int iw = (int)(t % W);
+        t /= W;
+        const int ih = (int)(t % H), n = (int)(t / H);
+        float acc = 0.f;
+        for (int kh = 0; kh < KH; ++kh) {
+            const int ty = ih + pt - kh;
+            if (ty < 0 || ty % sh) continue;
+            const int oh = ty / sh;
+            if (oh >= OH) continue;
+            for (int kw = 0; kw < KW; ++kw) {
+                const int tx = iw + pl - kw;
+                if (tx < 0 || tx % sw) continue;
+                const int ow = tx / sw;
+                if (ow >= OW) continue;
+                acc += cols[(((long)n * OH + oh) * OW + ow) * Kp + (kh * KW + kw) * C + c];
+            }
+        }
+        gx[e] = acc;
+    }
+}
+
 // gz = gy * (y > 0 ? 1 : 0) * scale[c]; writes gu = gy*(y>0) (fp32, optional), the
 // bf16 parts of gz, and accumulates the per-channel sum of gz (bias gradient).
 // A thread keeps one channel quad and walks rows (no index division, bias sums stay in
@@ -1974,6 +2058,48 @@ extern "C" int sln_act_split_f32(const float *x, int64_t M, int C, int C_pad, in
     else
         hipLaunchKernelGGL(act_split_kernel<3>, dim3(ew_grid(M * (C_pad / 4))), dim3(256), 0,
                            (hipStream_t)stream, x, (long)M, C, C_pad, (__bf16 *)out, q);
+    return sln_launch_status();
+}
+
+extern "C" int sln_im2col_split_f32(const float *x, int N, int H, int W, int C, int KH, int KW, int stride_h,
+                                    int stride_w, int pad_top, int pad_left, int OH, int OW, int K_pad,
+                                    int parts, uint16_t *out, int64_t out_rows, int64_t row0,
+                                    const float *q_scale, float *q_amax, int32_t *q_saturated,
+                                    sln_stream_t stream) {
+    sln_enter();
+    if (N < 0 || H < 1 || W < 1 || C < 1 || KH < 1 || KW < 1 || KH > 255 || KW > 255 || stride_h < 1 ||
+        stride_w < 1 || OH < 1 || OW < 1 || parts < 2 || parts > 3)
+        return SLN_ERR_INVALID_ARG;
+    if (K_pad < KH * KW * C || (K_pad & 7) || K_pad > 4096) return SLN_ERR_INVALID_ARG;
+    const long M = (long)N * OH * OW;
+    if (row0 < 0 || row0 + M > out_rows) return SLN_ERR_INVALID_ARG;
+    if (M == 0) return SLN_OK;
+    if (!x || (!out && !(parts == 2 && q_amax))) return SLN_ERR_INVALID_ARG;
+    const SplitScale q = {q_scale, q_amax, q_saturated};
+    const size_t lds = sizeof(int) * 2 * (size_t)K_pad;
+    const long pstride = (long)out_rows * K_pad;
+    if (parts == 2)
+        hipLaunchKernelGGL(im2col_split_kernel<2>, dim3(ew_grid(M * (K_pad / 4))), dim3(256), lds,
+                           (hipStream_t)stream, x, N, H, W, C, KH, KW, stride_h, stride_w, pad_top, pad_left, OH,
+                           OW, K_pad, pstride, (long)row0, (__bf16 *)out, q);
+    else
+        hipLaunchKernelGGL(im2col_split_kernel<3>, dim3(ew_grid(M * (K_pad / 4))), dim3(256), lds,
+                           (hipStream_t)stream, x, N, H, W, C, KH, KW, stride_h, stride_w, pad_top, pad_left, OH,
+                           OW, K_pad, pstride, (long)row0, (__bf16 *)out, q);
+    return sln_launch_status();
+}
+
+extern "C" int sln_col2im_f32(const float *cols, int N, int H, int W, int C, int KH, int KW, int stride_h,
+                              int stride_w, int pad_top, int pad_left, int OH, int OW, int K_pad, float *gx,
+                              sln_stream_t stream) {
+    sln_enter();
+    if (N < 0 || H < 1 || W < 1 || C < 1 || KH < 1 || KW < 1 || stride_h < 1 || stride_w < 1 || OH < 1 ||
+        OW < 1 || K_pad < KH * KW * C)
+        return SLN_ERR_INVALID_ARG;
+    if (N == 0) return SLN_OK;
+    if (!cols || !gx) return SLN_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(col2im_kernel, dim3(ew_grid((long)N * H * W * C)), dim3(256), 0, (hipStream_t)stream, cols,
+                       N, H, W, C, KH, KW, stride_h, stride_w, pad_top, pad_left, OH, OW, K_pad, gx);
     return sln_launch_status();
 }
 

@@ -65,11 +65,6 @@ def bn_affine(bn):
     return scale, shift
 
 
-def _is_stem(conv):
-    """The 3-channel 7x7/2 input convolutions (modals.py:311, resnet_deeplab.py stem)."""
-    return conv.in_channels == 3 and tuple(conv.kernel_size) == (7, 7)
-
-
 def conv_bn_act(x, conv, bn=None, relu=False, residual=None, same=False, link=None, chain_in=None,
                 chain_out=None):
     """x [B,C,H,W] (any memory format; channels-last preferred).
@@ -93,8 +88,10 @@ def conv_bn_act(x, conv, bn=None, relu=False, residual=None, same=False, link=No
     if hip is not None and x.is_cuda and hip.supports(conv, x):
         return hip.conv_bn_act(x, conv, bn, relu, residual, (pt, pb, pl, pr), link=link,
                                chain_in=chain_in, chain_out=chain_out)
-    if BACKEND != "torch" and x.is_cuda and not _is_stem(conv):
-        # no silent aten/MIOpen fallback on the GPU: only the two 3-channel 7x7 stems are aten by design
+    if hip is not None and not isinstance(x, hip.MultiScale) and hip.is_stem(conv, x) and residual is None:
+        return hip.stem_conv_bn_act(x, conv, bn, relu, (pt, pb, pl, pr))   # 3-channel 7x7/2 stems
+    if BACKEND != "torch" and x.is_cuda:
+        # no silent aten/MIOpen fallback on the GPU
         raise RuntimeError("conv %s -> %s k%s groups=%d dtype=%s has no HIP path (nn_ops.BACKEND=%r); "
                            "set BACKEND='torch' explicitly to run it on aten" %
                            (conv.in_channels, conv.out_channels, tuple(conv.kernel_size), conv.groups,

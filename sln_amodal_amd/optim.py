@@ -28,6 +28,7 @@ class ClippedSGD(object):
         self.lr, self.momentum = float(lr), float(momentum)
         self.state = {}                      # param -> momentum buffer
         self._plan_key, self._plan = None, None
+        self._ring, self._turn = [], 0       # pinned staging buffers of the pointer tables
         self.last_norm = None
 
     def zero_grad(self, set_to_none=True):
@@ -85,11 +86,24 @@ class ClippedSGD(object):
             ps.append(p); gs.append(g); bs.append(b)
         n = len(ps)
         ct, co, numel, partial, wd = self._chunks([p.numel() for p in ps], [w for _, w in act], dev)
-        host = np.empty((3, n), np.int64)
+        # Pointer tables: gradients are fresh allocations every step, so the tables are re-sent each
+        # time -- from pinned staging buffers and asynchronously, so the host never waits for the GPU
+        # here (a pageable copy would drain the stream once per step).  A staging buffer is reused
+        # only after the copy that read it has completed (4 in flight).
+        if not self._ring or self._ring[0][0].shape[1] != n:
+            self._ring = [[torch.empty((3, n), dtype=torch.int64, pin_memory=True), None] for _ in range(4)]
+        stage = self._ring[self._turn % len(self._ring)]
+        self._turn += 1
+        if stage[1] is not None:
+            stage[1].synchronize()
+        host = stage[0].numpy()
         host[0] = [p.data_ptr() for p in ps]
         host[1] = [g.data_ptr() for g in gs]
         host[2] = [b.data_ptr() for b in bs]
-        tab = torch.from_numpy(host).to(dev)
+        tab = torch.empty((3, n), dtype=torch.int64, device=dev)
+        tab.copy_(stage[0], non_blocking=True)
+        stage[1] = torch.cuda.Event()
+        stage[1].record()
         sq = torch.empty(1, dtype=torch.float64, device=dev)
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         L = _lib.lib()

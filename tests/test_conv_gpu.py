@@ -622,3 +622,104 @@ def test_weight_gradient_is_bit_reproducible(parts, shape, monkeypatch):
     monkeypatch.setattr(conv_hip, "DETERMINISTIC_WGRAD", False)
     atomic = grad()
     assert torch.allclose(atomic, first, rtol=1e-4, atol=1e-5 * float(first.abs().max()))
+
+
+# ------------------------------------------------------------------ 3-channel stems (im2col + 1x1)
+STEMS = [
+    # N, H, W, pads: backbone C1 (modals.py:311, padding 3) and the GLM stem at its three scales
+    (2, 128, 128, (3, 3, 3, 3)),
+    (1, 513, 513, (3, 3, 3, 3)),
+    (2, 96, 64, (3, 3, 3, 3)),
+    (1, 65, 71, (2, 3, 2, 3)),          # asymmetric padding, odd sizes
+]
+
+
+@pytest.mark.parametrize("case", STEMS)
+@pytest.mark.parametrize("parts", [3, 2])
+def test_stem_forward_and_weight_gradient_match_fp64(case, parts, monkeypatch):
+    from sln_amodal_amd import conv_hip
+    monkeypatch.setattr(conv_hip, "PARTS", parts)
+    N, H, W, pads = case
+    g = torch.Generator(device="cuda").manual_seed(H * 3 + W)
+    # image-like input: uint8 minus the mean pixel
+    x = (torch.randint(0, 256, (N, 3, H, W), device="cuda", generator=g).float() - 115.0) \
+        .contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(64, 3, 7, 7, device="cuda", generator=g) / 147 ** 0.5).requires_grad_(True)
+    b = torch.randn(64, device="cuda", generator=g).requires_grad_(True)
+    scale = torch.rand(64, device="cuda", generator=g) + 0.5
+    shift = torch.randn(64, device="cuda", generator=g)
+    for rnd in range(2):                # second pass: delayed scales in steady state
+        y = conv_hip._StemFn.apply(x, w, b, scale, shift, True, (2, 2), pads)
+        wd, bd = w.detach().double().requires_grad_(True), b.detach().double().requires_grad_(True)
+        pre = _ref(x, wd, bd, scale, shift, None, False, 2, 1, pads)
+        ref = F.relu(pre.detach())
+        assert y.shape == ref.shape and y.is_contiguous(memory_format=torch.channels_last)
+        err = (y.double() - ref).abs().max().item() / ref.abs().max().item()
+        assert err < 5e-6, (case, parts, rnd, err)
+        up = torch.randn(y.shape, device="cuda", generator=g).contiguous(memory_format=torch.channels_last)
+        gw, gb = torch.autograd.grad(y, [w, b], up)
+        # the fp64 reference differentiates through the SAME ReLU switches as the kernel (its own output's
+        # sign): among 4 M units one or two pre-activations lie within the 5e-6 forward tolerance of zero,
+        # and a flipped switch moves a whole 147-tap weight row by ~1e-3 (see test_e2e_gpu's analysis)
+        rw, rb = torch.autograd.grad(pre * (y.detach() > 0), [wd, bd], up.double())
+        assert gw.shape == w.shape
+        assert (gw.double() - rw).abs().max().item() / rw.abs().max().item() < 2e-5, (case, parts, rnd)
+        assert (gb.double() - rb).abs().max().item() / rb.abs().max().item() < 2e-5, (case, parts, rnd)
+
+
+def test_stem_without_bn_bias_relu_and_forward_only():
+    from sln_amodal_amd import conv_hip
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn(2, 3, 40, 56, device="cuda", generator=g).contiguous(memory_format=torch.channels_last)
+    w = torch.randn(64, 3, 7, 7, device="cuda", generator=g) / 12
+    with torch.no_grad():
+        y = conv_hip._StemFn.apply(x, w, None, None, None, False, (2, 2), (3, 3, 3, 3))
+    ref = _ref(x, w, None, None, None, None, False, 2, 1, (3, 3, 3, 3))
+    assert (y.double() - ref).abs().max().item() / ref.abs().max().item() < 5e-6
+
+
+def test_stem_dispatch_replaces_miopen_and_matches_module_semantics():
+    """nn_ops.conv_bn_act routes the 3-channel 7x7 convs to _StemFn (no aten convolution on the GPU
+    path); same result as conv -> eval BatchNorm -> ReLU."""
+    from sln_amodal_amd import nn_ops
+    torch.manual_seed(0)
+    conv = nn.Conv2d(3, 64, 7, 2, 3).cuda()
+    bn = nn.BatchNorm2d(64, eps=1e-3).cuda().eval()
+    with torch.no_grad():
+        bn.running_mean.normal_(); bn.running_var.uniform_(0.5, 2); bn.weight.normal_(1, 0.1); bn.bias.normal_()
+    for p in bn.parameters():
+        p.requires_grad = False
+    x = torch.randn(2, 3, 64, 64, device="cuda").contiguous(memory_format=torch.channels_last)
+    from torch.profiler import ProfilerActivity, profile
+    with profile(activities=[ProfilerActivity.CPU]) as prof:
+        y = nn_ops.conv_bn_act(x, conv, bn, relu=True)
+    assert not any("convolution" in e.key for e in prof.key_averages())
+    want = F.relu(F.batch_norm(F.conv2d(x.double(), conv.weight.double(), conv.bias.double(), 2, 3),
+                               bn.running_mean.double(), bn.running_var.double(), bn.weight.double(),
+                               bn.bias.double(), False, 0.0, bn.eps))
+    assert (y.double() - want).abs().max().item() / want.abs().max().item() < 5e-6
+    y.sum().backward()
+    assert conv.weight.grad is not None and conv.weight.grad.shape == conv.weight.shape
+    assert conv.bias.grad is not None
+
+
+@pytest.mark.parametrize("parts", [3, 2])
+def test_stem_data_gradient_matches_fp64(parts, monkeypatch):
+    """Only module-level callers differentiate with respect to the image (the reference's FPN gradient
+    fixture does): im2col adjoint = 1x1 data gradient over the 160 patch channels + col2im gather."""
+    from sln_amodal_amd import conv_hip
+    monkeypatch.setattr(conv_hip, "PARTS", parts)
+    g = torch.Generator(device="cuda").manual_seed(17)
+    x = torch.randn(2, 3, 45, 38, device="cuda", generator=g).contiguous(memory_format=torch.channels_last)
+    x.requires_grad_(True)
+    w = (torch.randn(64, 3, 7, 7, device="cuda", generator=g) / 12).requires_grad_(True)
+    for pads in [(3, 3, 3, 3), (2, 3, 2, 3)]:
+        for _ in range(2):
+            y = conv_hip._StemFn.apply(x, w, None, None, None, False, (2, 2), pads)
+            up = torch.randn(y.shape, device="cuda", generator=g)
+            gx, gw = torch.autograd.grad(y, [x, w], up)
+        xd, wd = x.detach().double().requires_grad_(True), w.detach().double().requires_grad_(True)
+        rx, rw = torch.autograd.grad(_ref(xd, wd, None, None, None, None, False, 2, 1, pads), [xd, wd], up.double())
+        assert gx.shape == x.shape
+        assert (gx.double() - rx).abs().max().item() / rx.abs().max().item() < 2e-5
+        assert (gw.double() - rw).abs().max().item() / rw.abs().max().item() < 2e-5
