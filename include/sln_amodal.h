@@ -151,7 +151,9 @@ int sln_gather_rois_f32(const float *dets, const int64_t *keep, const int32_t *n
  * out       [K,ch,cw,out_cstride] NHWC rows; this op writes channels
  *           [out_coffset, out_coffset+C) of each row (fused concat,
  *           modal/modals.py:481).
- * backward  grad_maps: 4 device pointers [B,H_l,W_l,C], zeroed by the callee.
+ * backward  grad_maps: 4 device pointers [B,H_l,W_l,C]; accumulate = 0: zeroed by the callee first,
+ *           accumulate = 1: added to what they hold (several crops of the same maps -- classifier and
+ *           mask head, modal/modals.py:438, 479 -- then share one set of gradient maps).
  * ------------------------------------------------------------------------- */
 int sln_pyramid_crop_fwd_f32(const float *const *maps, const int32_t *map_hw, int B, int C,
                              const float *boxes, const int32_t *box_ind, const int32_t *level,
@@ -159,7 +161,7 @@ int sln_pyramid_crop_fwd_f32(const float *const *maps, const int32_t *map_hw, in
                              int out_cstride, int out_coffset, sln_stream_t stream);
 int sln_pyramid_crop_bwd_f32(const float *grads, int g_cstride, int g_coffset, const float *boxes,
                              const int32_t *box_ind, const int32_t *level, int K, int ch, int cw,
-                             int B, int C, float *const *grad_maps, const int32_t *map_hw,
+                             int B, int C, float *const *grad_maps, const int32_t *map_hw, int accumulate,
                              sln_stream_t stream);
 
 /* ---------------------------------------------------------------------------

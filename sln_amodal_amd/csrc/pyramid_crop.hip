@@ -280,7 +280,7 @@ extern "C" int sln_pyramid_crop_fwd_f32(const float *const *maps, const int32_t 
 extern "C" int sln_pyramid_crop_bwd_f32(const float *grads, int g_cstride, int g_coffset,
                                         const float *boxes, const int32_t *box_ind,
                                         const int32_t *level, int K, int ch, int cw, int B, int C,
-                                        float *const *grad_maps, const int32_t *map_hw,
+                                        float *const *grad_maps, const int32_t *map_hw, int accumulate,
                                         sln_stream_t stream) {
     sln_enter();
     if (!grad_maps || !map_hw || B < 0 || C < 1 || K < 0 || ch < 1 || cw < 1) return SLN_ERR_INVALID_ARG;
@@ -290,7 +290,7 @@ extern "C" int sln_pyramid_crop_bwd_f32(const float *grads, int g_cstride, int g
     for (int i = 0; i < 4; ++i) {
         gm.ptr[i] = grad_maps[i]; gm.H[i] = map_hw[2 * i]; gm.W[i] = map_hw[2 * i + 1];
         if (!gm.ptr[i] || gm.H[i] < 1 || gm.W[i] < 1) return SLN_ERR_INVALID_ARG;
-        if (B > 0 && hipMemsetAsync(gm.ptr[i], 0, sizeof(float) * (size_t)B * gm.H[i] * gm.W[i] * C, st) !=
+        if (!accumulate && B > 0 && hipMemsetAsync(gm.ptr[i], 0, sizeof(float) * (size_t)B * gm.H[i] * gm.W[i] * C, st) !=
                          hipSuccess)
             return SLN_ERR_LAUNCH;
     }

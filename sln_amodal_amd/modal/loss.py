@@ -36,10 +36,24 @@ def compute_rpn_bbox_loss(target_bbox, rpn_match, rpn_bbox, reduce=True):
     (loss.py:37-63)."""
     match = rpn_match.squeeze(2)
     pos = match == 1
-    rank = (torch.cumsum(pos.long(), dim=1) - 1).clamp(min=0, max=target_bbox.shape[1] - 1)
+    T = target_bbox.shape[1]
+    if rpn_bbox.is_cuda and T <= 8192 and T <= match.shape[1]:
+        # The positives are at most T of ~262 k anchors: select them (anchor order) with the top-k kernel
+        # -- ties of the 0/1 score break by the lower index -- and evaluate the loss on [B,T,4] instead
+        # of scanning and masking every anchor (two int64 cumsums + a [B,A,4] smooth-L1 otherwise).
+        from .. import ops
+        idx = ops.topk_order(pos.to(torch.float32), T)                     # [B,T] positives first
+        npos = pos.sum(dim=1, keepdim=True).clamp(max=T)
+        valid = torch.arange(T, device=match.device).unsqueeze(0) < npos   # [B,T]
+        own = torch.gather(rpn_bbox, 1, idx.unsqueeze(2).expand(-1, -1, 4))
+        sl1 = F.smooth_l1_loss(own, target_bbox, reduction="none")
+        per_image, _ = _masked_mean(sl1, valid.unsqueeze(2).expand_as(sl1), dims=(1, 2))
+        return per_image.mean() if reduce else per_image
+    csum = torch.cumsum(pos.int(), dim=1) - 1
+    rank = csum.clamp(min=0, max=T - 1).long()
     tgt = torch.gather(target_bbox, 1, rank.unsqueeze(2).expand(-1, -1, 4))
     sl1 = F.smooth_l1_loss(rpn_bbox, tgt, reduction="none")
-    pos = pos & ((torch.cumsum(pos.long(), dim=1) - 1) < target_bbox.shape[1])
+    pos = pos & (csum < T)
     per_image, _ = _masked_mean(sl1, pos.unsqueeze(2).expand_as(sl1), dims=(1, 2))
     return per_image.mean() if reduce else per_image
 

@@ -47,11 +47,57 @@ def roi_levels(boxes, image_shape):
 import os
 CHAIN_TWO_READERS = os.environ.get("SLN_CHAIN_TWO_READERS", "1") != "0"   # RPN heads (A/B switch)
 
+class CropGradPool(object):
+    """One set of P2..P5 gradient maps shared by several pyramid crops of the same maps (classifier
+    7x7 and mask 16x16, modals.py:438, 479).  Each crop's backward scatters into the shared maps; all
+    but the last to run hand autograd `None` (= zero) for the maps, the last one returns the sum -- one
+    memset and no accumulation pass per extra crop (1.4 GB each at 16 x 1024^2).  Only for graphs in
+    which EVERY registered crop is differentiated (the train step): a crop whose output does not reach
+    the loss would hold the others' gradients back."""
+
+    def __init__(self):
+        self.registered = self.pending = 0
+        self.bufs = None
+
+    def register(self):
+        self.registered += 1
+        self.pending += 1
+
+
+def _pyramid_backward(ctx, g, cstride, coff):
+    import ctypes as C
+    from .. import _lib
+    boxes, box_ind, level = ctx.saved_tensors
+    g = g.contiguous(memory_format=torch.channels_last)
+    B, Cc = ctx.shapes[0][0], ctx.shapes[0][1]
+    pool = ctx.pool
+    first = pool is None or pool.bufs is None
+    if first:
+        grads = [torch.empty(s, dtype=torch.float32, device=g.device,
+                             memory_format=torch.channels_last) for s in ctx.shapes]
+        if pool is not None:
+            pool.bufs = grads
+    else:
+        grads = pool.bufs
+    ptrs = (C.c_void_p * 4)(*[t.data_ptr() for t in grads])
+    hw = (C.c_int * 8)(*[d for s in ctx.shapes for d in (s[2], s[3])])
+    _lib.check(_lib.lib().sln_pyramid_crop_bwd_f32(
+        ops._ptr(g), cstride if cstride else Cc, coff, ops._ptr(boxes), ops._ptr(box_ind), ops._ptr(level),
+        boxes.shape[0], ctx.pool_size, ctx.pool_size, B, Cc, ptrs, hw, 0 if first else 1, ops._stream()),
+        "sln_pyramid_crop_bwd_f32")
+    if pool is not None:
+        pool.pending -= 1
+        if pool.pending > 0:
+            return (None,) * len(grads)          # a later crop's backward returns the shared maps
+        pool.bufs, pool.pending = None, pool.registered
+    return tuple(grads)
+
+
 class _PyramidCrop(torch.autograd.Function):
     """All-level crop in one launch; gradient flows to the four maps only."""
 
     @staticmethod
-    def forward(ctx, boxes, box_ind, level, pool, *maps):
+    def forward(ctx, boxes, box_ind, level, pool, grad_pool, *maps):
         import ctypes as C
         from .. import _lib
         maps = [m if m.is_contiguous(memory_format=torch.channels_last) else
@@ -67,25 +113,14 @@ class _PyramidCrop(torch.autograd.Function):
             0.0, ops._ptr(out), Cc, 0, ops._stream()), "sln_pyramid_crop_fwd_f32")
         ctx.save_for_backward(boxes, box_ind, level)
         ctx.shapes = [tuple(m.shape) for m in maps]
-        ctx.pool = pool
+        ctx.pool_size, ctx.pool = pool, grad_pool
+        if grad_pool is not None:
+            grad_pool.register()
         return out
 
     @staticmethod
     def backward(ctx, g):
-        import ctypes as C
-        from .. import _lib
-        boxes, box_ind, level = ctx.saved_tensors
-        g = g.contiguous(memory_format=torch.channels_last)
-        B, Cc = ctx.shapes[0][0], ctx.shapes[0][1]
-        grads = [torch.empty(s, dtype=torch.float32, device=g.device,
-                             memory_format=torch.channels_last) for s in ctx.shapes]
-        ptrs = (C.c_void_p * 4)(*[t.data_ptr() for t in grads])
-        hw = (C.c_int * 8)(*[d for s in ctx.shapes for d in (s[2], s[3])])
-        _lib.check(_lib.lib().sln_pyramid_crop_bwd_f32(
-            ops._ptr(g), Cc, 0, ops._ptr(boxes), ops._ptr(box_ind), ops._ptr(level),
-            boxes.shape[0], ctx.pool, ctx.pool, B, Cc, ptrs, hw, ops._stream()),
-            "sln_pyramid_crop_bwd_f32")
-        return (None, None, None, None) + tuple(grads)
+        return (None, None, None, None, None) + _pyramid_backward(ctx, g, 0, 0)
 
 
 class _PyramidCropInto(torch.autograd.Function):
@@ -94,7 +129,7 @@ class _PyramidCropInto(torch.autograd.Function):
     first channels already hold the GLM crop (pyramid_roi_align_image(..., cat_extra=C))."""
 
     @staticmethod
-    def forward(ctx, buf, coff, boxes, box_ind, level, pool, *maps):
+    def forward(ctx, buf, coff, boxes, box_ind, level, pool, grad_pool, *maps):
         import ctypes as C
         from .. import _lib
         maps = [m if m.is_contiguous(memory_format=torch.channels_last) else
@@ -107,29 +142,18 @@ class _PyramidCropInto(torch.autograd.Function):
             pool, 0.0, ops._ptr(buf), buf.shape[1], coff, ops._stream()), "sln_pyramid_crop_fwd_f32")
         ctx.save_for_backward(boxes, box_ind, level)
         ctx.shapes = [tuple(m.shape) for m in maps]
-        ctx.pool, ctx.coff = pool, coff
+        ctx.pool_size, ctx.coff, ctx.pool = pool, coff, grad_pool
+        if grad_pool is not None:
+            grad_pool.register()
         ctx.mark_dirty(buf)
         return buf
 
     @staticmethod
     def backward(ctx, g):
-        import ctypes as C
-        from .. import _lib
-        boxes, box_ind, level = ctx.saved_tensors
-        g = g.contiguous(memory_format=torch.channels_last)
-        B, Cc = ctx.shapes[0][0], ctx.shapes[0][1]
-        grads = [torch.empty(s, dtype=torch.float32, device=g.device,
-                             memory_format=torch.channels_last) for s in ctx.shapes]
-        ptrs = (C.c_void_p * 4)(*[t.data_ptr() for t in grads])
-        hw = (C.c_int * 8)(*[d for s in ctx.shapes for d in (s[2], s[3])])
-        _lib.check(_lib.lib().sln_pyramid_crop_bwd_f32(
-            ops._ptr(g), g.shape[1], ctx.coff, ops._ptr(boxes), ops._ptr(box_ind), ops._ptr(level),
-            boxes.shape[0], ctx.pool, ctx.pool, B, Cc, ptrs, hw, ops._stream()),
-            "sln_pyramid_crop_bwd_f32")
-        return (None, None, None, None, None, None) + tuple(grads)
+        return (None, None, None, None, None, None, None) + _pyramid_backward(ctx, g, g.shape[1], ctx.coff)
 
 
-def pyramid_roi_align(inputs, pool_size, image_shape, box_ind=None, into=None):
+def pyramid_roi_align(inputs, pool_size, image_shape, box_ind=None, into=None, grad_pool=None):
     """inputs = [boxes] + [P2, P3, P4, P5].
     boxes: [B,R,4] (or the reference's [1,R,4]) normalised (y1,x1,y2,x2); image b's
     rois index feature-map batch entry b.  Padded roi slots may be marked by
@@ -154,11 +178,11 @@ def pyramid_roi_align(inputs, pool_size, image_shape, box_ind=None, into=None):
                  for m in feature_maps)
     if chlast and len(feature_maps) == 4 and into is not None:   # (buffer, channel offset): fused cat
         return _PyramidCropInto.apply(into[0], int(into[1]), flat, box_ind.contiguous(), level.contiguous(),
-                                      int(pool_size), *feature_maps)
+                                      int(pool_size), grad_pool, *feature_maps)
     if into is not None:
         raise RuntimeError("pyramid_roi_align(into=...) needs four channels-last feature maps")
     if chlast and len(feature_maps) == 4:
-        return _PyramidCrop.apply(flat, box_ind.contiguous(), level.contiguous(), int(pool_size),
+        return _PyramidCrop.apply(flat, box_ind.contiguous(), level.contiguous(), int(pool_size), grad_pool,
                                   *feature_maps)
     # Reference-layout (NCHW) maps: per-level crops, like the reference's loop.
     pooled = torch.zeros((flat.shape[0], feature_maps[0].shape[1], pool_size, pool_size),
@@ -414,8 +438,8 @@ class Classifier(nn.Module):
         self.softmax = nn.Softmax(dim=1)
         self.linear_bbox = nn.Linear(1024, num_classes * 4)
 
-    def forward(self, x, rois, box_ind=None):
-        x = pyramid_roi_align([rois] + list(x), self.pool_size, self.image_shape, box_ind)
+    def forward(self, x, rois, box_ind=None, grad_pool=None):
+        x = pyramid_roi_align([rois] + list(x), self.pool_size, self.image_shape, box_ind, grad_pool=grad_pool)
         x = nn_ops.conv_bn_act(x, self.conv1, self.bn1, relu=True)
         x = nn_ops.conv_bn_act(x, self.conv2, self.bn2, relu=True)
         x = x.reshape(-1, 1024)
@@ -447,15 +471,16 @@ class Mask(nn.Module):
         self.sigmoid = nn.Sigmoid()
         self.relu = nn.ReLU(inplace=True)
 
-    def forward(self, x, rois, cls_feature, box_ind=None):
+    def forward(self, x, rois, cls_feature, box_ind=None, grad_pool=None):
         wide = getattr(cls_feature, "_sln_cat_buf", None)
         if wide is not None and wide.shape[1] == cls_feature.shape[1] + self.depth:
             # GLM channels first (modals.py:481): they are already in `wide`; crop the roi features in
             # behind them (one launch, no concatenation copy)
             x = pyramid_roi_align([rois] + list(x), self.pool_size, self.image_shape, box_ind,
-                                  into=(wide, cls_feature.shape[1]))
+                                  into=(wide, cls_feature.shape[1]), grad_pool=grad_pool)
         else:
-            x = pyramid_roi_align([rois] + list(x), self.pool_size, self.image_shape, box_ind)
+            x = pyramid_roi_align([rois] + list(x), self.pool_size, self.image_shape, box_ind,
+                                  grad_pool=grad_pool)
             x = torch.cat((cls_feature, x), dim=1)  # GLM channels first (modals.py:481)
             x = x.contiguous(memory_format=torch.channels_last)
         conv = nn_ops.conv_bn_act

@@ -240,8 +240,16 @@ class MaskRCNN(nn.Module):
                                               box_ind=box_ind, cat_extra=256)
         if getattr(GLM_feature, "_sln_cat_buf", None) is None:
             GLM_feature = GLM_feature.detach()
-        mrcnn_class_logits, mrcnn_class, mrcnn_bbox = self.classifier(mrcnn_feature_maps, rois, box_ind)
-        mrcnn_mask, _feat = self.mask(mrcnn_feature_maps, rois, GLM_feature, box_ind)
+        # both heads' crops are differentiated by the step loss: they share one set of P2..P5 gradient maps
+        pool = None
+        if rois.is_cuda and torch.is_grad_enabled() and all(
+                m.requires_grad and m.is_contiguous(memory_format=torch.channels_last) and not m.is_contiguous()
+                for m in mrcnn_feature_maps):
+            from .modal.modals import CropGradPool
+            pool = CropGradPool()
+        mrcnn_class_logits, mrcnn_class, mrcnn_bbox = self.classifier(mrcnn_feature_maps, rois, box_ind,
+                                                                      grad_pool=pool)
+        mrcnn_mask, _feat = self.mask(mrcnn_feature_maps, rois, GLM_feature, box_ind, grad_pool=pool)
         nc = mrcnn_class_logits.shape[1]
         return {
             "rpn_class_logits": rpn_class_logits, "rpn_bbox": rpn_bbox,

@@ -176,6 +176,47 @@ def test_pyramid_golden_through_hip_crop():
         assert np.allclose(fm.grad.cpu().numpy(), g["grad%d" % i], rtol=1e-5, atol=1e-5)
 
 
+def test_pyramid_crops_sharing_gradient_maps_equal_separate_backward():
+    """CropGradPool: the classifier (7x7) and mask (16x16, cropped into a wider buffer) crops of the same
+    maps accumulate into one set of gradient maps; the sum autograd sees equals the sum of the two
+    separately computed gradients, for either backward order and for a second backward (retain_graph)."""
+    from sln_amodal_amd.modal.modals import CropGradPool, pyramid_roi_align
+    gen = torch.Generator().manual_seed(3)
+    B, C, R = 2, 64, 40
+    sizes = [(64, 64), (32, 32), (16, 16), (8, 8)]
+    ctr = torch.rand(B, R, 2, generator=gen) * 0.6 + 0.2
+    half = torch.rand(B, R, 2, generator=gen) * 0.25 + 0.01
+    rois = torch.cat([ctr - half, ctr + half], dim=2).clamp(0, 1).cuda()
+    base = [torch.randn(B, C, h, w, generator=gen).cuda().contiguous(memory_format=torch.channels_last)
+            for h, w in sizes]
+    up7 = torch.randn(B * R, C, 7, 7, generator=gen).cuda()
+    up16 = torch.randn(B * R, C + 8, 16, 16, generator=gen).cuda()
+
+    def run(pool, order):
+        maps = [m.clone().requires_grad_(True) for m in base]
+        a = pyramid_roi_align([rois] + maps, 7, (256, 256), grad_pool=pool)
+        wide = torch.zeros((B * R, C + 8, 16, 16), device="cuda").contiguous(memory_format=torch.channels_last)
+        b = pyramid_roi_align([rois] + maps, 16, (256, 256), into=(wide, 8), grad_pool=pool)
+        terms = [(a * up7).sum(), (b * up16).sum()]
+        loss = terms[order[0]] + terms[order[1]]
+        loss.backward(retain_graph=True)
+        first = [m.grad.clone() for m in maps]
+        for m in maps:
+            m.grad = None
+        loss.backward()
+        return first, [m.grad for m in maps]
+
+    want, _ = run(None, (0, 1))
+    for order in ((0, 1), (1, 0)):
+        pool = CropGradPool()
+        got, again = run(pool, order)
+        assert pool.registered == 2 and pool.pending == 2 and pool.bufs is None
+        for w, g, g2 in zip(want, got, again):
+            scale = w.abs().max().item()
+            assert (w - g).abs().max().item() <= 1e-5 * scale
+            assert (w - g2).abs().max().item() <= 1e-5 * scale
+
+
 @pytest.mark.parametrize("pool", [16, 8, 14, 7])
 def test_pyramid_crop_backward_vs_oracle_all_regimes(orc, pool):
     """sln_pyramid_crop_bwd_f32 against the oracle's serial crop_and_resize backward, one
@@ -200,7 +241,7 @@ def test_pyramid_crop_backward_vs_oracle_all_regimes(orc, pool):
     ind[5] = -1                                                         # padded slot
     maps = [torch.randn(B, C, h, w, generator=gen).cuda().contiguous(memory_format=torch.channels_last)
             .requires_grad_(True) for h, w in sizes]
-    out = _PyramidCrop.apply(boxes.cuda(), ind.cuda(), level.cuda(), pool, *maps)
+    out = _PyramidCrop.apply(boxes.cuda(), ind.cuda(), level.cuda(), pool, None, *maps)
     up = torch.randn(K, C, pool, pool, generator=gen)
     out.backward(up.cuda().contiguous(memory_format=torch.channels_last))
     for i, (h, w) in enumerate(sizes):

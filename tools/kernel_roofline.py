@@ -35,13 +35,13 @@ def measure(dev, B=16):
     from sln_amodal_amd.modal.modals import roi_levels
     lvl = roi_levels(boxes, (1024, 1024))
     elems = K * C * pool * pool
-    t = _time(lambda: _PyramidCrop.apply(boxes, ind, lvl, pool, *maps))
+    t = _time(lambda: _PyramidCrop.apply(boxes, ind, lvl, pool, None, *maps))
     out["roialign_fwd"] = {"kernel": "pyr_fwd_kernel<4>", "bound": "hbm", "bytes_per_elem": 20,
                            "elems": elems, "ms": round(t * 1e3, 4),
                            "achieved": round(elems * 20 / t / 1e9, 1), "peak": PEAK_HBM_GBS,
                            "unit": "GB/s", "frac": round(elems * 20 / t / 1e9 / PEAK_HBM_GBS, 4)}
     ms = [m.clone().requires_grad_(True) for m in maps]
-    o = _PyramidCrop.apply(boxes, ind, lvl, pool, *ms)
+    o = _PyramidCrop.apply(boxes, ind, lvl, pool, None, *ms)
     up = torch.randn_like(o)
     t = _time(lambda: torch.autograd.grad(o, ms, up, retain_graph=True))
     out["roialign_bwd"] = {"kernel": "pyr_bwd_patch_kernel (+memset of 4 grad maps)", "bound": "hbm",

@@ -17,14 +17,14 @@ def main(pool=16):
     ind = torch.arange(K, device="cuda").int() % B
     up = torch.randn(K, C, pool, pool, generator=g).cuda().contiguous(memory_format=torch.channels_last)
     for _ in range(3):
-        out = _PyramidCrop.apply(boxes, ind, level, pool, *maps)
+        out = _PyramidCrop.apply(boxes, ind, level, pool, None, *maps)
         out.backward(up)
     n = 20
     e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     tf = tb = 0.0
     for _ in range(n):
         e[0].record()
-        out = _PyramidCrop.apply(boxes, ind, level, pool, *maps)
+        out = _PyramidCrop.apply(boxes, ind, level, pool, None, *maps)
         e[1].record()
         out.backward(up)
         e[2].record()
