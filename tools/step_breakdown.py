@@ -1,10 +1,10 @@
 """Per-step kernel breakdown from a rocprofv3 --kernel-trace CSV: aggregates the
-kernels between the last two optimizer steps (multi_tensor_apply clusters)."""
+kernels between the last two optimizer steps (sgd_clip_kernel launches; multi_tensor_apply clusters in revisions before the fused optimiser)."""
 import csv, glob, collections, sys
 f = sys.argv[1]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-opt = [i for i, r in enumerate(rows) if 'multi_tensor_apply' in r['Kernel_Name']]
+opt = [i for i, r in enumerate(rows) if 'multi_tensor_apply' in r['Kernel_Name'] or 'sgd_clip_kernel' in r['Kernel_Name']]
 cl = []
 for i in opt:
     t = int(rows[i]['Start_Timestamp'])
