@@ -19,6 +19,7 @@ import torch
 import torch.nn.functional as F
 
 BACKEND = "auto"  # "auto" | "hip" | "torch"
+CALIBRATING = None   # [count] while synthetic._calibrate runs: conv_bn_act refreshes each frozen BN's statistics
 
 
 def _hip_conv():
@@ -74,6 +75,18 @@ def conv_bn_act(x, conv, bn=None, relu=False, residual=None, same=False, link=No
           (one as input, one as residual); HIP backend only, see conv_hip._ConvFn.
     chain_out / chain_in: dict shared by a conv (chain_out) and the ONLY conv that reads its
           output (chain_in): lets the reader's backward prepare this layer's gradient."""
+    if CALIBRATING is not None and bn is not None:
+        # statistics pass (synthetic.calibrate_*): the raw convolution on the same backend, its output's
+        # statistics into the frozen BN, then the un-fused normalisation / shortcut / ReLU
+        y = conv_bn_act(x, conv, None, False, None, same)
+        with torch.no_grad():
+            bn.running_mean.copy_(y.mean(dim=(0, 2, 3)))
+            bn.running_var.copy_(y.var(dim=(0, 2, 3), unbiased=False).clamp(min=1e-6))
+        CALIBRATING[0] += 1
+        y = F.batch_norm(y, bn.running_mean, bn.running_var, bn.weight, bn.bias, False, 0.0, bn.eps)
+        if residual is not None:
+            y = y + residual
+        return F.relu(y) if relu else y
     stride, dilation = conv.stride, conv.dilation
     kh, kw = conv.kernel_size
     if same:   # (never with a MultiScale: the GLM uses symmetric padding)

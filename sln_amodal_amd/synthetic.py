@@ -47,31 +47,31 @@ def make_batch(config, B, H, W, n_obj=8, seed=1234, device="cuda", anchors_f64=N
 
 
 def _calibrate(forward):
-    """Run `forward()` with the un-fused torch conv path while every eval-mode
-    batch_norm call first overwrites its running statistics with the statistics of
-    its input (so layer k is calibrated on activations normalised by layers < k)."""
+    """Run `forward()` while every conv + frozen-BN pair first overwrites the BN's running statistics
+    with the statistics of the raw convolution output (so layer k is calibrated on activations
+    normalised by layers < k).  Convolutions stay on the active backend (nn_ops.CALIBRATING); BN layers
+    reached through F.batch_norm directly (the aten backend) are caught by the patch below."""
     import torch.nn.functional as F
     from . import nn_ops
-    saved = nn_ops.BACKEND
     orig = F.batch_norm
     count = [0]
 
     def patched(x, rm, rv, w=None, b=None, training=False, momentum=0.1, eps=1e-5):
-        if not training:
+        if not training and nn_ops.CALIBRATING is None:
             with torch.no_grad():
                 rm.copy_(x.mean(dim=(0, 2, 3)))
                 rv.copy_(x.var(dim=(0, 2, 3), unbiased=False).clamp(min=1e-6))
             count[0] += 1
         return orig(x, rm, rv, w, b, training, momentum, eps)
 
-    nn_ops.BACKEND = "torch"
+    nn_ops.CALIBRATING = count
     F.batch_norm = patched
     try:
         with torch.no_grad():
             forward()
     finally:
         F.batch_norm = orig
-        nn_ops.BACKEND = saved
+        nn_ops.CALIBRATING = None
     return count[0]
 
 
