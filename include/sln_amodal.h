@@ -178,6 +178,18 @@ int sln_topk_order_f32(const float *scores, int B, int A, long stride_b, long st
                        int64_t *order, sln_stream_t stream);
 
 /* ---------------------------------------------------------------------------
+ * FPN top-down merge (modal/modals.py:243-246): out = lateral + nearest-2x(top) in one pass, and the
+ * coarse input's gradient.  NHWC fp32, C % 4 == 0.
+ * Replaces: F.upsample(scale_factor=2) + add (the upsampled map written and read back) and the
+ *           upsample backward.
+ * sln_upsample2x_add_f32  lateral, out [N,2h,2w,C]; top [N,h,w,C]
+ * sln_sumpool2x2_f32      g [N,2h,2w,C] -> gtop [N,h,w,C] = (g00 + g01) + (g10 + g11)
+ * ------------------------------------------------------------------------- */
+int sln_upsample2x_add_f32(const float *lateral, const float *top, int N, int h, int w, int C, float *out,
+                           sln_stream_t stream);
+int sln_sumpool2x2_f32(const float *g, int N, int h, int w, int C, float *gtop, sln_stream_t stream);
+
+/* ---------------------------------------------------------------------------
  * Optimiser step: global-norm clip + momentum SGD over the whole parameter set.
  * Replaces: torch.nn.utils.clip_grad_norm(params, 5.0) followed by torch.optim.SGD.step()
  *           (model.py:441-444, optimizer built at model.py:352-358): one norm kernel per tensor,

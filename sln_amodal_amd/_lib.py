@@ -27,6 +27,8 @@ SIGNATURES = {
     "sln_mask_targets_u64": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _i, _i, _i, _p, _p]),
     "sln_proposal_decode_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, C.POINTER(_f), _f, _f, _p, _p]),
     "sln_topk_order_f32": (_i, [_p, _i, _i, C.c_long, C.c_long, _i, _p, _p]),
+    "sln_upsample2x_add_f32": (_i, [_p, _p, _i, _i, _i, _i, _p, _p]),
+    "sln_sumpool2x2_f32": (_i, [_p, _i, _i, _i, _i, _p, _p]),
     "sln_grad_sqnorm_f32": (_i, [_p, _p, _p, _p, _i, _i, _p, _p, _p]),
     "sln_sgd_clip_step_f32": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _f, _f, _f, _p]),
     "sln_unmold_masks_u8": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p]),

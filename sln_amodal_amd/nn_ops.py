@@ -136,8 +136,44 @@ def max_pool_same(x, kernel, stride):
     return F.max_pool2d(F.pad(x, (pl, pr, pt, pb)), kernel, stride)
 
 
+class _FpnMerge(torch.autograd.Function):
+    """lateral + nearest-2x(top) as one HIP pass; backward: the lateral's gradient is the incoming one,
+    the coarse map's is its 2x2 sum-pool."""
+
+    @staticmethod
+    def forward(ctx, lateral, top):
+        from . import _lib, ops
+        lat = lateral if lateral.is_contiguous(memory_format=torch.channels_last) else \
+            lateral.contiguous(memory_format=torch.channels_last)
+        tp = top if top.is_contiguous(memory_format=torch.channels_last) else \
+            top.contiguous(memory_format=torch.channels_last)
+        N, C, h, w = tp.shape
+        out = torch.empty(lat.shape, dtype=torch.float32, device=lat.device, memory_format=torch.channels_last)
+        _lib.check(_lib.lib().sln_upsample2x_add_f32(ops._ptr(lat), ops._ptr(tp), N, h, w, C, ops._ptr(out),
+                                                     ops._stream()), "sln_upsample2x_add_f32")
+        ctx.top_shape = tuple(tp.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _lib, ops
+        gtop = None
+        if ctx.needs_input_grad[1]:
+            gc = g if g.is_contiguous(memory_format=torch.channels_last) else \
+                g.contiguous(memory_format=torch.channels_last)
+            N, C, h, w = ctx.top_shape
+            gtop = torch.empty(ctx.top_shape, dtype=torch.float32, device=g.device,
+                               memory_format=torch.channels_last)
+            _lib.check(_lib.lib().sln_sumpool2x2_f32(ops._ptr(gc), N, h, w, C, ops._ptr(gtop), ops._stream()),
+                       "sln_sumpool2x2_f32")
+        return (g if ctx.needs_input_grad[0] else None), gtop
+
+
 def upsample2x_add(lateral, top):
     """FPN merge: lateral + nearest-2x(top)  (modal/modals.py:243-246)."""
+    if BACKEND != "torch" and lateral.is_cuda and lateral.dtype == torch.float32 and lateral.shape[1] % 4 == 0 \
+            and lateral.shape[2] == 2 * top.shape[2] and lateral.shape[3] == 2 * top.shape[3]:
+        return _FpnMerge.apply(lateral, top)
     return lateral + F.interpolate(top, scale_factor=2, mode="nearest")
 
 

@@ -408,3 +408,27 @@ def test_topk_order_full_size_batch():
     got = ops.topk_order(s, 6000)
     want = torch.sort(s, dim=1, descending=True, stable=True)[1][:, :6000]
     assert torch.equal(got, want)
+
+
+# ------------------------------------------------------------------ FPN top-down merge
+@pytest.mark.parametrize("shape", [(2, 256, 16, 16), (1, 64, 5, 7), (3, 8, 1, 1)])
+def test_fpn_merge_equals_upsample_then_add(shape):
+    """nn_ops.upsample2x_add (modal/modals.py:243-246): forward bit-identical to F.interpolate(nearest) + add,
+    gradients: the lateral's is the incoming one, the coarse map's the 2x2 sums (1 ulp: summation order)."""
+    import torch.nn.functional as F
+    from sln_amodal_amd import nn_ops
+    N, C, h, w = shape
+    g = torch.Generator(device="cuda").manual_seed(h * 10 + w)
+    lat = torch.randn(N, C, 2 * h, 2 * w, device="cuda", generator=g).contiguous(memory_format=torch.channels_last)
+    top = torch.randn(N, C, h, w, device="cuda", generator=g).contiguous(memory_format=torch.channels_last)
+    up = torch.randn(N, C, 2 * h, 2 * w, device="cuda", generator=g).contiguous(memory_format=torch.channels_last)
+    a, b = lat.clone().requires_grad_(True), top.clone().requires_grad_(True)
+    out = nn_ops.upsample2x_add(a, b)
+    assert type(out.grad_fn).__name__ == "_FpnMergeBackward"
+    ra, rb = lat.clone().requires_grad_(True), top.clone().requires_grad_(True)
+    ref = ra + F.interpolate(rb, scale_factor=2, mode="nearest")
+    assert torch.equal(out, ref)
+    out.backward(up)
+    ref.backward(up)
+    assert torch.equal(a.grad, ra.grad)
+    assert torch.allclose(b.grad, rb.grad, rtol=1e-6, atol=1e-6)
