@@ -489,6 +489,6 @@ class Mask(nn.Module):
         x = conv(x, self.conv2, self.bn2, relu=True, same=True, chain_in=c12, chain_out=c23)
         x = conv(x, self.conv3, self.bn3, relu=True, same=True, chain_in=c23, chain_out=c34)
         feat = conv(x, self.conv4, self.bn4, relu=True, same=True, chain_in=c34)   # feat is also returned
-        x = nn_ops.deconv2x2_relu(feat, self.deconv)
-        x = conv(x, self.conv5)  # logits; the sigmoid lives in the losses (modals.py:497)
+        # deconv + ReLU + 1x1 logits; the sigmoid lives in the losses (modals.py:494-497)
+        x = nn_ops.deconv2x2_relu_conv1x1(feat, self.deconv, self.conv5)
         return x, feat

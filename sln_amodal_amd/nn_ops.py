@@ -197,6 +197,32 @@ def deconv2x2_relu(x, deconv):
     return y.reshape(N, 2 * H, 2 * W, Co).permute(0, 3, 1, 2)      # logical NCHW, NHWC in memory
 
 
+def deconv2x2_relu_conv1x1(x, deconv, conv):
+    """The mask head's tail (modal/modals.py:494-497): ConvTranspose2d(2, stride 2) + ReLU + 1x1 conv to
+    the class logits.  A pointwise convolution commutes with the depth-to-space shuffle, so it runs on the
+    un-shuffled deconv output -- [N, H, W, (a, b), Cout] is [N*H*W*4 pixels, Cout] as it lies in memory,
+    parts included -- and only the few logit channels are shuffled: the 1.7-GB activation is neither
+    permuted (forward and backward) nor split a second time."""
+    hip = _hip_conv() if BACKEND in ("auto", "hip") else None
+    if hip is None or not x.is_cuda or tuple(conv.kernel_size) != (1, 1) or tuple(conv.stride) != (1, 1) or \
+            deconv.weight.shape[1] % 8:
+        return conv_bn_act(deconv2x2_relu(x, deconv), conv)
+    Ci, Co = deconv.weight.shape[0], deconv.weight.shape[1]
+    w2 = deconv.weight.permute(2, 3, 1, 0).reshape(4 * Co, Ci, 1, 1)
+    b2 = deconv.bias.repeat(4) if deconv.bias is not None else None
+    y = hip._ConvFn.apply(x, w2, b2, None, None, None, True, (1, 1), (1, 1), (0, 0, 0, 0), None, None, None,
+                          deconv.weight)
+    N, _, H, W = y.shape
+    y4 = y.permute(0, 2, 3, 1).reshape(N, H, W * 4, Co).permute(0, 3, 1, 2)     # pixel (i, 4j + 2a + b)
+    hit = getattr(y, "_sln_parts", None)
+    if hit is not None and hit[0][0] == y._version:     # the epilogue's parts of y are y4's, re-viewed
+        y4._sln_parts = ((y4._version, hit[0][1]), hit[1].view(hit[1].shape[0], -1, Co), hit[2])
+    z = conv_bn_act(y4, conv)
+    K = z.shape[1]
+    z = z.permute(0, 2, 3, 1).reshape(N, H, W, 2, 2, K).permute(0, 5, 1, 3, 2, 4)
+    return z.reshape(N, K, 2 * H, 2 * W)
+
+
 def linear(x, lin):
     """nn.Linear on [R, C] rows through the same GEMM kernel (a 1x1 conv on R 1x1 'images')."""
     hip = _hip_conv() if BACKEND in ("auto", "hip") else None
