@@ -26,13 +26,14 @@ import torch.distributed as dist  # noqa: E402
 # algorithmic GFLOP per 1024^2 image, ResNet-101, R=100 rois
 GFLOP_FWD = {"backbone_fpn": 435.1, "rpn": 207.6, "heads": 158.7, "glm": 872.9}
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md, dense fp32-input MFMA (context only)
-PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md, dense bf16 MFMA: the pipes the conv kernels run on
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md, dense bf16 / fp16 MFMA: the pipes the conv kernels run on
 
 
 def split_peak(parts):
-    """Roofline for ALGORITHMIC (fp32-equivalent, 2*MACs) FLOPs of the split-bf16 scheme: every
-    fp32 multiply-add is 6 (3 parts) or 3 (2 parts) bf16 MFMA products, so the dense bf16 peak
-    bounds the algorithmic rate at 2500/6 = 416.7 (2500/3 = 833.3) TFLOP/s."""
+    """Roofline for ALGORITHMIC (fp32-equivalent, 2*MACs) FLOPs of the split-operand scheme: every
+    fp32 multiply-add is 3 fp16 MFMA products (2 scaled fp16 parts per operand, the default) or 6 bf16
+    products (3 bf16 parts); both run at the dense 16-bit MFMA peak, which therefore bounds the
+    algorithmic rate at 2500/3 = 833.3 (2500/6 = 416.7) TFLOP/s."""
     return PEAK_BF16_MFMA_TFLOPS / (6 if parts == 3 else 3)
 PEAK_HBM_GBS = 8000.0
 # HBM bytes per launch cannot be collected live (PMC needs rocprofv3 around the process): the bench line
@@ -99,7 +100,7 @@ def dominant_kernel_roofline(prof, elapsed, parts):
     peak = split_peak(parts)
     return {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": round(peak, 1),
             "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-            "peak_note": "algorithmic fp32-equivalent FLOPs against dense bf16 MFMA peak / %d part products; "
+            "peak_note": "algorithmic fp32-equivalent FLOPs against dense 16-bit MFMA peak / %d part products; "
                          "the fp32-input MFMA peak is %.1f (ratio in vs_fp32_mfma_peak, not a roofline "
                          "fraction: this kernel does not run on that path)" % (6 if parts == 3 else 3,
                                                                               PEAK_F32_MFMA_TFLOPS),
@@ -157,7 +158,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--conv-backend", default="auto", choices=["auto", "hip", "torch"])
     ap.add_argument("--parts", type=int, default=None, choices=[2, 3],
-                    help="bf16 parts per fp32 operand in the conv stack (default 3 = fp32-class)")
+                    help="operand format of the conv stack: 2 = two scaled fp16 parts (default), 3 = three bf16 parts; "
+                         "both fp32-class")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(launch_ranks(args.gpus))
@@ -251,6 +253,8 @@ def main():
                        "arch": args.arch, "images_per_gpu": args.batch, "image_dim": args.dim,
                        "stage": args.stage, "parallelism": "dp%d" % world,
                        "conv_backend": nn_ops.BACKEND, "conv_split_parts": conv_hip.PARTS,
+                       "conv_operand_format": "2 x scaled fp16 (3 MFMA products per fp32 multiply-add)"
+                       if conv_hip.PARTS == 2 else "3 x bf16 (6 MFMA products per fp32 multiply-add)",
                        "final_loss": round(final_loss, 5),
                        "loss_trace": [round(float(l), 4) for l in losses[:: max(1, len(losses) // 8)]],
                        "max_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)},
@@ -263,13 +267,14 @@ def main():
         out["roofline"] = dominant_kernel_roofline(prof, elapsed, conv_hip.PARTS)
         if os.environ.get("SLN_PROFILE_SHAPES"):
             agg = {}
-            for e0, e1, fl, name, shape, _rd, _wr in prof:
-                d = agg.setdefault(shape, [0.0, 0.0, 0])
-                d[0] += e0.elapsed_time(e1); d[1] += fl; d[2] += 1
+            for e0, e1, fl, name, shape, rd, wr in prof:
+                d = agg.setdefault((name, shape), [0.0, 0.0, 0, 0.0])
+                d[0] += e0.elapsed_time(e1); d[1] += fl; d[2] += 1; d[3] += rd + wr
             tot = sum(v[0] for v in agg.values())
-            for shape, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:45]:
-                print("%6.2f%% %8.2f ms/step n=%4d %6.1f TF  %s" % (100 * v[0] / tot, v[0] / args.steps,
-                      v[2] // args.steps, v[1] / v[0] / 1e9, shape), file=sys.stderr)
+            for (name, shape), v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:70]:
+                print("%6.2f%% %8.2f ms/step n=%4d %6.1f TF %5.2f TB/s  %-26s %s" % (
+                    100 * v[0] / tot, v[0] / args.steps, v[2] // args.steps, v[1] / v[0] / 1e9,
+                    v[3] / v[0] / 1e9, name, shape), file=sys.stderr)
         try:
             from tools import kernel_roofline
             out["roofline_kernels"] = kernel_roofline.measure(dev)

@@ -787,11 +787,12 @@ def _dummy_grad(device):
     return d
 
 
-def conv_bn_act(x, conv, bn, relu, residual, pads, weight=None, link=None, chain_in=None, chain_out=None):
+def conv_bn_act(x, conv, bn, relu, residual, pads, weight=None, link=None, chain_in=None, chain_out=None,
+                stride=None):
     from .nn_ops import bn_affine
     scale = shift = None
     if bn is not None:
         scale, shift = bn_affine(bn)
     return _ConvFn.apply(x, conv.weight if weight is None else weight, conv.bias, scale, shift,
-                         residual, bool(relu), tuple(conv.stride), tuple(conv.dilation), tuple(pads),
+                         residual, bool(relu), tuple(stride or conv.stride), tuple(conv.dilation), tuple(pads),
                          link if LINK_SHORTCUT_GRAD else None, chain_in, chain_out, conv.weight)

@@ -99,6 +99,16 @@ def conv_bn_act(x, conv, bn=None, relu=False, residual=None, same=False, link=No
     if hip is not None and isinstance(x, hip.MultiScale):   # all GLM scales in one launch
         return hip.conv_bn_act_ms(x, conv, bn, relu, residual, (pt, pb, pl, pr))
     if hip is not None and x.is_cuda and hip.supports(conv, x):
+        if kh * kw > 1 and (kh, kw) == tuple(x.shape[2:]) and (pt, pb, pl, pr) == (0, 0, 0, 0) and \
+                residual is None and x.shape[1] % 8 == 0:
+            # Whole-window convolution (the classifier's 7x7 "FC" conv on 7x7 crops, modals.py:441): one
+            # output pixel, so it IS a linear layer over K = KH*KW*C -- the NHWC crop is that row already.
+            # As a KxK convolution its data gradient would visit KH*KW output positions with KH*KW taps
+            # each, all but one of them outside the 1x1 gradient map: 49x the work.
+            N, C = x.shape[0], x.shape[1]
+            xr = x.permute(0, 2, 3, 1).reshape(N, 1, 1, kh * kw * C).permute(0, 3, 1, 2)
+            w2 = conv.weight.permute(0, 2, 3, 1).reshape(conv.out_channels, kh * kw * C, 1, 1)
+            return hip.conv_bn_act(xr, conv, bn, relu, None, (0, 0, 0, 0), weight=w2, stride=(1, 1))
         return hip.conv_bn_act(x, conv, bn, relu, residual, (pt, pb, pl, pr), link=link,
                                chain_in=chain_in, chain_out=chain_out)
     if hip is not None and not isinstance(x, hip.MultiScale) and hip.is_stem(conv, x) and residual is None:

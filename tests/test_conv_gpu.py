@@ -723,3 +723,40 @@ def test_stem_data_gradient_matches_fp64(parts, monkeypatch):
         assert gx.shape == x.shape
         assert (gx.double() - rx).abs().max().item() / rx.abs().max().item() < 2e-5
         assert (gw.double() - rw).abs().max().item() / rw.abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("parts", [3, 2])
+def test_whole_window_conv_runs_as_linear_layer_and_matches_fp64(parts, monkeypatch):
+    """The classifier's 7x7 conv on 7x7 crops (modals.py:441) through nn_ops.conv_bn_act: routed to a 1x1
+    convolution over K = 7*7*C (one GEMM forward, one per gradient); values and all three gradients
+    against the fp64 convolution."""
+    from sln_amodal_amd import conv_hip, nn_ops
+    monkeypatch.setattr(conv_hip, "PARTS", parts)
+    torch.manual_seed(1)
+    conv = nn.Conv2d(64, 128, 7).cuda()
+    bn = nn.BatchNorm2d(128, eps=1e-3).cuda().eval()
+    with torch.no_grad():
+        bn.running_mean.normal_(); bn.running_var.uniform_(0.5, 2); bn.weight.normal_(1, 0.1); bn.bias.normal_()
+    for p in bn.parameters():
+        p.requires_grad = False
+    g = torch.Generator(device="cuda").manual_seed(2)
+    x = torch.randn(37, 64, 7, 7, device="cuda", generator=g).contiguous(memory_format=torch.channels_last)
+    x.requires_grad_(True)
+    seen = []
+    real = conv_hip._ConvFn.apply
+    monkeypatch.setattr(conv_hip._ConvFn, "apply", staticmethod(lambda *a: (seen.append(tuple(a[1].shape)), real(*a))[1]))
+    for _ in range(2):
+        y = nn_ops.conv_bn_act(x, conv, bn, relu=True)
+    assert seen[-1] == (128, 7 * 7 * 64, 1, 1) and y.shape == (37, 128, 1, 1)
+    xd = x.detach().double().requires_grad_(True)
+    wd, bd = conv.weight.detach().double().requires_grad_(True), conv.bias.detach().double().requires_grad_(True)
+    pre = F.batch_norm(F.conv2d(xd, wd, bd), bn.running_mean.double(), bn.running_var.double(), bn.weight.double(),
+                       bn.bias.double(), False, 0.0, bn.eps)
+    ref = F.relu(pre.detach())
+    assert (y.double() - ref).abs().max().item() / ref.abs().max().item() < 5e-6
+    up = torch.randn(y.shape, device="cuda", generator=g)
+    gx, gw, gb = torch.autograd.grad(y, [x, conv.weight, conv.bias], up)
+    rx, rw, rb = torch.autograd.grad(pre * (y.detach() > 0), [xd, wd, bd], up.double())
+    for got, want in ((gx, rx), (gw, rw), (gb, rb)):
+        assert got.shape == want.shape
+        assert (got.double() - want).abs().max().item() / want.abs().max().item() < 2e-5
