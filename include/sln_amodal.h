@@ -172,10 +172,14 @@ int sln_pyramid_crop_bwd_f32(const float *grads, int g_cstride, int g_coffset, c
  *           (strides in elements, so the foreground column of [B,A,2] is read in place).
  * order     [B,k] int64: indices of the k largest scores, score descending, ties by the lower
  *           index (== a stable descending sort; NaN sorts first, like torch).  k <= min(A, 8192).
- * One 1024-thread block per image: radix select, ordered tie collection, LDS bitonic sort.
+ * Every 8192-element segment of every image is a block (three 11/11/10-bit radix-select passes through
+ * per-image global histograms, a count pass, an ordered scatter of the k candidates), then one block
+ * per image sorts its candidates in LDS.  workspace: sln_topk_workspace_bytes(B, A, k) bytes of device
+ * scratch (histograms, per-segment counts, candidates).
  * ------------------------------------------------------------------------- */
+size_t sln_topk_workspace_bytes(int B, int A, int k);
 int sln_topk_order_f32(const float *scores, int B, int A, long stride_b, long stride_a, int k,
-                       int64_t *order, sln_stream_t stream);
+                       int64_t *order, void *workspace, size_t workspace_bytes, sln_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * FPN top-down merge (modal/modals.py:243-246): out = lateral + nearest-2x(top) in one pass, and the

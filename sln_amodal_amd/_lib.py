@@ -26,7 +26,8 @@ SIGNATURES = {
     "sln_label_decode_u64": (_i, [_p, _i, _i, _i, _i, _i, _p, _p]),
     "sln_mask_targets_u64": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _i, _i, _i, _p, _p]),
     "sln_proposal_decode_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, C.POINTER(_f), _f, _f, _p, _p]),
-    "sln_topk_order_f32": (_i, [_p, _i, _i, C.c_long, C.c_long, _i, _p, _p]),
+    "sln_topk_workspace_bytes": (C.c_size_t, [_i, _i, _i]),
+    "sln_topk_order_f32": (_i, [_p, _i, _i, C.c_long, C.c_long, _i, _p, _p, C.c_size_t, _p]),
     "sln_upsample2x_add_f32": (_i, [_p, _p, _i, _i, _i, _i, _p, _p]),
     "sln_sumpool2x2_f32": (_i, [_p, _i, _i, _i, _i, _p, _p]),
     "sln_grad_sqnorm_f32": (_i, [_p, _p, _p, _p, _i, _i, _p, _p, _p]),

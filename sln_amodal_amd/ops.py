@@ -171,8 +171,10 @@ def topk_order(scores, k):
         raise ValueError("scores must be [B,A]")
     B, A = scores.shape
     order = torch.empty((B, k), dtype=torch.int64, device=scores.device)
+    nbytes = _lib.lib().sln_topk_workspace_bytes(B, A, int(k))
+    ws = _workspace(nbytes, scores.device)
     _lib.check(_lib.lib().sln_topk_order_f32(_ptr(scores), B, A, scores.stride(0), scores.stride(1), int(k),
-                                             _ptr(order), _stream()), "sln_topk_order_f32")
+                                             _ptr(order), _ptr(ws), nbytes, _stream()), "sln_topk_order_f32")
     return order
 
 

@@ -400,6 +400,33 @@ def test_topk_order_equals_a_stable_descending_sort(case):
         assert torch.equal(got, want)
 
 
+@pytest.mark.parametrize("npos", [0, 3, 200, 256, 1000])
+def test_topk_order_selects_positive_anchors_in_anchor_order(npos):
+    """The RPN box loss's use (modal/loss.py): a 0/1 mask over 261 888 anchors, k = 256 -- the positives in
+    anchor order first, then the lowest-index zeros; ties span every segment of the image."""
+    from sln_amodal_amd import ops
+    g = torch.Generator().manual_seed(npos)
+    B, A, k = 4, 261888, 256
+    s = torch.zeros(B, A)
+    for b in range(B):
+        s[b, torch.randperm(A, generator=g)[:npos]] = 1.0
+    got = ops.topk_order(s.cuda(), k).cpu()
+    want = torch.sort(s, dim=1, descending=True, stable=True)[1][:, :k]
+    assert torch.equal(got, want)
+
+
+def test_topk_order_is_reproducible_and_validates_its_workspace():
+    from sln_amodal_amd import _lib, ops
+    g = torch.Generator(device="cuda").manual_seed(5)
+    s = torch.round(torch.rand(3, 50001, device="cuda", generator=g) * 100) / 100
+    a, b = ops.topk_order(s, 3000), ops.topk_order(s, 3000)
+    assert torch.equal(a, b)
+    L = _lib.lib()
+    assert L.sln_topk_workspace_bytes(3, 50001, 3000) > 3 * 3000 * 8
+    assert L.sln_topk_order_f32(ops._ptr(s), 3, 50001, s.stride(0), s.stride(1), 3000, ops._ptr(a), None, 0,
+                                None) == 2          # SLN_ERR_WORKSPACE
+
+
 def test_topk_order_full_size_batch():
     from sln_amodal_amd import ops
     g = torch.Generator(device="cuda").manual_seed(3)
