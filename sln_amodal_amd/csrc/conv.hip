@@ -560,7 +560,7 @@ struct ConvParams {
     int Cin, Cout, KH, KW, sh, sw, dh, dw, pt, pl, relu;
     int M, Ktot, cin_chunks, gm, gn;
     int w_tiled;   // weights in conv_fwd256_kernel's LDS-image order (split_weights_tiled_kernel)
-    int dbg;   // ablation bits, debug sessions only (SLN_CONV_DBG): 1 no DMA in the k-loop, 2 no MFMA, 4 no fragment reads
+    int dbg;   // ablation bits, debug sessions only (SLN_CONV_DBG): 1 no DMA in the k-loop, 2 no MFMA, 4 no fragment reads, 8 no wave-group stagger, 16 general epilogue
     // Up to SLN_MAX_SEG image groups of different sizes share one launch (the GLM's three
     // scales): group s holds segN[s] images of segH x segW, its output rows start at
     // seg_m0[s] and its input pixels at seg_x0[s] of the flat [pixels][C] buffers.
@@ -702,6 +702,126 @@ __device__ __forceinline__ void epilogue_slab(const ConvParams &p, const float *
                 if (csum[e] != 0.f) atomicAdd(&s_colsum[4 * (t & (NCOLQ - 1)) + e], csum[e]);
         }
     }
+}
+
+// The same slab for the fp16 x 2 format whenever rows are whole 16-B groups (Cout % 4 == 0): residual and
+// output parts fixed at compile time, the backward extras (mask, post-scale, column sums, no fp32 output)
+// as uniform branches, running row pointers instead of 64-bit index math per row, saturation derived once
+// from the running amax.  The general epilogue_slab spends ~150 VALU instructions per four outputs on
+// per-element feature selects and index arithmetic: the 256x256 tile's epilogue cost 50-70 k cycles with it
+// (stamps, tools/conv_stamps.py: the slab calls themselves, not their barriers or the store drain) -- more
+// than the whole k-loop of a K = 256 layer; 17-40 k with this one.  Same arithmetic per element as
+// epilogue_slab + split4<2> (bit-identical y, parts and column sums up to their summation order).
+template <int NCOLQ, int LD, int NTHREADS, bool RES, bool PARTS>
+__device__ __forceinline__ void epilogue_slab_f16(const ConvParams &p, const float *stage, int m_base, int n0,
+                                                  int t, float *s_colsum, float alpha, float yqs, float &amx) {
+    constexpr int RG = NTHREADS / NCOLQ;
+    constexpr int NQ = 64 / RG;
+    const int c = n0 + 4 * (t & (NCOLQ - 1));
+    if (c >= p.Cout) return;
+    const int row0 = t / NCOLQ;
+    float4 sc = make_float4(alpha, alpha, alpha, alpha), sf = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.scale) {
+        const float4 s4 = *(const float4 *)(p.scale + c);
+        sc = make_float4(s4.x * alpha, s4.y * alpha, s4.z * alpha, s4.w * alpha);
+    }
+    if (p.shift) sf = *(const float4 *)(p.shift + c);
+    const long o0 = (long)(m_base + row0) * p.Cout + c;
+    const long ostep = (long)RG * p.Cout;
+    float4 res4[NQ];
+    if (RES) {
+        const float *r = p.residual + o0;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            res4[q] = (m_base + row0 + RG * q) < p.M ? *(const float4 *)r : make_float4(0.f, 0.f, 0.f, 0.f);
+            r += ostep;
+        }
+    }
+    // backward extras (uniform per launch): the producer's ReLU mask, a scale applied to the parts and
+    // column sums only, per-channel sums of what the parts hold (the previous layer's bias gradient)
+    const float *mk = p.mask ? p.mask + o0 : nullptr;
+    float4 ps4 = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (p.post_scale) ps4 = *(const float4 *)(p.post_scale + c);
+    float csum[4] = {0.f, 0.f, 0.f, 0.f};
+    float *yp = p.y ? p.y + o0 : nullptr;
+    __bf16 *p0 = nullptr, *p1 = nullptr;
+    long pstep = 0;
+    if (PARTS) {
+        p0 = p.yparts + (long)(m_base + row0) * p.Cop + c;
+        p1 = p0 + p.y_part_stride;
+        pstep = (long)RG * p.Cop;
+    }
+    const float *sg = stage + row0 * LD + 4 * (t & (NCOLQ - 1));
+    const bool relu = p.relu != 0;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        if (m_base + row0 + RG * q < p.M) {
+            const float4 a4 = *(const float4 *)(sg + q * RG * LD);
+            float v[4] = {a4.x * sc.x + sf.x, a4.y * sc.y + sf.y, a4.z * sc.z + sf.z, a4.w * sc.w + sf.w};
+            if (RES) {
+                v[0] += res4[q].x; v[1] += res4[q].y; v[2] += res4[q].z; v[3] += res4[q].w;
+            }
+            if (relu) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            if (mk) {
+                const float4 k4 = *(const float4 *)mk;
+                if (!(k4.x > 0.f)) v[0] = 0.f;
+                if (!(k4.y > 0.f)) v[1] = 0.f;
+                if (!(k4.z > 0.f)) v[2] = 0.f;
+                if (!(k4.w > 0.f)) v[3] = 0.f;
+            }
+            if (yp) *(float4 *)yp = make_float4(v[0], v[1], v[2], v[3]);
+            if (p.post_scale) {
+                // rounded to fp32 before the split (no contraction into split4's subtraction): the same
+                // value sln_conv_grad_prep_f32 would split
+#pragma clang fp contract(off)
+                v[0] = v[0] * ps4.x; v[1] = v[1] * ps4.y; v[2] = v[2] * ps4.z; v[3] = v[3] * ps4.w;
+            }
+            if (p.colsum) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) csum[e] += v[e];
+            }
+            if (PARTS) {
+                amx = amax4(amx, v);
+                bf16x4 ps[2];
+                (void)split4<2>(make_float4(v[0], v[1], v[2], v[3]), ps, yqs);
+                *(bf16x4 *)p0 = ps[0];
+                *(bf16x4 *)p1 = ps[1];
+            }
+        }
+        if (yp) yp += ostep;
+        if (mk) mk += ostep;
+        if (PARTS) { p0 += pstep; p1 += pstep; }
+    }
+    if (p.colsum) {   // the row groups share a column: combine in LDS first
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (csum[e] != 0.f) atomicAdd(&s_colsum[4 * (t & (NCOLQ - 1)) + e], csum[e]);
+    }
+}
+
+// Dispatch of a slab: the fixed-feature version whenever the rows are whole 16-B groups.
+template <int P, int NCOLQ, int LD, int NTHREADS>
+__device__ __forceinline__ void epilogue_any(const ConvParams &p, const float *stage, int m_base, int n0, int t,
+                                             float *s_colsum, float alpha, float yqs, float &amx, bool &sat,
+                                             bool fast) {
+    if (P == 2 && fast) {
+        if (p.residual) {
+            if (p.yparts) epilogue_slab_f16<NCOLQ, LD, NTHREADS, true, true>(p, stage, m_base, n0, t, s_colsum, alpha, yqs, amx);
+            else epilogue_slab_f16<NCOLQ, LD, NTHREADS, true, false>(p, stage, m_base, n0, t, s_colsum, alpha, yqs, amx);
+        } else {
+            if (p.yparts) epilogue_slab_f16<NCOLQ, LD, NTHREADS, false, true>(p, stage, m_base, n0, t, s_colsum, alpha, yqs, amx);
+            else epilogue_slab_f16<NCOLQ, LD, NTHREADS, false, false>(p, stage, m_base, n0, t, s_colsum, alpha, yqs, amx);
+        }
+    } else {
+        epilogue_slab<P, NCOLQ, LD, NTHREADS>(p, stage, m_base, n0, t, s_colsum, alpha, yqs, amx, sat);
+    }
+}
+
+__device__ __forceinline__ bool epilogue_is_plain(const ConvParams &p) {
+    return (p.Cout & 3) == 0 && (!p.yparts || (p.Cop & 3) == 0);
 }
 
 // BNT = 128: waves 2x2, each 64x64 (2x2 MFMA tiles).  BNT = 64 (Cout <= 64: the C2 stage): waves 4x1,
@@ -865,6 +985,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvParams p) {
     // tiles), read back row-major: thread t owns columns 4*(t&31)..+3 of rows
     // (t>>5) + 8q.  Per element: v = acc*scale[c] + shift[c] (+ residual) (ReLU).
     float(*stage)[SLD] = (float(*)[SLD])smem;
+    const bool plain = P == 2 && epilogue_is_plain(p) && !(p.dbg & 16);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         // rows 64h .. 64h+63 of the tile: waves wr == h (BNT 128, 64 rows each) or wr>>1 == h (BNT 64, 32 each)
@@ -880,11 +1001,12 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvParams p) {
                             acc[i][j][r];
         }
         __syncthreads();
-        epilogue_slab<P, BNT / 4, SLD, 256>(p, &stage[0][0], m0 + h * 64, n0, t, s_colsum, alpha, yqs, amx, sat);
+        epilogue_any<P, BNT / 4, SLD, 256>(p, &stage[0][0], m0 + h * 64, n0, t, s_colsum, alpha, yqs, amx, sat, plain);
         __syncthreads();
     }
     if (p.colsum && t < BNT && n0 + t < p.Cout && s_colsum[t] != 0.f)   // one global atomic per column
         atomicAdd(p.colsum + n0 + t, s_colsum[t]);
+    if (P == 2 && plain) sat = amx * yqs > SLN_F16_MAX;
     if (P == 2 && p.yparts) amax_commit(amx, sat, p.yq, s_word);
 }
 
@@ -1115,6 +1237,8 @@ __global__ __launch_bounds__(512) void conv_fwd256h_kernel(const ConvParams p) {
     bool sat = false;
     typedef __attribute__((address_space(3))) void lds_void;
     typedef __attribute__((address_space(1))) const void glb_void;
+    unsigned long long ts_start = 0, ts_loop0 = 0, ts_loop1 = 0, ts_end = 0;   // STAMP: whole-tile segments
+    SLN_STAMP(ts_start);
 
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
@@ -1244,6 +1368,7 @@ __global__ __launch_bounds__(512) void conv_fwd256h_kernel(const ConvParams p) {
     asm volatile("" ::: "memory");
 
     bf16x8 b[2][P];
+    SLN_STAMP(ts_loop0);
     for (int s = 0; s < nk; ++s) {
         const unsigned char *st = smem + (s & 1) * STAGE;
         const bool more = s + 1 < nk;
@@ -1322,16 +1447,15 @@ __global__ __launch_bounds__(512) void conv_fwd256h_kernel(const ConvParams p) {
             }
         }
     }
-    if (STAMP && blockIdx.x == 0 && lane == 0) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) sln_stamp_sums[wave * 16 + i] = sums[i];
-    }
+    SLN_STAMP(ts_loop1);
     if (wr == 0 && stagger) __builtin_amdgcn_s_barrier();      // re-align the two groups
     __syncthreads();
 
     // ---- epilogue: four 64-row slabs through LDS ([64][260] floats), as in conv_fwd256_kernel ----
     float *stage = (float *)smem;
     static_assert(64 * 260 * 4 <= 2 * STAGE, "staging slab must fit");
+    const bool plain = epilogue_is_plain(p) && !(p.dbg & 16);      // (dbg 16: A/B against epilogue_slab)
+    SLN_STAMP(t0);
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
         if (wr == (h >> 1)) {
@@ -1344,12 +1468,34 @@ __global__ __launch_bounds__(512) void conv_fwd256h_kernel(const ConvParams p) {
                         stage[(ii * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 260 + wc * 64 + j * 32 +
                               (lane & 31)] = acc[2 * (h & 1) + ii][j][r];
         }
+        SLN_STAMP(t1);
         __syncthreads();
-        epilogue_slab<P, 64, 260, 512>(p, stage, m0 + h * 64, n0, t, s_colsum, alpha, yqs, amx, sat);
+        SLN_STAMP(t2);
+        epilogue_any<P, 64, 260, 512>(p, stage, m0 + h * 64, n0, t, s_colsum, alpha, yqs, amx, sat, plain);
+        SLN_STAMP(t3);
         __syncthreads();
+        SLN_STAMP(t4);
+        if (STAMP && NPH == 2) {
+            sums[11] += t1 - t0; sums[12] += t2 - t1; sums[13] += t3 - t2; sums[14] += t4 - t3;
+        }
+        t0 = t4;
     }
     if (p.colsum && t < T2 && n0 + t < p.Cout && s_colsum[t] != 0.f) atomicAdd(p.colsum + n0 + t, s_colsum[t]);
+    if (plain) sat = amx * yqs > SLN_F16_MAX;      // the fixed-feature slabs clamp without recording it
     if (p.yparts) amax_commit(amx, sat, p.yq, s_word);
+    if (STAMP) {
+        SLN_STAMP(t1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the tile's stores have left the wave
+        SLN_STAMP(ts_end);
+        if (NPH == 2) sums[15] = ts_end - t1;
+        if (NPH == 2) {   // (phases 2, 3 unused) whole-tile segments: prologue, k-loop, epilogue
+            sums[8] = ts_loop0 - ts_start; sums[9] = ts_loop1 - ts_loop0; sums[10] = ts_end - ts_loop1;
+        }
+        if (blockIdx.x == 0 && lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sln_stamp_sums[wave * 16 + i] = sums[i];
+        }
+    }
 }
 
 // ------------------------------------------------------------ weight gradient
