@@ -450,6 +450,48 @@ def _grad_prep(gy, y, scale, want_gu, want_bias, parts, slot=None):
     return gz, (gu if want_gu else None), gb
 
 
+# ------------------------------------------------------------------ bias folded into the frozen-BN shift
+# shift' = bias * bn_scale + bn_shift of every conv with a bias and a frozen BN (the whole detector: the
+# reference's convs all carry a bias, modals.py:264-355).  The biases train, so the value changes every step
+# -- for all layers at once, when the optimiser steps.  Instead of two 5-us kernels per layer per step the
+# stale entries are recomputed together (two foreach launches) the first time one of them is asked for.
+_FOLDS = {}          # id(bias) -> [weakref(bias), bn_scale, bn_shift, bias version, folded shift]
+FOLD_STATS = [0, 0]  # batched refreshes, entries refreshed
+
+
+def folded_shift(bias, bn_scale, bn_shift):
+    import weakref
+    e = _FOLDS.get(id(bias))
+    if e is not None and e[0]() is bias and e[1] is bn_scale and e[2] is bn_shift:
+        if e[3] == bias._version:
+            return e[4]
+        # stale: refresh every stale entry of this device in one go
+        live, dead = [], []
+        for k, f in _FOLDS.items():
+            b = f[0]()
+            if b is None:
+                dead.append(k)
+            elif b._version != f[3] and b.device == bias.device and b.dtype == bias.dtype:
+                live.append((f, b))
+        for k in dead:
+            del _FOLDS[k]
+        with torch.no_grad():
+            outs = torch._foreach_mul([b.detach() for _, b in live], [f[1] for f, _ in live])
+            torch._foreach_add_(outs, [f[2] for f, _ in live])
+        for (f, b), o in zip(live, outs):
+            f[3], f[4] = b._version, o
+        FOLD_STATS[0] += 1
+        FOLD_STATS[1] += len(live)
+        return e[4]
+    with torch.no_grad():
+        out = (bias.detach() * bn_scale + bn_shift).contiguous()
+    try:
+        _FOLDS[id(bias)] = [weakref.ref(bias), bn_scale, bn_shift, bias._version, out]
+    except TypeError:
+        pass
+    return out
+
+
 class _ConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, bn_scale, bn_shift, residual, relu, stride, dil, pads, link=None,
@@ -464,7 +506,9 @@ class _ConvFn(torch.autograd.Function):
         OW = (W + pl + pr - dil[1] * (KW - 1) - 1) // stride[1] + 1
         scale, shift = bn_scale, bn_shift
         if bias is not None:
-            shift = bias * bn_scale + bn_shift if bn_scale is not None else bias
+            frozen = bn_scale is not None and not (bn_scale.requires_grad or bn_shift.requires_grad)
+            shift = (folded_shift(bias, bn_scale, bn_shift) if frozen else bias * bn_scale + bn_shift) \
+                if bn_scale is not None else bias
         if shift is not None:
             shift = shift.detach().contiguous()
         if scale is not None:

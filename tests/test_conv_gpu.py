@@ -760,3 +760,25 @@ def test_whole_window_conv_runs_as_linear_layer_and_matches_fp64(parts, monkeypa
     for got, want in ((gx, rx), (gw, rw), (gb, rb)):
         assert got.shape == want.shape
         assert (got.double() - want).abs().max().item() / want.abs().max().item() < 2e-5
+
+
+def test_folded_bias_shift_refreshes_all_layers_together():
+    """bias * bn_scale + bn_shift of every layer is cached and, once the biases change (an optimiser step
+    changes all of them), recomputed for all stale layers in one batch -- same values as the direct formula."""
+    from sln_amodal_amd import conv_hip
+    g = torch.Generator(device="cuda").manual_seed(4)
+    layers = [(torch.nn.Parameter(torch.randn(c, device="cuda", generator=g)),
+               torch.rand(c, device="cuda", generator=g) + 0.5, torch.randn(c, device="cuda", generator=g))
+              for c in (64, 256, 1024, 8)]
+    first = [conv_hip.folded_shift(b, s, h) for b, s, h in layers]
+    for (b, s, h), f in zip(layers, first):
+        assert torch.equal(f, b.detach() * s + h)
+    assert conv_hip.folded_shift(*layers[0]) is first[0]                 # cached
+    with torch.no_grad():
+        for b, _, _ in layers:
+            b.add_(0.125)
+    before = list(conv_hip.FOLD_STATS)
+    second = [conv_hip.folded_shift(b, s, h) for b, s, h in layers]
+    assert conv_hip.FOLD_STATS[0] == before[0] + 1 and conv_hip.FOLD_STATS[1] >= before[1] + len(layers)
+    for (b, s, h), f in zip(layers, second):
+        assert torch.equal(f, b.detach() * s + h)
