@@ -115,8 +115,7 @@ def _neg_count_table(rois_per_image, positive_ratio, device):
     exactly as Functions.py:356-357 does, for p = 0..max positives."""
     max_pos = int(rois_per_image * positive_ratio)
     r = 1.0 / positive_ratio
-    return torch.tensor([int(r * p - p) for p in range(max_pos + 1)], dtype=torch.int64,
-                        device=device)
+    return utils.const_tensor([int(r * p - p) for p in range(max_pos + 1)], torch.int64, device)
 
 
 def priorities_from_draws(candidates, draws):
@@ -195,9 +194,10 @@ def detection_target_layer(proposals, gt_class_ids, gt_boxes, gt_masks, config,
     pos_assign = torch.gather(assign, 1, pidx)
     roi_gt = torch.gather(gt_boxes, 1, pos_assign.unsqueeze(2).expand(-1, -1, 4))
     roi_cls = torch.gather(gt_class_ids, 1, pos_assign).to(torch.int32)
-    std = torch.as_tensor(np.asarray(config.BBOX_STD_DEV), dtype=torch.float32, device=dev)
-    safe_rois = torch.where(pos_slot.unsqueeze(2), pos_rois, torch.tensor([0., 0., 1., 1.], device=dev))
-    safe_gt = torch.where(pos_slot.unsqueeze(2), roi_gt, torch.tensor([0., 0., 1., 1.], device=dev))
+    std = utils.const_tensor(np.asarray(config.BBOX_STD_DEV), torch.float32, dev)
+    unit = utils.const_tensor([0., 0., 1., 1.], torch.float32, dev)
+    safe_rois = torch.where(pos_slot.unsqueeze(2), pos_rois, unit)
+    safe_gt = torch.where(pos_slot.unsqueeze(2), roi_gt, unit)
     deltas = utils.box_refinement(safe_rois.reshape(-1, 4), safe_gt.reshape(-1, 4)).view(B, kp, 4) / std
 
     mh, mw = config.MASK_SHAPE[0], config.MASK_SHAPE[1]
@@ -251,11 +251,10 @@ def clip_to_window(window, boxes):
 def coordinate_convert(rois, deltas_specific, config, use_cuda=False):
     """Apply class-specific deltas (scaled by RPN_BBOX_STD_DEV, as the reference
     does at inference, Functions.py:436-450) and go to pixel coordinates."""
-    std = torch.as_tensor(np.reshape(config.RPN_BBOX_STD_DEV, [1, 4]), dtype=torch.float32,
-                          device=rois.device)
+    std = utils.const_tensor(np.reshape(config.RPN_BBOX_STD_DEV, [1, 4]), torch.float32, rois.device)
     refined = apply_box_deltas(rois, deltas_specific * std)
     height, width = config.IMAGE_SHAPE[:2]
-    scale = torch.tensor([height, width, height, width], dtype=torch.float32, device=rois.device)
+    scale = utils.const_tensor([height, width, height, width], torch.float32, rois.device)
     return refined * scale
 
 

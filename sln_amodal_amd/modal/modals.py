@@ -23,7 +23,8 @@ from ..roialign.roi_align.crop_and_resize import CropAndResizeFunction
 
 def log2(x):
     """log(x)/log(2) in fp32, like the reference helper (modals.py:8-13)."""
-    ln2 = torch.log(torch.tensor([2.0], dtype=torch.float32, device=x.device))
+    from ..utils import const_tensor
+    ln2 = torch.log(const_tensor([2.0], torch.float32, x.device))
     return torch.log(x) / ln2
 
 
@@ -37,8 +38,8 @@ def roi_levels(boxes, image_shape):
     y1, x1, y2, x2 = boxes.chunk(4, dim=1)
     h = y2 - y1
     w = x2 - x1
-    image_area = torch.tensor([float(image_shape[0] * image_shape[1])], dtype=torch.float32,
-                              device=boxes.device)
+    from ..utils import const_tensor
+    image_area = const_tensor([float(image_shape[0] * image_shape[1])], torch.float32, boxes.device)
     lvl = 4 + log2(torch.sqrt(h * w) / (224.0 / torch.sqrt(image_area)))
     lvl = torch.nan_to_num(lvl, nan=2.0, posinf=5.0, neginf=2.0)
     return lvl.round().int().clamp(2, 5).view(-1)

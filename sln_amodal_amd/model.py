@@ -213,7 +213,7 @@ class MaskRCNN(nn.Module):
             rpn_rois, num_rois = proposal_layer([rpn_class, rpn_bbox], proposal_count=count,
                                                 nms_threshold=cfg.RPN_NMS_THRESHOLD,
                                                 anchors=self.anchors, config=cfg, return_counts=True)
-        scale = torch.tensor([H, W, H, W], dtype=torch.float32, device=molded_images.device)
+        scale = utils.const_tensor([H, W, H, W], torch.float32, molded_images.device)
 
         if mode == "inference":
             return self._predict_inference(rpn_rois, num_rois, mrcnn_feature_maps, probs,

@@ -98,3 +98,19 @@ def labels_from_painter_order(amodal_masks):
         label[m & covered] |= np.uint64(1) << np.uint64(32 + i)
         covered |= m
     return label
+
+
+_CONST_TENSORS = {}
+
+
+def const_tensor(values, dtype, device):
+    """A small constant as a device tensor, created once per (values, dtype, device).  torch.tensor(list,
+    device="cuda") is a pageable host-to-device copy: the host waits for it, loses its lead over the GPU, and
+    the queue runs dry (two 300-us holes per train step before this cache).  Do not modify the result."""
+    import torch
+    flat = tuple(np.asarray(values, dtype=np.float64).reshape(-1).tolist())
+    key = (flat, tuple(np.shape(values)), dtype, str(device))
+    t = _CONST_TENSORS.get(key)
+    if t is None:
+        t = _CONST_TENSORS[key] = torch.tensor(values, dtype=dtype, device=device)
+    return t
