@@ -1236,7 +1236,6 @@ __global__ __launch_bounds__(512) void conv_fwd256h_kernel(const ConvParams p) {
     float amx = 0.f;
     bool sat = false;
     typedef __attribute__((address_space(3))) void lds_void;
-    typedef __attribute__((address_space(1))) const void glb_void;
     unsigned long long ts_start = 0, ts_loop0 = 0, ts_loop1 = 0, ts_end = 0;   // STAMP: whole-tile segments
     SLN_STAMP(ts_start);
 
