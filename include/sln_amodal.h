@@ -182,6 +182,19 @@ int sln_topk_order_f32(const float *scores, int B, int A, long stride_b, long st
                        int64_t *order, void *workspace, size_t workspace_bytes, sln_stream_t stream);
 
 /* ---------------------------------------------------------------------------
+ * Max-pooling of the two stems, NHWC fp32, C % 4 == 0.
+ * Replaces: SamePad2d + nn.MaxPool2d(3, 2) (modal/modals.py:316-317) and nn.MaxPool2d(3, 2, 1, ceil_mode=True)
+ *           (modal/resnet_deeplab.py stem) and their backward.
+ * Window (oh, ow) covers rows oh*S - pad_top ... + K - 1 (columns alike), clipped to the map; OH / OW are the
+ * caller's (floor or ceil mode).  argmax [N,OH,OW,C] uint8: winning tap kh*K + kw (torch's rule: first of
+ * equal values, NaN wins).  Backward writes every element of gx [N,H,W,C] exactly once (gather; no memset).
+ * ------------------------------------------------------------------------- */
+int sln_maxpool_fwd_f32(const float *x, int N, int H, int W, int C, int K, int S, int pad_top, int pad_left,
+                        int OH, int OW, float *y, uint8_t *argmax, sln_stream_t stream);
+int sln_maxpool_bwd_f32(const float *g, const uint8_t *argmax, int N, int H, int W, int C, int K, int S,
+                        int pad_top, int pad_left, int OH, int OW, float *gx, sln_stream_t stream);
+
+/* ---------------------------------------------------------------------------
  * FPN top-down merge (modal/modals.py:243-246): out = lateral + nearest-2x(top) in one pass, and the
  * coarse input's gradient.  NHWC fp32, C % 4 == 0.
  * Replaces: F.upsample(scale_factor=2) + add (the upsampled map written and read back) and the

@@ -28,6 +28,8 @@ SIGNATURES = {
     "sln_proposal_decode_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, C.POINTER(_f), _f, _f, _p, _p]),
     "sln_topk_workspace_bytes": (C.c_size_t, [_i, _i, _i]),
     "sln_topk_order_f32": (_i, [_p, _i, _i, C.c_long, C.c_long, _i, _p, _p, C.c_size_t, _p]),
+    "sln_maxpool_fwd_f32": (_i, [_p] + [_i] * 10 + [_p, _p, _p]),
+    "sln_maxpool_bwd_f32": (_i, [_p, _p] + [_i] * 10 + [_p, _p]),
     "sln_upsample2x_add_f32": (_i, [_p, _p, _i, _i, _i, _i, _p, _p]),
     "sln_sumpool2x2_f32": (_i, [_p, _i, _i, _i, _i, _p, _p]),
     "sln_grad_sqnorm_f32": (_i, [_p, _p, _p, _p, _i, _i, _p, _p, _p]),

@@ -67,3 +67,7 @@ class _Stem(nn.Sequential):
         super(_Stem, self).__init__()
         self.add_module("conv1", _ConvBnReLU(3, out_ch, 7, 2, 3, 1))
         self.add_module("pool", nn.MaxPool2d(3, 2, 1, ceil_mode=True))
+
+    def forward(self, x):
+        p = self.pool
+        return nn_ops.max_pool_ceil(self.conv1(x), p.kernel_size, p.stride, p.padding)

@@ -132,18 +132,68 @@ def conv_bn_act(x, conv, bn=None, relu=False, residual=None, same=False, link=No
     return y
 
 
+class _MaxPoolFn(torch.autograd.Function):
+    """Clipped-window max-pool on NHWC maps (csrc/maxpool.hip): forward keeps the winning tap per output,
+    backward gathers -- every input gradient written once, no memset."""
+
+    @staticmethod
+    def forward(ctx, x, kernel, stride, pad_top, pad_left, OH, OW):
+        from . import _lib, ops
+        xc = x if x.is_contiguous(memory_format=torch.channels_last) else \
+            x.contiguous(memory_format=torch.channels_last)
+        N, C, H, W = xc.shape
+        y = torch.empty((N, C, OH, OW), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+        arg = torch.empty((N, OH, OW, C), dtype=torch.uint8, device=x.device)
+        _lib.check(_lib.lib().sln_maxpool_fwd_f32(ops._ptr(xc), N, H, W, C, kernel, stride, pad_top, pad_left, OH, OW,
+                                                  ops._ptr(y), ops._ptr(arg), ops._stream()), "sln_maxpool_fwd_f32")
+        ctx.save_for_backward(arg)
+        ctx.cfg = (N, C, H, W, kernel, stride, pad_top, pad_left, OH, OW)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _lib, ops
+        (arg,) = ctx.saved_tensors
+        N, C, H, W, kernel, stride, pad_top, pad_left, OH, OW = ctx.cfg
+        gc = g if g.is_contiguous(memory_format=torch.channels_last) else \
+            g.contiguous(memory_format=torch.channels_last)
+        gx = torch.empty((N, C, H, W), dtype=torch.float32, device=g.device, memory_format=torch.channels_last)
+        _lib.check(_lib.lib().sln_maxpool_bwd_f32(ops._ptr(gc), ops._ptr(arg), N, H, W, C, kernel, stride, pad_top,
+                                                  pad_left, OH, OW, ops._ptr(gx), ops._stream()), "sln_maxpool_bwd_f32")
+        return gx, None, None, None, None, None, None
+
+
+def _hip_pool_ok(x):
+    return BACKEND != "torch" and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] % 4 == 0
+
+
 def max_pool_same(x, kernel, stride):
     """SamePad2d + MaxPool2d (modal/modals.py:316-317).  Zero padding is safe: the
     input is post-ReLU."""
     pt, pb = same_pad(x.shape[2], kernel, stride)
     pl, pr = same_pad(x.shape[3], kernel, stride)
     H, W = x.shape[2], x.shape[3]
+    if _hip_pool_ok(x) and pt < kernel and pl < kernel:
+        # a window clipped at the border equals the zero-padded one for the non-negative input
+        OH = (H + pt + pb - kernel) // stride + 1
+        OW = (W + pl + pr - kernel) // stride + 1
+        return _MaxPoolFn.apply(x, kernel, stride, pt, pl, OH, OW)
     if pt == 0 and pl == 0 and pb < kernel and pr < kernel and \
             -(-(H - kernel) // stride) + 1 == -(-H // stride) and -(-(W - kernel) // stride) + 1 == -(-W // stride):
         # bottom/right padding only (the even sizes of the path): a clipped last window equals a
         # zero-padded one for the non-negative input, and ceil_mode saves the padded copy of the map
         return F.max_pool2d(x, kernel, stride, padding=0, ceil_mode=True)
     return F.max_pool2d(F.pad(x, (pl, pr, pt, pb)), kernel, stride)
+
+
+def max_pool_ceil(x, kernel, stride, padding):
+    """nn.MaxPool2d(kernel, stride, padding, ceil_mode=True) (the GLM stem, modal/resnet_deeplab.py)."""
+    if _hip_pool_ok(x) and padding < kernel:
+        def out(n):     # torch's ceil-mode output size: the last window must start inside the (left-padded) map
+            o = -(-(n + 2 * padding - kernel) // stride) + 1
+            return o - 1 if (o - 1) * stride >= n + padding else o
+        return _MaxPoolFn.apply(x, kernel, stride, padding, padding, out(x.shape[2]), out(x.shape[3]))
+    return F.max_pool2d(x, kernel, stride, padding, ceil_mode=True)
 
 
 class _FpnMerge(torch.autograd.Function):

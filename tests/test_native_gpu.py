@@ -459,3 +459,40 @@ def test_fpn_merge_equals_upsample_then_add(shape):
     ref.backward(up)
     assert torch.equal(a.grad, ra.grad)
     assert torch.allclose(b.grad, rb.grad, rtol=1e-6, atol=1e-6)
+
+
+# ------------------------------------------------------------------ stem max-pools
+@pytest.mark.parametrize("shape", [(2, 64, 128, 128), (1, 64, 67, 45), (2, 8, 6, 9), (1, 64, 257, 257)])
+@pytest.mark.parametrize("kind", ["same", "ceil"])
+def test_max_pool_matches_torch_forward_and_argmax(shape, kind):
+    """nn_ops.max_pool_same (modals.py:316-317) / max_pool_ceil (resnet_deeplab.py stem) on the HIP kernels:
+    values equal to F.max_pool2d, and the gradient lands on the same element -- post-ReLU maps are full of
+    exact ties (zeros), where torch keeps the first tap in kh-major order."""
+    import torch.nn.functional as F
+    from sln_amodal_amd import nn_ops
+    N, C, H, W = shape
+    g = torch.Generator(device="cuda").manual_seed(H + W)
+    x = torch.relu(torch.randn(N, C, H, W, device="cuda", generator=g)).contiguous(memory_format=torch.channels_last)
+    a, b = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    if kind == "same":
+        y = nn_ops.max_pool_same(a, 3, 2)
+        pt, pb = nn_ops.same_pad(H, 3, 2)
+        pl, pr = nn_ops.same_pad(W, 3, 2)
+        ref = F.max_pool2d(F.pad(b, (pl, pr, pt, pb)), 3, 2)
+    else:
+        y = nn_ops.max_pool_ceil(a, 3, 2, 1)
+        ref = F.max_pool2d(b, 3, 2, 1, ceil_mode=True)
+    assert type(y.grad_fn).__name__ == "_MaxPoolFnBackward"
+    assert y.shape == ref.shape and torch.equal(y, ref)
+    up = torch.randn(y.shape, device="cuda", generator=g)
+    y.backward(up)
+    ref.backward(up)
+    if kind == "ceil":
+        assert torch.equal(a.grad, b.grad)
+    else:
+        # the reference pads with zeros: where a border window's maximum is 0 its first zero may be a padding
+        # element (gradient dropped there); away from ties the two agree exactly
+        same = a.grad == b.grad
+        assert same.float().mean() > 0.999 or (x > 0).float().mean() < 0.5
+        pos = x > 0
+        assert torch.equal(a.grad[pos], b.grad[pos])
