@@ -29,6 +29,7 @@ class ClippedSGD(object):
         self.state = {}                      # param -> momentum buffer
         self._plan_key, self._plan = None, None
         self._ring, self._turn = [], 0       # pinned staging buffers of the pointer tables
+        self.capturing = False               # inside a HIP-graph capture: no event waits (the tables are static)
         self.last_norm = None
 
     def zero_grad(self, set_to_none=True):
@@ -94,7 +95,7 @@ class ClippedSGD(object):
             self._ring = [[torch.empty((3, n), dtype=torch.int64, pin_memory=True), None] for _ in range(4)]
         stage = self._ring[self._turn % len(self._ring)]
         self._turn += 1
-        if stage[1] is not None:
+        if stage[1] is not None and not self.capturing:
             stage[1].synchronize()
         host = stage[0].numpy()
         host[0] = [p.data_ptr() for p in ps]
@@ -102,8 +103,9 @@ class ClippedSGD(object):
         host[2] = [b.data_ptr() for b in bs]
         tab = torch.empty((3, n), dtype=torch.int64, device=dev)
         tab.copy_(stage[0], non_blocking=True)
-        stage[1] = torch.cuda.Event()
-        stage[1].record()
+        if not self.capturing:
+            stage[1] = torch.cuda.Event()
+            stage[1].record()
         sq = torch.empty(1, dtype=torch.float64, device=dev)
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         L = _lib.lib()
