@@ -212,9 +212,11 @@ def main():
         torch.cuda.synchronize()
 
     losses = []
+    from sln_amodal_amd import conv_hip
+    sat_setup = conv_hip.saturation_count()        # (host syncs outside the timed region)
     for i in range(args.warmup):
         loss, _ = model.train_step(batches[i % 2], opt, sync)
-    from sln_amodal_amd import conv_hip
+    sat_warmup = conv_hip.saturation_count()
     if rank == 0:
         conv_hip.PROFILE = []          # HIP-event pairs around every conv launch (launch stream)
     barrier()
@@ -257,7 +259,11 @@ def main():
                        if conv_hip.PARTS == 2 else "3 x bf16 (6 MFMA products per fp32 multiply-add)",
                        "final_loss": round(final_loss, 5),
                        "loss_trace": [round(float(l), 4) for l in losses[:: max(1, len(losses) // 8)]],
-                       "max_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)},
+                       "max_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
+                       # fp16 x 2 operands: blocks that had to clamp a value to +-65504 since start-up
+                       # (set-up, warm-up steps, timed steps)
+                       "conv_saturated_blocks": [sat_setup, sat_warmup - sat_setup,
+                                                 conv_hip.saturation_count() - sat_warmup]},
             "step_roofline": {"bound": "mfma", "kernel": "whole train step (all kernels)",
                               "achieved": round(achieved, 3), "peak": round(split_peak(conv_hip.PARTS), 1),
                               "unit": "TFLOP/s", "frac": round(achieved / split_peak(conv_hip.PARTS), 4),

@@ -43,16 +43,18 @@ _cache = _NoCache()   # kept for tools that call _cache.clear(); caches live on 
 
 # ------------------------------------------------------------------ per-tensor scales (PARTS = 2)
 SCALE_TARGET_LOG2 = 11      # max|v| * s lands in [2^10, 2^11): 2^5 of head room below fp16's 65504
+SCALE_HISTORY_DECAY = 0.5   # the assumed maximum shrinks by at most this factor per step (grows at once)
 
 
 class _Slot(object):
     """One tensor role of one layer: views of its device-side scale / running amax."""
-    __slots__ = ("scale", "amax", "fresh", "book")
+    __slots__ = ("scale", "amax", "hist", "fresh", "book")
 
     def __init__(self, book, idx):
         self.book = book
         self.scale = book.scale[idx:idx + 1]
         self.amax = book.amax[idx:idx + 1]
+        self.hist = book.hist[idx:idx + 1]
         self.fresh = True            # no scale yet: the first producer bootstraps it from an amax pass
 
 
@@ -61,8 +63,10 @@ class ScaleBook(object):
         self.device = device
         self.amax = torch.zeros(capacity, dtype=torch.float32, device=device)
         self.scale = torch.ones(capacity, dtype=torch.float32, device=device)
+        self.hist = torch.zeros(capacity, dtype=torch.float32, device=device)     # decaying running maximum
         self.saturated = torch.zeros(1, dtype=torch.int32, device=device)
         self.n = 0
+        self.names = []              # (role key, owner shape) per slot: diagnostics (tools/sat_probe.py)
 
     def new_slot(self):
         if self.n >= self.amax.numel():
@@ -79,17 +83,19 @@ class ScaleBook(object):
             import torch.distributed as dist
             if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
                 dist.all_reduce(self.amax[:self.n], op=dist.ReduceOp.MAX)
-            _lib.check(_lib.lib().sln_scale_update_f32(ops._ptr(self.amax), ops._ptr(self.scale), self.n,
-                                                       SCALE_TARGET_LOG2, ops._stream()), "sln_scale_update_f32")
+            _lib.check(_lib.lib().sln_scale_update_f32(ops._ptr(self.amax), ops._ptr(self.scale), ops._ptr(self.hist),
+                                                       self.n, SCALE_TARGET_LOG2, SCALE_HISTORY_DECAY, ops._stream()),
+                       "sln_scale_update_f32")
 
     def settle(self, slot):
         """Bootstrap: slot.amax holds an exact amax pass -> its scale; clears the fresh flag."""
-        _lib.check(_lib.lib().sln_scale_update_f32(ops._ptr(slot.amax), ops._ptr(slot.scale), 1,
-                                                   SCALE_TARGET_LOG2, ops._stream()), "sln_scale_update_f32")
+        _lib.check(_lib.lib().sln_scale_update_f32(ops._ptr(slot.amax), ops._ptr(slot.scale), ops._ptr(slot.hist), 1,
+                                                   SCALE_TARGET_LOG2, 0.0, ops._stream()), "sln_scale_update_f32")
         slot.fresh = False
 
 
 _books = {}
+SCALE_EPOCH = [0]     # advanced by update_scales(): cached activation parts encode the scale of their epoch
 
 
 def book(device):
@@ -103,6 +109,7 @@ def update_scales():
     """Call once per step (MaskRCNN.predict does): scales follow the previous step's amax."""
     for b in _books.values():
         b.update()
+    SCALE_EPOCH[0] += 1
 
 
 def saturation_count():
@@ -120,6 +127,7 @@ def _slot(owner, key):
     sl = slots.get(key)
     if sl is None:
         sl = slots[key] = book(owner.device).new_slot()
+        sl.book.names.append((key, tuple(owner.shape)))
     return sl
 
 
@@ -226,7 +234,7 @@ def act_parts(x, parts=None, owner=None, key=None):
     scale slot for this input (PARTS = 2; the first consumer's slot serves the others)."""
     parts = parts or PARTS
     hit = getattr(x, "_sln_parts", None)
-    if hit is not None and hit[0] == (x._version, parts):
+    if hit is not None and hit[0] == (x._version, parts, SCALE_EPOCH[0]):
         return hit[1], hit[2]
     xc = _nhwc(x.detach())
     N, C, H, W = xc.shape
@@ -236,7 +244,8 @@ def act_parts(x, parts=None, owner=None, key=None):
     out = _act_split(xc, N * H * W, C, parts, slot)
     q = slot.scale if slot is not None else None
     try:
-        x._sln_parts = ((x._version, parts), out, q)
+        x._sln_parts = ((x._version, parts, SCALE_EPOCH[0]), out, q)   # (a tensor that outlives
+        # update_scales() -- the same input fed again next step -- is split again with the new scale)
     except Exception:
         pass
     return out, q
@@ -325,7 +334,7 @@ def _fwd(xparts, N, H, W, w, Cout, KH, KW, stride, dil, pt, pl, OH, OW, scale, s
     if fresh:   # first use of this output's slot: exact amax pass over y, then the split
         yp = _act_split(_nhwc(y), N * OH * OW, Cout, P, yslot)
     if yp is not None and y is not None and post_scale is None:
-        y._sln_parts = ((y._version, P), yp, yslot.scale if P == 2 else None)
+        y._sln_parts = ((y._version, P, SCALE_EPOCH[0]), yp, yslot.scale if P == 2 else None)
     if mask is not None or not want_y or want_colsum:
         return y, yp, cs
     return y

@@ -1,6 +1,6 @@
 #include "common.h"
 
-extern "C" int sln_abi_version(void) { return 5; }  // 3: scaled split-fp16 operands (scale / amax arguments); 4: tail, optimiser, stem, crop accumulate; 5: top-k workspace
+extern "C" int sln_abi_version(void) { return 6; }  // 3: scaled split-fp16 operands (scale / amax arguments); 4: tail, optimiser, stem, crop accumulate; 5: top-k workspace; 6: scale history
 
 extern "C" const char *sln_error_string(int code) {
     switch (code) {

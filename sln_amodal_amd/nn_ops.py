@@ -276,7 +276,7 @@ def deconv2x2_relu_conv1x1(x, deconv, conv):
     y4 = y.permute(0, 2, 3, 1).reshape(N, H, W * 4, Co).permute(0, 3, 1, 2)     # pixel (i, 4j + 2a + b)
     hit = getattr(y, "_sln_parts", None)
     if hit is not None and hit[0][0] == y._version:     # the epilogue's parts of y are y4's, re-viewed
-        y4._sln_parts = ((y4._version, hit[0][1]), hit[1].view(hit[1].shape[0], -1, Co), hit[2])
+        y4._sln_parts = ((y4._version,) + tuple(hit[0][1:]), hit[1].view(hit[1].shape[0], -1, Co), hit[2])
     z = conv_bn_act(y4, conv)
     K = z.shape[1]
     z = z.permute(0, 2, 3, 1).reshape(N, H, W, 2, 2, K).permute(0, 5, 1, 3, 2, 4)

@@ -512,12 +512,38 @@ def test_two_part_fp16_delayed_scale_tracks_growth_and_saturates_without_inf():
         if e < 5e-6 and conv_hip.saturation_count() == sat1:
             break
     assert it <= 2 and e < 5e-6, (it, e)
-    for it in range(4):                         # shrinking by 1e10: stale scales flush the parts to
-        e, _ = two_layers(x0 * 1e-6)            # zero; again one update per layer brings them back
-        if e < 5e-6:
-            break
+    # Shrinking: the assumed maximum halves per produced step (it never follows a drop at once: tensors
+    # whose maximum comes and goes with the batch would clamp on its return).  A tensor 100x smaller than
+    # its recent maximum keeps its accuracy -- its values sit 7 binades lower in a 19-binade window; a
+    # collapse by many orders of magnitude is followed at one binade per step (a stated limit).
+    for _ in range(16):                         # let the running maxima come down from the 8000x episode
         conv_hip.update_scales()
-    assert it <= 3 and e < 5e-6, (it, e)
+        two_layers(x0)
+    e, _ = two_layers(x0)
+    assert e < 5e-6, e
+    conv_hip.update_scales()
+    e, _ = two_layers(x0 * 0.01)
+    assert e < 5e-6, e
+    for _ in range(10):
+        conv_hip.update_scales()
+        e, _ = two_layers(x0 * 0.01)
+    assert e < 5e-6, e
+    for _ in range(3):
+        conv_hip.update_scales()
+        two_layers(x0)
+    # a maximum that comes and goes with the batch (x200 up and down every step, like the RPN class-logit
+    # gradient of a pyramid level without positives) is covered by the decaying running maximum
+    for _ in range(3):
+        conv_hip.update_scales()
+        two_layers(x0)
+    sat2 = conv_hip.saturation_count()
+    for it in range(6):
+        conv_hip.update_scales()
+        e, _ = two_layers(x0 * (200.0 if it % 2 == 0 else 1.0))
+        if it >= 1:                             # (the very first spike is outside the 2^5 head room: clamped)
+            assert e < 5e-6, (it, e)
+            assert conv_hip.saturation_count() == sat2, it
+        sat2 = conv_hip.saturation_count()
 
 
 def _relu_margin(net64, x64):
