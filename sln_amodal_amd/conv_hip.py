@@ -43,18 +43,19 @@ _cache = _NoCache()   # kept for tools that call _cache.clear(); caches live on 
 
 # ------------------------------------------------------------------ per-tensor scales (PARTS = 2)
 SCALE_TARGET_LOG2 = 11      # max|v| * s lands in [2^10, 2^11): 2^5 of head room below fp16's 65504
-SCALE_HISTORY_DECAY = 0.5   # the assumed maximum shrinks by at most this factor per step (grows at once)
+SCALE_WINDOW = 16           # the scale follows the maximum over this many recent steps of the tensor
 
 
 class _Slot(object):
     """One tensor role of one layer: views of its device-side scale / running amax."""
-    __slots__ = ("scale", "amax", "hist", "fresh", "book")
+    __slots__ = ("scale", "amax", "hist", "cursor", "fresh", "book")
 
     def __init__(self, book, idx):
         self.book = book
         self.scale = book.scale[idx:idx + 1]
         self.amax = book.amax[idx:idx + 1]
-        self.hist = book.hist[idx:idx + 1]
+        self.hist = book.hist[0, idx:idx + 1]      # column idx of the ring (row stride = capacity)
+        self.cursor = book.cursor[idx:idx + 1]
         self.fresh = True            # no scale yet: the first producer bootstraps it from an amax pass
 
 
@@ -63,7 +64,8 @@ class ScaleBook(object):
         self.device = device
         self.amax = torch.zeros(capacity, dtype=torch.float32, device=device)
         self.scale = torch.ones(capacity, dtype=torch.float32, device=device)
-        self.hist = torch.zeros(capacity, dtype=torch.float32, device=device)     # decaying running maximum
+        self.hist = torch.zeros((SCALE_WINDOW, capacity), dtype=torch.float32, device=device)   # ring of maxima
+        self.cursor = torch.zeros(capacity, dtype=torch.int32, device=device)
         self.saturated = torch.zeros(1, dtype=torch.int32, device=device)
         self.n = 0
         self.names = []              # (role key, owner shape) per slot: diagnostics (tools/sat_probe.py)
@@ -84,13 +86,14 @@ class ScaleBook(object):
             if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
                 dist.all_reduce(self.amax[:self.n], op=dist.ReduceOp.MAX)
             _lib.check(_lib.lib().sln_scale_update_f32(ops._ptr(self.amax), ops._ptr(self.scale), ops._ptr(self.hist),
-                                                       self.n, SCALE_TARGET_LOG2, SCALE_HISTORY_DECAY, ops._stream()),
-                       "sln_scale_update_f32")
+                                                       ops._ptr(self.cursor), self.n, self.hist.shape[1], SCALE_WINDOW,
+                                                       SCALE_TARGET_LOG2, ops._stream()), "sln_scale_update_f32")
 
     def settle(self, slot):
         """Bootstrap: slot.amax holds an exact amax pass -> its scale; clears the fresh flag."""
-        _lib.check(_lib.lib().sln_scale_update_f32(ops._ptr(slot.amax), ops._ptr(slot.scale), ops._ptr(slot.hist), 1,
-                                                   SCALE_TARGET_LOG2, 0.0, ops._stream()), "sln_scale_update_f32")
+        _lib.check(_lib.lib().sln_scale_update_f32(ops._ptr(slot.amax), ops._ptr(slot.scale), ops._ptr(slot.hist),
+                                                   ops._ptr(slot.cursor), 1, slot.book.hist.shape[1], SCALE_WINDOW,
+                                                   SCALE_TARGET_LOG2, ops._stream()), "sln_scale_update_f32")
         slot.fresh = False
 
 

@@ -51,7 +51,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 //          h0 = fp16_rne(v*s),  h1 = fp16_rne(v*s - h0)          (22 significant bits)
 //        and three part products a0*b0 + a0*b1 + a1*b0 on v_mfma_f32_32x32x16_f16; the dropped
 //        a1*b1 term is 2^-22 relative.  fp16's narrow exponent needs the scale: s is chosen so that
-//        max|v|*s sits near 2^11 (sln_scale_update_f32, from a decaying running maximum), which leaves 2^5 of head room before
+//        max|v|*s sits near 2^11 (sln_scale_update_f32, from the maximum over a window of recent steps), which leaves 2^5 of head room before
 //        +-65504 and keeps every element down to max|v| * 2^-14 at full 22-bit precision (smaller
 //        ones degrade gracefully: absolute error <= max|v| * 2^-36).  The scale of a tensor that a
 //        conv epilogue writes is not known before that conv has run, so s comes from the amax the
@@ -523,20 +523,21 @@ __global__ __launch_bounds__(256) void split_weights_kernel(const float *__restr
 // scale[i] <- the power of two that puts amax[i] near 2^target_log2 (amax[i] == 0: unchanged);
 // amax[i] <- 0.  One launch per step over every tensor slot (delayed scaling).
 __global__ __launch_bounds__(256) void scale_update_kernel(float *__restrict__ amax, float *__restrict__ scale,
-                                                           float *__restrict__ hist, int n, int target_log2,
-                                                           float decay) {
+                                                           float *__restrict__ hist, int32_t *__restrict__ cursor,
+                                                           int n, long stride, int window, int target_log2) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     float a = amax[i];
     if (hist && a > 0.f && a < INFINITY) {
-        // running maximum with a half-life: the range grows at once and shrinks by `decay` per step in which
-        // the tensor was produced, so a tensor whose maximum comes and goes with the batch (the RPN
-        // class-logit gradient of a pyramid level without positives: x230 between two steps) keeps the
-        // range of its recent spikes.  (No cap relative to the present maximum: such tensors do record
-        // maxima of 1e-17 in between, and a cap of 256x made the next ordinary step clamp everything.)
-        const float h = hist[i] * decay;
-        if (h > a) a = h;
-        hist[i] = a;
+        // The scale follows the maximum over the last `window` steps in which the tensor was produced: the
+        // range grows at once, a maximum that comes and goes with the batch is kept (the RPN class-logit
+        // gradient of a pyramid level whose anchors were not drawn this time is ~1e-13, x230 ... x1e10 below
+        // the next step's), and a tensor that really shrank is followed exactly, `window` steps later.
+        int c = cursor[i];
+        c = (c < 0 || c >= window) ? 0 : c;
+        hist[(long)c * stride + i] = a;
+        cursor[i] = c + 1 == window ? 0 : c + 1;
+        for (int k = 0; k < window; ++k) a = fmaxf(a, hist[(long)k * stride + i]);
     }
     if (a > 0.f && a < INFINITY) {
         int e;
@@ -2283,14 +2284,15 @@ extern "C" int sln_conv_grad_prep_f32(const float *gy, const float *y, const flo
     return sln_launch_status();
 }
 
-extern "C" int sln_scale_update_f32(float *amax, float *scale, float *history, int n, int target_log2,
-                                    float decay, sln_stream_t stream) {
+extern "C" int sln_scale_update_f32(float *amax, float *scale, float *history, int32_t *cursor, int n,
+                                    int64_t history_stride, int window, int target_log2, sln_stream_t stream) {
     sln_enter();
-    if (n < 0 || target_log2 < -14 || target_log2 > 15 || !(decay >= 0.f && decay <= 1.f)) return SLN_ERR_INVALID_ARG;
+    if (n < 0 || target_log2 < -14 || target_log2 > 15) return SLN_ERR_INVALID_ARG;
+    if (history && (!cursor || window < 1 || window > 1024 || history_stride < n)) return SLN_ERR_INVALID_ARG;
     if (n == 0) return SLN_OK;
     if (!amax || !scale) return SLN_ERR_INVALID_ARG;
     hipLaunchKernelGGL(scale_update_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, amax, scale,
-                       history, n, target_log2, decay);
+                       history, cursor, n, (long)history_stride, window, target_log2);
     return sln_launch_status();
 }
 

@@ -512,11 +512,11 @@ def test_two_part_fp16_delayed_scale_tracks_growth_and_saturates_without_inf():
         if e < 5e-6 and conv_hip.saturation_count() == sat1:
             break
     assert it <= 2 and e < 5e-6, (it, e)
-    # Shrinking: the assumed maximum halves per produced step (it never follows a drop at once: tensors
-    # whose maximum comes and goes with the batch would clamp on its return).  A tensor 100x smaller than
-    # its recent maximum keeps its accuracy -- its values sit 7 binades lower in a 19-binade window; a
-    # collapse by many orders of magnitude is followed at one binade per step (a stated limit).
-    for _ in range(16):                         # let the running maxima come down from the 8000x episode
+    # Shrinking: the scale follows the maximum over the last 16 steps in which the tensor was produced (it
+    # never follows a drop at once: tensors whose maximum comes and goes with the batch would clamp on its
+    # return), so a real drop is followed exactly, 16 steps later.  Meanwhile a tensor 100x below its recent
+    # maximum keeps its accuracy -- its values sit 7 binades lower in a 19-binade window.
+    for _ in range(17):                         # the 8000x episode leaves the window
         conv_hip.update_scales()
         two_layers(x0)
     e, _ = two_layers(x0)
@@ -532,7 +532,7 @@ def test_two_part_fp16_delayed_scale_tracks_growth_and_saturates_without_inf():
         conv_hip.update_scales()
         two_layers(x0)
     # a maximum that comes and goes with the batch (x200 up and down every step, like the RPN class-logit
-    # gradient of a pyramid level without positives) is covered by the decaying running maximum
+    # gradient of a pyramid level without positives) is covered by the window maximum
     for _ in range(3):
         conv_hip.update_scales()
         two_layers(x0)

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
 
-def main(steps=10, batch=16, dim=1024, arch="resnet101"):
+def main(steps=60, batch=16, dim=1024, arch="resnet101"):
     from sln_amodal_amd import conv_hip, synthetic
     from sln_amodal_amd.config import Config
     from sln_amodal_amd.model import LAYER_REGEX, MaskRCNN
