@@ -85,6 +85,26 @@ def dominant_kernel_roofline(prof, elapsed, parts):
     secs, flops, n, rd_b, wr_b = by[name]
     ach = flops / secs / 1e12
     mult = 6 if parts == 3 else 3
+    # the same launches split by which roof bounds them: machine balance = MFMA peak / HBM peak in part-product
+    # FLOPs per algorithmic byte (every operand read once, every output written once)
+    balance = PEAK_BF16_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
+    sub = {"mfma": [0.0, 0.0, 0.0, 0], "hbm": [0.0, 0.0, 0.0, 0]}
+    for e0, e1, fl, nm, _shape, rd, wr in prof:
+        if nm != name:
+            continue
+        k = "mfma" if (rd + wr) <= 0 or fl * mult / (rd + wr) >= balance else "hbm"
+        sub[k][0] += e0.elapsed_time(e1) * 1e-3
+        sub[k][1] += fl
+        sub[k][2] += rd + wr
+        sub[k][3] += 1
+    by_bound = {}
+    for k, (t_, f_, b_, c_) in sub.items():
+        if c_:
+            by_bound[k + "_bound_launches"] = {
+                "launches": c_, "share_of_step_time": round(t_ / elapsed, 4),
+                "tflops": round(f_ / t_ / 1e12, 1), "frac_of_mfma_roofline": round(f_ / t_ / 1e12 / split_peak(parts), 4),
+                "algorithmic_tb_per_s": round(b_ / t_ / 1e12, 2),
+                "frac_of_hbm_peak": round(b_ / t_ / 1e9 / PEAK_HBM_GBS, 4)}
     traffic = None
     try:   # HBM bytes per launch from the committed rocprofv3 PMC passes (not collectable live)
         pmc = json.load(open(os.path.join(ROOT, PMC_TRAFFIC)))[name]["last_step"]
@@ -110,6 +130,7 @@ def dominant_kernel_roofline(prof, elapsed, parts):
             "share_of_step_time": round(secs / elapsed, 4),
             "bf16_mfma_tflops": round(ach * mult, 1), "bf16_mfma_peak": 2500.0,
             "bf16_mfma_frac": round(ach * mult / 2500.0, 4),
+            "by_bound": by_bound,
             "other_kernels": {k: dict({"tflops": round(v[1] / v[0] / 1e12, 2), "launches": v[2],
                                        "share_of_step_time": round(v[0] / elapsed, 4),
                                        "frac": round(v[1] / v[0] / 1e12 / peak, 4),
