@@ -37,8 +37,8 @@ for (name, N, Cin, H, Cout, k, use_res) in LAYERS:
     f(); f()
     row = []
     for rep in range(2):
-        for dbg in ("16", "0"):
+        for dbg in (sys.argv[1:] or ["16", "0"]):
             os.environ["SLN_CONV_DBG"] = dbg
             t = timeit(f)
-            row.append("%s %.3f ms %4.0f TF" % ("general" if dbg == "16" else "fixed  ", t, fl / t / 1e9))
+            row.append("%s %.3f ms %4.0f TF" % ({"16": "general", "0": "fixed  ", "32": "no-ahead"}.get(dbg, dbg), t, fl / t / 1e9))
     print("%-40s | %s" % (name, " | ".join(row)))
