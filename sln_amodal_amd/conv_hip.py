@@ -47,11 +47,19 @@ SCALE_WINDOW = 16           # the scale follows the maximum over this many recen
 
 
 class _Slot(object):
-    """One tensor role of one layer: views of its device-side scale / running amax."""
-    __slots__ = ("scale", "amax", "hist", "cursor", "fresh", "book")
+    """One tensor role of one layer: views of its device-side scale / running amax.  The table entry goes
+    back to the book when the slot dies (with its layer)."""
+    __slots__ = ("scale", "amax", "hist", "cursor", "fresh", "book", "idx")
+
+    def __del__(self):
+        try:
+            self.book.free.append(self.idx)
+        except Exception:
+            pass
 
     def __init__(self, book, idx):
         self.book = book
+        self.idx = idx
         self.scale = book.scale[idx:idx + 1]
         self.amax = book.amax[idx:idx + 1]
         self.hist = book.hist[0, idx:idx + 1]      # column idx of the ring (row stride = capacity)
@@ -68,9 +76,22 @@ class ScaleBook(object):
         self.cursor = torch.zeros(capacity, dtype=torch.int32, device=device)
         self.saturated = torch.zeros(1, dtype=torch.int32, device=device)
         self.n = 0
-        self.names = []              # (role key, owner shape) per slot: diagnostics (tools/sat_probe.py)
+        self.free = []               # indices of dead slots
+        self.names = {}              # slot index -> (role key, owner shape): diagnostics (tools/sat_probe.py)
 
     def new_slot(self):
+        if self.free:                        # an entry whose layer has died: back to the initial state
+            idx = self.free.pop()
+            tables = [self.amax, self.scale, self.hist, self.cursor]
+            versions = [t._version for t in tables]
+            self.amax[idx] = 0.0
+            self.scale[idx] = 1.0
+            self.hist[:, idx] = 0.0
+            self.cursor[idx] = 0
+            # (the tables are only ever written by kernels; autograd has saved views of `scale` whose version
+            # check must not trip over the reset of an unrelated, dead entry)
+            torch._C._autograd._unsafe_set_version_counter(tables, versions)
+            return _Slot(self, idx)
         if self.n >= self.amax.numel():
             raise RuntimeError("ScaleBook is full (%d tensor slots)" % self.n)
         self.n += 1
@@ -130,7 +151,7 @@ def _slot(owner, key):
     sl = slots.get(key)
     if sl is None:
         sl = slots[key] = book(owner.device).new_slot()
-        sl.book.names.append((key, tuple(owner.shape)))
+        sl.book.names[sl.idx] = (key, tuple(owner.shape))
     return sl
 
 

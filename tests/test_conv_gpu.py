@@ -808,3 +808,28 @@ def test_folded_bias_shift_refreshes_all_layers_together():
     assert conv_hip.FOLD_STATS[0] == before[0] + 1 and conv_hip.FOLD_STATS[1] >= before[1] + len(layers)
     for (b, s, h), f in zip(layers, second):
         assert torch.equal(f, b.detach() * s + h)
+
+
+def test_scale_slots_are_recycled_when_layers_die():
+    """Per-tensor scale slots live on their layer's weight: a process that builds many models (this suite)
+    must not run the 32 k-entry table full."""
+    import gc
+    from sln_amodal_amd import conv_hip
+    x = torch.randn(1, 16, 8, 8, device="cuda").contiguous(memory_format=torch.channels_last)
+
+    def once():
+        w = torch.randn(16, 16, 3, 3, device="cuda")
+        conv_hip._ConvFn.apply(x.clone(), w, None, None, None, None, False, (1, 1), (1, 1), (1, 1, 1, 1))
+
+    once()
+    gc.collect()
+    book = conv_hip.book(x.device)
+    n0 = book.n
+    for _ in range(50):
+        once()
+    gc.collect()
+    assert book.n <= n0 + 8, (n0, book.n)
+    y = conv_hip._ConvFn.apply(x, torch.ones(16, 16, 3, 3, device="cuda"), None, None, None, None, False, (1, 1), (1, 1),
+                               (1, 1, 1, 1))
+    ref = F.conv2d(x.double(), torch.ones(16, 16, 3, 3, device="cuda").double(), None, 1, 1)
+    assert (y.double() - ref).abs().max().item() / ref.abs().max().item() < 5e-6      # a recycled slot starts fresh
