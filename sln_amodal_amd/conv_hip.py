@@ -401,8 +401,10 @@ class MultiScale(object):
         return self.parts, getattr(self, "q", None)
 
 
-def conv_bn_act_ms(x, conv, bn, relu, residual, pads):
-    """conv (+bias) -> frozen-BN affine -> (+residual) -> ReLU on a MultiScale, one launch."""
+def conv_bn_act_ms(x, conv, bn, relu, residual, pads, parts_only=False):
+    """conv (+bias) -> frozen-BN affine -> (+residual) -> ReLU on a MultiScale, one launch.
+    parts_only: the output is read by convolutions only (the GLM bottlenecks' reduce / 3x3 layers: forward
+    only, no ReLU mask to keep) -- its fp32 copy is not written, the result carries the parts alone."""
     import ctypes as C
     from .nn_ops import bn_affine
     if torch.is_grad_enabled() and (conv.weight.requires_grad or
@@ -430,13 +432,15 @@ def conv_bn_act_ms(x, conv, bn, relu, residual, pads):
     xp, xq = x.get_parts(parts, owner=conv.weight)
     layout = weights_layout(M, Co, xp.shape[2], KH * KW, parts, xp.shape[1])
     wp, wq = _split_weights(conv.weight, parts=parts, layout=layout)
-    y = torch.empty((M, Co), dtype=torch.float32, device=x.y.device)
+    dev = xp.device
     yslot = _slot(conv.weight, ("y_ms",) + tuple(osegs)) if parts == 2 else None
     fresh = yslot is not None and yslot.fresh
     yp = None
     if not fresh:
         alloc = torch.empty if Co % 8 == 0 else torch.zeros
-        yp = alloc((parts, M, _pad8(Co)), dtype=torch.bfloat16, device=x.y.device)
+        yp = alloc((parts, M, _pad8(Co)), dtype=torch.bfloat16, device=dev)
+    # (a fresh slot bootstraps its scale from the fp32 output: that one time it is written)
+    y = None if (parts_only and yp is not None) else torch.empty((M, Co), dtype=torch.float32, device=dev)
     seg = (C.c_int32 * (3 * len(x.segs)))(*[v for s_ in x.segs for v in s_])
     res = residual.y if residual is not None else None
     if res is not None and tuple(res.shape) != (M, Co):

@@ -24,9 +24,10 @@ class _ConvBnReLU(nn.Sequential):
         if relu:
             self.add_module("relu", nn.ReLU())
 
-    def forward(self, x, residual=None, relu=None):
+    def forward(self, x, residual=None, relu=None, parts_only=False):
         return nn_ops.conv_bn_act(x, self.conv, self.bn,
-                                  relu=self.has_relu if relu is None else relu, residual=residual)
+                                  relu=self.has_relu if relu is None else relu, residual=residual,
+                                  parts_only=parts_only)
 
 
 class _Bottleneck(nn.Module):
@@ -42,7 +43,9 @@ class _Bottleneck(nn.Module):
 
     def forward(self, x):
         sc = self.shortcut(x) if self.has_shortcut else x
-        h = self.conv3x3(self.reduce(x))
+        # reduce and the 3x3 feed one convolution each and nothing else (frozen net: no ReLU mask to keep):
+        # on the packed HIP path their fp32 copies are not written
+        h = self.conv3x3(self.reduce(x, parts_only=True), parts_only=True)
         return self.increase(h, residual=sc, relu=True)  # relu(increase(h) + shortcut)
 
 

@@ -19,6 +19,7 @@ import torch
 import torch.nn.functional as F
 
 BACKEND = "auto"  # "auto" | "hip" | "torch"
+PARTS_ONLY = os.environ.get("SLN_PARTS_ONLY", "1") != "0"   # A/B switch of conv_bn_act(parts_only=True)
 CALIBRATING = None   # [count] while synthetic._calibrate runs: conv_bn_act refreshes each frozen BN's statistics
 
 
@@ -67,14 +68,15 @@ def bn_affine(bn):
 
 
 def conv_bn_act(x, conv, bn=None, relu=False, residual=None, same=False, link=None, chain_in=None,
-                chain_out=None):
+                chain_out=None, parts_only=False):
     """x [B,C,H,W] (any memory format; channels-last preferred).
     conv: nn.Conv2d parameter holder (weight, bias, stride, padding, dilation).
     bn:   frozen nn.BatchNorm2d or None.  same: apply SamePad2d first.
     link: dict shared by the two convs of an identity-shortcut block that see the same x
           (one as input, one as residual); HIP backend only, see conv_hip._ConvFn.
     chain_out / chain_in: dict shared by a conv (chain_out) and the ONLY conv that reads its
-          output (chain_in): lets the reader's backward prepare this layer's gradient."""
+          output (chain_in): lets the reader's backward prepare this layer's gradient.
+    parts_only: (packed, forward-only GLM scales) the output feeds convolutions only: no fp32 copy."""
     if CALIBRATING is not None and bn is not None:
         # statistics pass (synthetic.calibrate_*): the raw convolution on the same backend, its output's
         # statistics into the frozen BN, then the un-fused normalisation / shortcut / ReLU
@@ -97,7 +99,8 @@ def conv_bn_act(x, conv, bn=None, relu=False, residual=None, same=False, link=No
         pl = pr = conv.padding[1]
     hip = _hip_conv() if BACKEND in ("auto", "hip") else None
     if hip is not None and isinstance(x, hip.MultiScale):   # all GLM scales in one launch
-        return hip.conv_bn_act_ms(x, conv, bn, relu, residual, (pt, pb, pl, pr))
+        return hip.conv_bn_act_ms(x, conv, bn, relu, residual, (pt, pb, pl, pr),
+                                  parts_only=parts_only and PARTS_ONLY)
     if hip is not None and x.is_cuda and hip.supports(conv, x):
         if kh * kw > 1 and (kh, kw) == tuple(x.shape[2:]) and (pt, pb, pl, pr) == (0, 0, 0, 0) and \
                 residual is None and x.shape[1] % 8 == 0:
