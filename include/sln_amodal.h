@@ -390,13 +390,15 @@ int sln_conv_fwd_tile(int64_t M, int Cout, int64_t K, int parts);
 int sln_conv_wgrad_tile(int64_t M, int Cout, int Cin, int taps, int parts);
 /* workspace (optional): sln_conv_wgrad_workspace_bytes() bytes lent by the caller make the split-K
  * sum two-phase -- every pixel range stores its partial gradient, a second kernel adds the ranges in
- * order: bit-reproducible, no atomics.  NULL: fp32 atomics (summation order not deterministic). */
+ * order: bit-reproducible, no atomics.  NULL: fp32 atomics (summation order not deterministic).
+ * gw_layout 0: gw [Cout][KH][KW][Cin]; 1: gw [Cout][Cin][KH][KW], the parameter's own order (written by the
+ * reduce pass: needs the workspace), so that no layout copy stands between the kernel and the optimiser. */
 size_t sln_conv_wgrad_workspace_bytes(int64_t M, int Cout, int Cin, int taps, int parts);
 int sln_conv2d_wgrad_f32(const uint16_t *gz_parts, int Cout, int Cout_pad, const uint16_t *x_parts,
                          int N, int H, int W, int Cin, int Cin_pad, int parts, int KH, int KW,
                          int stride_h, int stride_w, int dil_h, int dil_w, int pad_top, int pad_left,
                          int OH, int OW, float *gw, const float *gz_scale, const float *x_scale,
-                         void *workspace, size_t workspace_bytes, sln_stream_t stream);
+                         void *workspace, size_t workspace_bytes, int gw_layout, sln_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -730,23 +730,28 @@ class _ConvFn(torch.autograd.Function):
             else:
                 raise NotImplementedError("data gradient of a strided %dx%d conv" % (KH, KW))
         if need_w:
-            gw_t = torch.empty((Co, KH, KW, Ci), dtype=torch.float32, device=weight.device)
             ws, ws_bytes = None, 0
             if DETERMINISTIC_WGRAD:     # two-phase split-K through a lent workspace: no atomics
                 ws_bytes = _lib.lib().sln_conv_wgrad_workspace_bytes(N * OH * OW, Co, Ci, KH * KW, parts)
                 ws = ops._workspace(max(ws_bytes, 16), weight.device)
+            # with the workspace the reduce pass writes the parameter's own [Co,Ci,KH,KW] order (no layout
+            # copy in AccumulateGrad); the atomic path produces [Co,KH,KW,Ci]
+            own_layout = ws is not None
+            gw_t = torch.empty((Co, Ci, KH, KW) if own_layout else (Co, KH, KW, Ci), dtype=torch.float32,
+                               device=weight.device)
             e0 = _prof_begin()
             _lib.check(_lib.lib().sln_conv2d_wgrad_f32(
                 ops._ptr(gz), Co, gz.shape[2], ops._ptr(xp), N, H, W, Ci, xp.shape[2], parts, KH, KW,
                 stride[0], stride[1], dil[0], dil[1], pt, pl, OH, OW, ops._ptr(gw_t), ops._ptr(gzq),
-                ops._ptr(xq), ops._ptr(ws), ws_bytes, ops._stream()), "sln_conv2d_wgrad_f32")
+                ops._ptr(xq), ops._ptr(ws), ws_bytes, 1 if own_layout else 0, ops._stream()),
+                "sln_conv2d_wgrad_f32")
             wt_ = _lib.lib().sln_conv_wgrad_tile(N * OH * OW, Co, Ci, KH * KW, parts) if e0 is not None else 128
             _prof_end(e0, 2.0 * N * OH * OW * Co * KH * KW * Ci,
                       ("conv_wgrad256h_kernel" if (wt_ == 256 and parts == 2) else
                        ("conv_wgrad256_kernel<%d>" if wt_ == 256 else "conv_wgrad_kernel<%d>") % parts),
                       "wgrad N%d %dx%d C%d->%d k%d s%d d%d" % (N, H, W, Ci, Co, KH, stride[0], dil[0]),
                       _nbytes(gz, xp), _nbytes(gw_t))
-            gw = gw_t.permute(0, 3, 1, 2)  # logical [Co,Ci,KH,KW]
+            gw = gw_t if own_layout else gw_t.permute(0, 3, 1, 2)  # logical [Co,Ci,KH,KW]
         return gx, gw, g_bias, None, None, g_res, None, None, None, None, None, None, None, None
 
 
@@ -835,7 +840,7 @@ class _StemFn(torch.autograd.Function):
             e0 = _prof_begin()
             _lib.check(_lib.lib().sln_conv2d_wgrad_f32(
                 ops._ptr(gz), Co, gz.shape[2], ops._ptr(xp), N, OH, OW, Kp, Kp, parts, 1, 1, 1, 1, 1, 1, 0, 0,
-                OH, OW, ops._ptr(gw_t), ops._ptr(gzq), ops._ptr(xq), ops._ptr(ws), ws_bytes, ops._stream()),
+                OH, OW, ops._ptr(gw_t), ops._ptr(gzq), ops._ptr(xq), ops._ptr(ws), ws_bytes, 0, ops._stream()),
                 "sln_conv2d_wgrad_f32")
             _prof_end(e0, 2.0 * N * OH * OW * Co * K, "conv_wgrad_kernel<%d>" % parts,
                       "wgrad stem N%d %dx%d K%d->%d" % (N, OH, OW, K, Co), _nbytes(gz, xp), _nbytes(gw_t))

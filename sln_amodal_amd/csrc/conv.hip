@@ -2043,8 +2043,11 @@ __global__ __launch_bounds__(512) void conv_wgrad256h_kernel(const WgradParams p
 // Second phase of the split-K weight gradient: gw[e] = sum over the pixel ranges, in range order --
 // the same sum on every run (fp32 atomics arrive in any order), and plain stores instead of ~8 GB of
 // atomic traffic per step.  One thread per 4 elements when the count allows.
+// taps > 0: gw is written in the parameter's own [Cout][Cin][KH][KW] order (element (co, tap, ci) of the
+// slabs' [Cout][taps][Cin] order goes to (co*Cin + ci)*taps + tap): autograd then accumulates it as it is,
+// without the layout copy a permuted view costs per weight and step.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ partial, int ksplit,
-                                                           long n, float *__restrict__ gw) {
+                                                           long n, float *__restrict__ gw, int taps, int Cin) {
     // 32 element quads x 8 range lanes per block: lane kl adds the ranges kl, kl+8, ... in order, the
     // eight sums are then added in lane order -- a fixed summation tree, whatever the launch timing
     __shared__ float4 s_part[8][32];
@@ -2085,7 +2088,17 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
             const float4 b = s_part[k][q];
             r.x += b.x; r.y += b.y; r.z += b.z; r.w += b.w;
         }
-        if (i4 + 3 < n) *(float4 *)(gw + i4) = r;
+        if (taps > 1) {
+            const float t4[4] = {r.x, r.y, r.z, r.w};
+            for (int e = 0; e < 4 && i4 + e < n; ++e) {
+                const long i = i4 + e;
+                const long row = i / Cin;                    // co * taps + tap
+                const int ci = (int)(i - row * Cin);
+                const long co = row / taps;
+                const int tap = (int)(row - co * taps);
+                gw[(co * Cin + ci) * taps + tap] = t4[e];
+            }
+        } else if (i4 + 3 < n) *(float4 *)(gw + i4) = r;
         else {
             const float t4[4] = {r.x, r.y, r.z, r.w};
             for (int e = 0; e < 4 && i4 + e < n; ++e) gw[i4 + e] = t4[e];
@@ -2444,7 +2457,8 @@ extern "C" int sln_conv_wgrad_tile(int64_t M, int Cout, int Cin, int taps, int p
 extern "C" size_t sln_conv_wgrad_workspace_bytes(int64_t M, int Cout, int Cin, int taps, int parts) {
     if (M < 1 || Cout < 1 || Cin < 1 || taps < 1) return 0;
     const WgradPlan w = wgrad_plan(M, Cout, Cin, taps, parts);
-    return w.ksplit > 1 ? sizeof(float) * (size_t)w.ksplit * Cout * taps * Cin : 0;
+    // (one slab even for a single pixel range: gw_layout 1 goes through the reduce pass)
+    return sizeof(float) * (size_t)w.ksplit * Cout * taps * Cin;
 }
 
 extern "C" int sln_conv2d_wgrad_f32(const uint16_t *gz_parts, int Cout, int Cout_pad,
@@ -2452,8 +2466,9 @@ extern "C" int sln_conv2d_wgrad_f32(const uint16_t *gz_parts, int Cout, int Cout
                                     int parts, int KH, int KW, int stride_h, int stride_w, int dil_h,
                                     int dil_w, int pad_top, int pad_left, int OH, int OW, float *gw,
                                     const float *gz_scale, const float *x_scale, void *workspace,
-                                    size_t workspace_bytes, sln_stream_t stream) {
+                                    size_t workspace_bytes, int gw_layout, sln_stream_t stream) {
     sln_enter();
+    if (gw_layout != 0 && gw_layout != 1) return SLN_ERR_INVALID_ARG;
     if (!gz_parts || !x_parts || !gw || N < 0 || H < 1 || W < 1 || Cin < 1 || Cout < 1 || KH < 1 || KW < 1 ||
         OH < 1 || OW < 1 || Cin_pad < Cin || Cout_pad < Cout || (Cin_pad & 7) || (Cout_pad & 7))
         return SLN_ERR_INVALID_ARG;
@@ -2465,10 +2480,14 @@ extern "C" int sln_conv2d_wgrad_f32(const uint16_t *gz_parts, int Cout, int Cout
     if (M > 2147483647L - BK) return SLN_ERR_UNSUPPORTED;
     const WgradPlan w = wgrad_plan(M, Cout, Cin, KH * KW, parts);
     // two-phase (deterministic) when the caller lends a workspace; fp32 atomics into the zeroed gw else
-    const size_t need = w.ksplit > 1 ? sizeof(float) * (size_t)w.ksplit * gw_elems : 0;
-    const bool two_phase = workspace != nullptr && w.ksplit > 1;
+    // gw_layout 1 ([Cout][Cin][KH][KW], the parameter's own order) is produced by the reduce pass: it needs the
+    // workspace even for a single pixel range (1x1 kernels: the two orders coincide)
+    const bool transpose = gw_layout == 1 && KH * KW > 1;
+    if (transpose && !workspace) return SLN_ERR_WORKSPACE;
+    const size_t need = (w.ksplit > 1 || transpose) ? sizeof(float) * (size_t)w.ksplit * gw_elems : 0;
+    const bool two_phase = workspace != nullptr && (w.ksplit > 1 || transpose);
     if (two_phase && workspace_bytes < need) return SLN_ERR_WORKSPACE;
-    const bool direct = w.ksplit == 1 && workspace != nullptr;     // a single pixel range: plain stores into gw
+    const bool direct = w.ksplit == 1 && workspace != nullptr && !transpose;   // a single pixel range: plain stores into gw
     if (!two_phase && !direct &&
         hipMemsetAsync(gw, 0, sizeof(float) * gw_elems, st) != hipSuccess)
         return SLN_ERR_LAUNCH;
@@ -2511,6 +2530,6 @@ extern "C" int sln_conv2d_wgrad_f32(const uint16_t *gz_parts, int Cout, int Cout
     }
     if (two_phase)
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((gw_elems + 127) / 128)), dim3(256), 0, st,
-                           (const float *)workspace, w.ksplit, (long)gw_elems, gw);
+                           (const float *)workspace, w.ksplit, (long)gw_elems, gw, transpose ? KH * KW : 0, Cin);
     return sln_launch_status();
 }

@@ -60,7 +60,7 @@ for parts in (2, 3):
         gw = torch.empty((Cout, k, k, Cin), device="cuda")
         t_wg = timeit(lambda: conv_hip._lib.check(conv_hip._lib.lib().sln_conv2d_wgrad_f32(
             conv_hip.ops._ptr(gz), Cout, gz.shape[2], conv_hip.ops._ptr(xp), N, H, W, Cin, xp.shape[2], parts, k, k,
-            s, s, d, d, pad, pad, OH, OH, conv_hip.ops._ptr(gw), conv_hip.ops._ptr(gzq), conv_hip.ops._ptr(xq), None, 0,
+            s, s, d, d, pad, pad, OH, OH, conv_hip.ops._ptr(gw), conv_hip.ops._ptr(gzq), conv_hip.ops._ptr(xq), None, 0, 0,
             conv_hip.ops._stream()), "w"))
         t_wref = timeit(lambda: torch.ops.aten.convolution_backward(gy, x, wcl, None, [s, s], [pad, pad], [d, d], False, [0, 0], 1, [False, True, False]))
         print("%-28s fwd hip %6.3f ms %5.0f TF (split %5.3f) aten %6.3f ms %5.0f TF x%.2f | wgrad hip %6.3f %5.0f TF aten %6.3f %5.0f TF x%.2f" %
