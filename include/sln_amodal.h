@@ -350,6 +350,23 @@ int sln_debug_read_stamps(uint64_t *out128);
 /* The layout a forward call must pass: M output pixels, Cout, Cin (padded, as in x_parts), taps =
  * KH*KW, parts, and x_pixels = the number of input pixels (rows of x_parts). */
 int sln_conv_fwd_weights_layout(int64_t M, int Cout, int Cin, int taps, int parts, int64_t x_pixels);
+/* One entry of sln_conv_split_weights_batch_f32's device-resident table: the arguments of one
+ * sln_conv_split_weights_f32 call with parts = 2 (total = elements of one part in the chosen layout:
+ * O*KH*KW*I_pad for ROWS, sln_conv_tiled_weight_elems() otherwise). */
+typedef struct {
+    const float *w;
+    uint16_t *out;
+    const float *q_scale;
+    float *q_amax;
+    int32_t *q_saturated;
+    int64_t s_o, s_i, s_kh, s_kw, total;
+    int32_t O, I, Ip, KH, KW, flip, layout, reserved;
+} sln_split_desc_t;
+/* Every stale weight tensor of a step in one launch (parts = 2): chunk b covers elements
+ * [chunk_first[b], chunk_first[b] + chunk_elems) of entry chunk_entry[b]; all three arrays in device memory. */
+int sln_conv_split_weights_batch_f32(const sln_split_desc_t *descs, const int32_t *chunk_entry,
+                                     const int64_t *chunk_first, int n_chunks, int chunk_elems,
+                                     sln_stream_t stream);
 int sln_conv_split_weights_f32(const float *w, int O, int I, int I_pad, int KH, int KW, long s_o,
                                long s_i, long s_kh, long s_kw, int flip, int parts, int layout,
                                uint16_t *out, const float *q_scale, float *q_amax,

@@ -46,6 +46,7 @@ SIGNATURES = {
     "sln_conv_tiled_weight_elems": (C.c_int64, [_i, _i, _i, _i, _i]),
     "sln_conv_fwd_weights_layout": (_i, [C.c_int64, _i, _i, _i, _i, C.c_int64]),
     "sln_debug_read_stamps": (_i, [_p]),
+    "sln_conv_split_weights_batch_f32": (_i, [_p, _p, _p, _i, _i, _p]),
     "sln_conv_split_weights_f32": (_i, [_p, _i, _i, _i, _i, _i, C.c_long, C.c_long, C.c_long,
                                         C.c_long, _i, _i, _i, _p, _p, _p, _p, _p]),
     "sln_act_split_f32": (_i, [_p, C.c_int64, _i, _i, _i, _p, _p, _p, _p, _p]),

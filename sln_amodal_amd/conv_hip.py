@@ -16,6 +16,7 @@ slot is used it is bootstrapped exactly (an amax pass, then the split).
 """
 import os
 
+import numpy as np
 import torch
 
 from . import _lib, ops
@@ -198,6 +199,12 @@ def _split_weights(weight, flip_swap=False, parts=None, owner=None, layout=ROWS)
     hit = cache.get((flip_swap, parts, layout))
     if hit is not None and hit[0] == weight._version:
         return hit[1], hit[2]
+    if hit is not None and parts == 2 and BATCH_WEIGHT_SPLITS and (id(weight), flip_swap, layout) in _WSPLIT:
+        # stale (the optimiser stepped): every stale registered entry is refreshed in one launch
+        _refresh_weight_parts(weight.device)
+        hit = cache.get((flip_swap, parts, layout))
+        if hit is not None and hit[0] == weight._version:
+            return hit[1], hit[2]
     w = weight.detach()
     Co, Ci, KH, KW = w.shape
     s = w.stride()
@@ -223,7 +230,78 @@ def _split_weights(weight, flip_swap=False, parts=None, owner=None, layout=ROWS)
     launch(out)
     q = slot.scale if slot is not None else None
     cache[(flip_swap, parts, layout)] = (weight._version, out, q)
+    if parts == 2 and BATCH_WEIGHT_SPLITS and weight.requires_grad and weight.is_leaf:   # (Parameters: stable objects)
+        _register_weight_split(weight, flip_swap, layout, out, slot, (O, I, Ip, KH, KW, so, si, s[2], s[3]))
     return out, q
+
+
+# ------------------------------------------------------------------ batched re-split of the trainable weights
+BATCH_WEIGHT_SPLITS = os.environ.get("SLN_BATCH_WEIGHT_SPLITS", "1") != "0"     # A/B switch
+_WSPLIT = {}            # (id(weight), flip, layout) -> entry dict
+_WSPLIT_STATE = {"table": None, "order": None, "chunks": {}}
+WSPLIT_CHUNK = 1 << 16
+WSPLIT_STATS = [0, 0]   # batched refreshes, entries refreshed
+_DESC = np.dtype([("w", "<u8"), ("out", "<u8"), ("q_scale", "<u8"), ("q_amax", "<u8"), ("q_sat", "<u8"),
+                  ("s_o", "<i8"), ("s_i", "<i8"), ("s_kh", "<i8"), ("s_kw", "<i8"), ("total", "<i8"),
+                  ("O", "<i4"), ("I", "<i4"), ("Ip", "<i4"), ("KH", "<i4"), ("KW", "<i4"), ("flip", "<i4"),
+                  ("layout", "<i4"), ("reserved", "<i4")])     # == sln_split_desc_t
+
+
+def _register_weight_split(weight, flip, layout, out, slot, geom):
+    import weakref
+    O, I, Ip, KH, KW, so, si, skh, skw = geom
+    total = out.numel() // 2
+    _WSPLIT[(id(weight), flip, layout)] = dict(ref=weakref.ref(weight), flip=flip, layout=layout, out=out, slot=slot,
+                                               desc=(weight.data_ptr(), out.data_ptr(), slot.scale.data_ptr(),
+                                                     slot.amax.data_ptr(), slot.book.saturated.data_ptr(), so, si, skh,
+                                                     skw, total, O, I, Ip, KH, KW, 1 if flip else 0, layout, 0))
+    _WSPLIT_STATE["order"] = None        # the device table is rebuilt at the next refresh
+
+
+def _refresh_weight_parts(device):
+    """Re-split every registered weight whose version moved since its parts were written: one launch."""
+    st = _WSPLIT_STATE
+    dead = [k for k, e in _WSPLIT.items() if e["ref"]() is None or
+            e["ref"]().data_ptr() != e["desc"][0]]
+    for k in dead:
+        del _WSPLIT[k]
+        st["order"] = None
+    if st["order"] is None:
+        st["order"] = [k for k, e in _WSPLIT.items() if e["out"].device == device]
+        tab = np.zeros(len(st["order"]), _DESC)
+        for i, k in enumerate(st["order"]):
+            tab[i] = _WSPLIT[k]["desc"]
+        st["table"] = torch.from_numpy(tab.view(np.uint8)).to(device)
+        st["chunks"] = {}
+    stale = []
+    for i, k in enumerate(st["order"]):
+        e = _WSPLIT[k]
+        wt = e["ref"]()
+        c = getattr(wt, "_sln_wparts", {}).get((e["flip"], 2, e["layout"]))
+        if c is not None and c[1] is e["out"] and c[0] != wt._version and not e["slot"].fresh:
+            stale.append(i)
+    if not stale:
+        return
+    key = tuple(stale)
+    ch = st["chunks"].get(key)
+    if ch is None:
+        ce, cf = [], []
+        for i in stale:
+            total = _WSPLIT[st["order"][i]]["desc"][9]
+            for off in range(0, total, WSPLIT_CHUNK):
+                ce.append(i)
+                cf.append(off)
+        ch = st["chunks"][key] = (torch.tensor(ce, dtype=torch.int32, device=device),
+                                  torch.tensor(cf, dtype=torch.int64, device=device))
+    _lib.check(_lib.lib().sln_conv_split_weights_batch_f32(ops._ptr(st["table"]), ops._ptr(ch[0]), ops._ptr(ch[1]),
+                                                           ch[0].numel(), WSPLIT_CHUNK, ops._stream()),
+               "sln_conv_split_weights_batch_f32")
+    for i in stale:
+        e = _WSPLIT[st["order"][i]]
+        wt = e["ref"]()
+        wt._sln_wparts[(e["flip"], 2, e["layout"])] = (wt._version, e["out"], e["slot"].scale)
+    WSPLIT_STATS[0] += 1
+    WSPLIT_STATS[1] += len(stale)
 
 
 _split = _split_weights

@@ -520,6 +520,76 @@ __global__ __launch_bounds__(256) void split_weights_kernel(const float *__restr
     if (P == 2) amax_commit(amx, sat, q, s_word);
 }
 
+// All stale weight tensors of a step in ONE launch (parts = 2).  A training step re-splits every trainable
+// weight twice (forward order and mirrored / transposed for the data gradient): ~250 launches of ~10 us for
+// ~1 us of work each.  Here every 64 k-element chunk of every (weight, orientation, layout) entry is a
+// block; the entries are described by a device-resident table (sln_split_desc_t).  Same element mapping and
+// arithmetic as split_weights_kernel / split_weights_tiled_kernel / split_weights_tiledh_kernel.
+__global__ __launch_bounds__(256) void split_weights_batch_kernel(const sln_split_desc_t *__restrict__ descs,
+                                                                  const int32_t *__restrict__ chunk_entry,
+                                                                  const int64_t *__restrict__ chunk_first,
+                                                                  int chunk_elems) {
+    __shared__ unsigned s_word[2];
+    const sln_split_desc_t d = descs[chunk_entry[blockIdx.x]];
+    const long first = chunk_first[blockIdx.x];
+    const long last = min(first + (long)chunk_elems, (long)d.total);
+    const float *w = d.w;
+    __bf16 *out = (__bf16 *)d.out;
+    const SplitScale q = {d.q_scale, d.q_amax, d.q_saturated};
+    const float qs = q.scale ? *q.scale : 1.f;
+    const int KH = d.KH, KW = d.KW, O = d.O, I = d.I, flip = d.flip;
+    const int ntap = KH * KW;
+    float amx = 0.f;
+    bool sat = false;
+    for (long idx = first + threadIdx.x; idx < last; idx += 256) {
+        int o, i, kh, kw;
+        long dst0, dst1;
+        if (d.layout == SLN_WEIGHTS_ROWS) {
+            i = (int)(idx % d.Ip);
+            long r = idx / d.Ip;
+            kw = (int)(r % KW); r /= KW;
+            kh = (int)(r % KH);
+            o = (int)(r / KH);
+            dst0 = idx;
+            dst1 = idx + d.total;
+        } else {
+            const bool h = d.layout == SLN_WEIGHTS_TILED256H;
+            const int KS = h ? T2H : T2K;
+            const long per_part = (long)T2 * KS;
+            const int ncc = (I + KS - 1) / KS, nk = ntap * ncc;
+            const int pos = (int)(idx % per_part);
+            const long blk = idx / per_part;                        // nt * nk + s
+            const int st = (int)(blk % nk), nt = (int)(blk / nk);
+            int r, jl, tap, cc;
+            if (h) {
+                r = pos >> 5;
+                const int j = pos & 31;
+                jl = ((((j >> 3) ^ ((r >> 2) & 3))) << 3) | (j & 7);
+                fwd256h_stage(st, ntap, ncc, tap, cc);
+            } else {
+                r = pos >> 4;
+                const int j = pos & 15;
+                jl = (((j >> 3) ^ ((r >> 3) & 1)) << 3) | (j & 7);
+                fwd256_stage(st, ntap, ncc, tap, cc);
+            }
+            kh = tap / KW; kw = tap - kh * KW;
+            o = nt * T2 + r; i = cc * KS + jl;
+            dst0 = blk * 2 * per_part + pos;
+            dst1 = dst0 + per_part;
+        }
+        const int skh = flip ? KH - 1 - kh : kh, skw = flip ? KW - 1 - kw : kw;
+        const float v = (o < O && i < I) ? w[o * d.s_o + i * d.s_i + skh * d.s_kh + skw * d.s_kw] : 0.f;
+        amx = fmaxf(amx, fabsf(v));
+        float qv = v * qs;
+        if (fabsf(qv) > SLN_F16_MAX) { qv = copysignf(SLN_F16_MAX, qv); sat = true; }
+        const _Float16 h0 = (_Float16)qv;
+        const _Float16 h1 = (_Float16)(qv - (float)h0);
+        out[dst0] = __builtin_bit_cast(__bf16, h0);
+        out[dst1] = __builtin_bit_cast(__bf16, h1);
+    }
+    amax_commit(amx, sat, q, s_word);
+}
+
 // scale[i] <- the power of two that puts amax[i] near 2^target_log2 (amax[i] == 0: unchanged);
 // amax[i] <- 0.  One launch per step over every tensor slot (delayed scaling).
 __global__ __launch_bounds__(256) void scale_update_kernel(float *__restrict__ amax, float *__restrict__ scale,
@@ -2228,6 +2298,18 @@ extern "C" int sln_act_split_f32(const float *x, int64_t M, int C, int C_pad, in
     else
         hipLaunchKernelGGL(act_split_kernel<3>, dim3(ew_grid(M * (C_pad / 4))), dim3(256), 0,
                            (hipStream_t)stream, x, (long)M, C, C_pad, (__bf16 *)out, q);
+    return sln_launch_status();
+}
+
+extern "C" int sln_conv_split_weights_batch_f32(const sln_split_desc_t *descs, const int32_t *chunk_entry,
+                                               const int64_t *chunk_first, int n_chunks, int chunk_elems,
+                                               sln_stream_t stream) {
+    sln_enter();
+    if (n_chunks < 0 || chunk_elems < 256) return SLN_ERR_INVALID_ARG;
+    if (n_chunks == 0) return SLN_OK;
+    if (!descs || !chunk_entry || !chunk_first) return SLN_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(split_weights_batch_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, descs,
+                       chunk_entry, chunk_first, chunk_elems);
     return sln_launch_status();
 }
 

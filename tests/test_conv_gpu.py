@@ -833,3 +833,33 @@ def test_scale_slots_are_recycled_when_layers_die():
                                (1, 1, 1, 1))
     ref = F.conv2d(x.double(), torch.ones(16, 16, 3, 3, device="cuda").double(), None, 1, 1)
     assert (y.double() - ref).abs().max().item() / ref.abs().max().item() < 5e-6      # a recycled slot starts fresh
+
+
+def test_batched_weight_resplit_equals_individual_splits(monkeypatch):
+    """After an optimiser step every stale trainable weight is re-split by ONE launch
+    (sln_conv_split_weights_batch_f32): the parts must be the ones the per-tensor kernels write, for the three
+    layouts and both orientations, and convolutions that use them must stay exact."""
+    from sln_amodal_amd import conv_hip
+    monkeypatch.setattr(conv_hip, "PARTS", 2)
+    g = torch.Generator(device="cuda").manual_seed(9)
+    shapes = [(64, 64, 3, 3), (256, 256, 3, 3), (256, 1024, 1, 1), (1024, 256, 1, 1), (24, 40, 1, 1), (182, 256, 3, 3)]
+    ws = [torch.nn.Parameter(torch.randn(s, device="cuda", generator=g) / (s[1] * s[2] * s[3]) ** 0.5) for s in shapes]
+    combos = [(w, flip, lay) for w in ws for flip in (False, True)
+              for lay in (conv_hip.ROWS, conv_hip.TILED256, conv_hip.TILED256H)]
+    first = {}
+    for i, (w, flip, lay) in enumerate(combos):
+        first[i] = conv_hip._split_weights(w, flip, 2, None, lay)[0]
+    conv_hip.update_scales()
+    with torch.no_grad():
+        for w in ws:
+            w.mul_(1.01).add_(1e-3)
+    before = list(conv_hip.WSPLIT_STATS)
+    got = {i: conv_hip._split_weights(w, flip, 2, None, lay)[0] for i, (w, flip, lay) in enumerate(combos)}
+    assert conv_hip.WSPLIT_STATS[0] == before[0] + 1 and conv_hip.WSPLIT_STATS[1] >= before[1] + len(combos)
+    monkeypatch.setattr(conv_hip, "BATCH_WEIGHT_SPLITS", False)
+    for i, (w, flip, lay) in enumerate(combos):
+        assert got[i] is first[i]                                  # refreshed in place
+        have = got[i].clone()
+        w._sln_wparts.pop((flip, 2, lay))
+        want = conv_hip._split_weights(w, flip, 2, None, lay)[0]
+        assert torch.equal(have.view(torch.int16), want.view(torch.int16)), (tuple(w.shape), flip, lay)
