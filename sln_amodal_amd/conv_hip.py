@@ -35,6 +35,8 @@ CHAIN_GRAD_PREP = os.environ.get("SLN_CHAIN_GRAD_PREP", "1") != "0"            #
 CHAIN_BLOCK_OUTPUT = os.environ.get("SLN_CHAIN_BLOCK_OUTPUT", "1") != "0"      # A/B switch
 CHAIN_STATS = [0, 0]  # prepared gradients handed over by consumers / used by producers
 LINK_STATS = [0, 0]   # shortcut gradients handed over by tails / consumed by heads
+PAIR_STATS = [0]      # strided data-gradient pairs merged on the lattice
+PAIR_STRIDED = os.environ.get("SLN_PAIR_STRIDED", "1") != "0"             # A/B switch
 FUSE_OUTPUT_SPLIT = True   # conv epilogue writes the output's parts (skips the next act_split)
 # weight gradients: split-K partial sums through a workspace + ordered reduce (bit-reproducible) instead of
 # fp32 atomics; "0" restores the atomics for A/B runs
@@ -610,7 +612,7 @@ def folded_shift(bias, bn_scale, bn_shift):
 class _ConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, bn_scale, bn_shift, residual, relu, stride, dil, pads, link=None,
-                chain_in=None, chain_out=None, owner=None):
+                chain_in=None, chain_out=None, owner=None, pair=None):
         parts = PARTS
         if PARTS_NOGRAD and not any(ctx.needs_input_grad):
             parts = PARTS_NOGRAD
@@ -642,6 +644,14 @@ class _ConvFn(torch.autograd.Function):
         # conv that adds the same x as its residual (tail) share a dict, so that the tail's
         # gradient for x is added inside the head's data-gradient epilogue instead of by a
         # separate autograd accumulation pass over the whole activation.
+        # the two strided 1x1 convolutions of a stage's first block (conv1 and the downsample, modals.py:269,
+        # 331-337) read the same x: their data gradients live on the same stride lattice, so whichever runs
+        # second adds the other's quarter-size result to its own and builds the zero-filled full-size map
+        # ONCE (one fill, one scatter and one full-size autograd add less per stage transition)
+        ctx.pair = None
+        if pair is not None and PAIR_STRIDED and stride != (1, 1) and (KH, KW) == (1, 1) and ctx.needs_input_grad[0]:
+            pair["n"] = pair.get("n", 0) + 1
+            ctx.pair = pair
         ctx.link_head = ctx.link_tail = None
         if link is not None:
             if residual is None:
@@ -803,8 +813,20 @@ class _ConvFn(torch.autograd.Function):
                 # strided 1x1: the gradient lives on the stride lattice, zero elsewhere
                 small = _fwd(gz, N, OH, OW, wt, Ci, 1, 1, (1, 1), (1, 1), 0, 0, OH, OW, None, None,
                              None, False, cin=Co, **qs)
-                gx = torch.zeros((N, H, W, Ci), dtype=torch.float32, device=weight.device).permute(0, 3, 1, 2)
-                gx[:, :, ::stride[0], ::stride[1]] = small
+                pr = ctx.pair if (ctx.pair is not None and ctx.pair.get("n") == 2) else None
+                if pr is not None and "small" not in pr:
+                    pr["small"] = small                 # the sibling builds the map
+                    gx = None
+                else:
+                    if pr is not None:
+                        other = pr.pop("small")
+                        if other.shape == small.shape:
+                            small = small + other
+                            PAIR_STATS[0] += 1
+                        else:                            # (cannot happen for the two convs of one block)
+                            raise RuntimeError("paired strided data gradients of different shapes")
+                    gx = torch.zeros((N, H, W, Ci), dtype=torch.float32, device=weight.device).permute(0, 3, 1, 2)
+                    gx[:, :, ::stride[0], ::stride[1]] = small
             else:
                 raise NotImplementedError("data gradient of a strided %dx%d conv" % (KH, KW))
         if need_w:
@@ -830,7 +852,7 @@ class _ConvFn(torch.autograd.Function):
                       "wgrad N%d %dx%d C%d->%d k%d s%d d%d" % (N, H, W, Ci, Co, KH, stride[0], dil[0]),
                       _nbytes(gz, xp), _nbytes(gw_t))
             gw = gw_t if own_layout else gw_t.permute(0, 3, 1, 2)  # logical [Co,Ci,KH,KW]
-        return gx, gw, g_bias, None, None, g_res, None, None, None, None, None, None, None, None
+        return gx, gw, g_bias, None, None, g_res, None, None, None, None, None, None, None, None, None
 
 
 class _StemFn(torch.autograd.Function):
@@ -952,11 +974,11 @@ def _dummy_grad(device):
 
 
 def conv_bn_act(x, conv, bn, relu, residual, pads, weight=None, link=None, chain_in=None, chain_out=None,
-                stride=None):
+                stride=None, pair=None):
     from .nn_ops import bn_affine
     scale = shift = None
     if bn is not None:
         scale, shift = bn_affine(bn)
     return _ConvFn.apply(x, conv.weight if weight is None else weight, conv.bias, scale, shift,
                          residual, bool(relu), tuple(stride or conv.stride), tuple(conv.dilation), tuple(pads),
-                         link if LINK_SHORTCUT_GRAD else None, chain_in, chain_out, conv.weight)
+                         link if LINK_SHORTCUT_GRAD else None, chain_in, chain_out, conv.weight, pair)

@@ -319,16 +319,17 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         conv = nn_ops.conv_bn_act
-        residual, link = x, {}
+        residual, link, pair = x, {}, None
         if self.downsample is not None:
-            residual, link = conv(x, self.downsample[0], self.downsample[1]), None
+            pair = {} if self.stride != 1 else None      # conv1 and the downsample: same x, same stride lattice
+            residual, link = conv(x, self.downsample[0], self.downsample[1], pair=pair), None
         c12, c23 = {}, {}   # conv1 -> conv2 -> conv3: each output has exactly one reader
         # block output -> next block: inside a stage the next identity block (its conv1, and its
         # shortcut through `link`) is the only reader; the dict travels on the tensor object and a
         # second reader is detected in backward (conv_hip._ConvFn)
         cx_in = getattr(x, "_sln_chain", None) if link is not None else None
         cx_out = {}
-        out = conv(x, self.conv1, self.bn1, relu=True, link=link, chain_in=cx_in, chain_out=c12)
+        out = conv(x, self.conv1, self.bn1, relu=True, link=link, chain_in=cx_in, chain_out=c12, pair=pair)
         out = conv(out, self.conv2, self.bn2, relu=True, same=True, chain_in=c12, chain_out=c23)
         out = conv(out, self.conv3, self.bn3, relu=True, residual=residual, link=link, chain_in=c23,
                    chain_out=cx_out)

@@ -68,7 +68,7 @@ def bn_affine(bn):
 
 
 def conv_bn_act(x, conv, bn=None, relu=False, residual=None, same=False, link=None, chain_in=None,
-                chain_out=None, parts_only=False):
+                chain_out=None, parts_only=False, pair=None):
     """x [B,C,H,W] (any memory format; channels-last preferred).
     conv: nn.Conv2d parameter holder (weight, bias, stride, padding, dilation).
     bn:   frozen nn.BatchNorm2d or None.  same: apply SamePad2d first.
@@ -76,7 +76,8 @@ def conv_bn_act(x, conv, bn=None, relu=False, residual=None, same=False, link=No
           (one as input, one as residual); HIP backend only, see conv_hip._ConvFn.
     chain_out / chain_in: dict shared by a conv (chain_out) and the ONLY conv that reads its
           output (chain_in): lets the reader's backward prepare this layer's gradient.
-    parts_only: (packed, forward-only GLM scales) the output feeds convolutions only: no fp32 copy."""
+    parts_only: (packed, forward-only GLM scales) the output feeds convolutions only: no fp32 copy.
+    pair: dict shared by the two strided 1x1 convs that read the same x (a stage's first block)."""
     if CALIBRATING is not None and bn is not None:
         # statistics pass (synthetic.calibrate_*): the raw convolution on the same backend, its output's
         # statistics into the frozen BN, then the un-fused normalisation / shortcut / ReLU
@@ -113,7 +114,7 @@ def conv_bn_act(x, conv, bn=None, relu=False, residual=None, same=False, link=No
             w2 = conv.weight.permute(0, 2, 3, 1).reshape(conv.out_channels, kh * kw * C, 1, 1)
             return hip.conv_bn_act(xr, conv, bn, relu, None, (0, 0, 0, 0), weight=w2, stride=(1, 1))
         return hip.conv_bn_act(x, conv, bn, relu, residual, (pt, pb, pl, pr), link=link,
-                               chain_in=chain_in, chain_out=chain_out)
+                               chain_in=chain_in, chain_out=chain_out, pair=pair)
     if hip is not None and not isinstance(x, hip.MultiScale) and hip.is_stem(conv, x) and residual is None:
         return hip.stem_conv_bn_act(x, conv, bn, relu, (pt, pb, pl, pr))   # 3-channel 7x7/2 stems
     if BACKEND != "torch" and x.is_cuda:

@@ -863,3 +863,50 @@ def test_batched_weight_resplit_equals_individual_splits(monkeypatch):
         w._sln_wparts.pop((flip, 2, lay))
         want = conv_hip._split_weights(w, flip, 2, None, lay)[0]
         assert torch.equal(have.view(torch.int16), want.view(torch.int16)), (tuple(w.shape), flip, lay)
+
+
+def test_strided_sibling_data_gradients_share_one_lattice_map():
+    """A stage's first block: conv1 and the downsample are stride-2 1x1 convs of the same x.  Their data
+    gradients are merged on the stride lattice (one zero-filled map instead of two + an autograd add); the
+    input gradient must equal the unmerged path's up to the order of two additions, and the fp64 one."""
+    from sln_amodal_amd import conv_hip
+    from sln_amodal_amd.modal.modals import Bottleneck
+    torch.manual_seed(3)
+    down = nn.Sequential(nn.Conv2d(64, 128, 1, stride=2), nn.BatchNorm2d(128, eps=1e-3))
+    blk = Bottleneck(64, 32, stride=2, downsample=down).cuda().eval()
+    for m in blk.modules():
+        if isinstance(m, nn.BatchNorm2d):
+            with torch.no_grad():
+                m.running_mean.normal_(); m.running_var.uniform_(0.5, 2); m.weight.normal_(1, 0.1); m.bias.normal_()
+            for p in m.parameters():
+                p.requires_grad = False
+    g = torch.Generator(device="cuda").manual_seed(4)
+    x0 = torch.randn(2, 64, 24, 24, device="cuda", generator=g).contiguous(memory_format=torch.channels_last)
+    up = torch.randn(2, 128, 12, 12, device="cuda", generator=g)
+    grads = []
+    for merged in (True, False):
+        conv_hip.PAIR_STRIDED = merged
+        try:
+            x = x0.clone().requires_grad_(True)
+            y = blk(x)
+            before = conv_hip.PAIR_STATS[0]
+            y.backward(up)
+            assert conv_hip.PAIR_STATS[0] == before + (1 if merged else 0)
+        finally:
+            conv_hip.PAIR_STRIDED = True
+        grads.append(x.grad.clone())
+    xd = x0.double().requires_grad_(True)
+    ref_blk = Bottleneck(64, 32, stride=2, downsample=nn.Sequential(nn.Conv2d(64, 128, 1, stride=2),
+                                                                    nn.BatchNorm2d(128, eps=1e-3))).double().eval()
+    ref_blk.load_state_dict({k: v.double() for k, v in blk.state_dict().items()})
+    from sln_amodal_amd import nn_ops
+    old = nn_ops.BACKEND
+    nn_ops.BACKEND = "torch"
+    try:
+        yr = ref_blk.cuda()(xd)
+    finally:
+        nn_ops.BACKEND = old
+    yr.backward(up.double())
+    scale = xd.grad.abs().max().item()
+    assert (grads[0].double() - xd.grad).abs().max().item() / scale < 5e-5
+    assert (grads[0] - grads[1]).abs().max().item() / scale < 1e-6
