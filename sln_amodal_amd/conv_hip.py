@@ -35,7 +35,7 @@ CHAIN_GRAD_PREP = os.environ.get("SLN_CHAIN_GRAD_PREP", "1") != "0"            #
 CHAIN_BLOCK_OUTPUT = os.environ.get("SLN_CHAIN_BLOCK_OUTPUT", "1") != "0"      # A/B switch
 CHAIN_STATS = [0, 0]  # prepared gradients handed over by consumers / used by producers
 LINK_STATS = [0, 0]   # shortcut gradients handed over by tails / consumed by heads
-PAIR_STATS = [0]      # strided data-gradient pairs merged on the lattice
+PAIR_STATS = [0, 0]   # strided data-gradient pairs merged on the lattice / merged into a stride-1 reader's gradient
 PAIR_STRIDED = os.environ.get("SLN_PAIR_STRIDED", "1") != "0"             # A/B switch
 FUSE_OUTPUT_SPLIT = True   # conv epilogue writes the output's parts (skips the next act_split)
 # weight gradients: split-K partial sums through a workspace + ordered reduce (bit-reproducible) instead of
@@ -648,10 +648,16 @@ class _ConvFn(torch.autograd.Function):
         # 331-337) read the same x: their data gradients live on the same stride lattice, so whichever runs
         # second adds the other's quarter-size result to its own and builds the zero-filled full-size map
         # ONCE (one fill, one scatter and one full-size autograd add less per stage transition)
-        ctx.pair = None
+        ctx.pair = ctx.pair_base = None
         if pair is not None and PAIR_STRIDED and stride != (1, 1) and (KH, KW) == (1, 1) and ctx.needs_input_grad[0]:
             pair["n"] = pair.get("n", 0) + 1
             ctx.pair = pair
+        elif pair is not None and PAIR_STRIDED and stride == (1, 1) and pair.get("n") == 2 and \
+                ctx.needs_input_grad[0] and link is None and chain_in is None and residual is None:
+            # a third, stride-1 reader of the same x (the FPN lateral of c2..c4, created after the stage's
+            # convs and therefore differentiated before them): its full-size data gradient becomes the map the
+            # strided pair adds its lattice into -- no zero fill, no autograd add
+            ctx.pair_base = pair
         ctx.link_head = ctx.link_tail = None
         if link is not None:
             if residual is None:
@@ -809,6 +815,13 @@ class _ConvFn(torch.autograd.Function):
                 gx = _fwd(gz, N, OH, OW, wt, Ci, KH, KW, (1, 1), dil, dil[0] * (KH - 1) - pt,
                           dil[1] * (KW - 1) - pl, H, W, None, None,
                           _nhwc(id_grad) if id_grad is not None else None, False, cin=Co, **qs)
+                pb = ctx.pair_base
+                if pb is not None:
+                    if pb.get("pair_done"):          # the pair ran first (not the engine's usual order):
+                        pb["pair_done"] = False      # ordinary accumulation by autograd
+                    elif "base" not in pb:
+                        pb["base"] = gx              # handed to the strided pair, which returns the sum
+                        gx = None
             elif KH == 1 and KW == 1 and pads == (0, 0, 0, 0):
                 # strided 1x1: the gradient lives on the stride lattice, zero elsewhere
                 small = _fwd(gz, N, OH, OW, wt, Ci, 1, 1, (1, 1), (1, 1), 0, 0, OH, OW, None, None,
@@ -825,8 +838,18 @@ class _ConvFn(torch.autograd.Function):
                             PAIR_STATS[0] += 1
                         else:                            # (cannot happen for the two convs of one block)
                             raise RuntimeError("paired strided data gradients of different shapes")
-                    gx = torch.zeros((N, H, W, Ci), dtype=torch.float32, device=weight.device).permute(0, 3, 1, 2)
-                    gx[:, :, ::stride[0], ::stride[1]] = small
+                    base = pr.pop("base", None) if pr is not None else None
+                    if pr is not None:
+                        pr["pair_done"] = base is None
+                    if base is not None and tuple(base.shape) == (N, Ci, H, W):
+                        gx = base                        # the stride-1 reader's gradient: add the lattice in place
+                        gx[:, :, ::stride[0], ::stride[1]] += small
+                        PAIR_STATS[1] += 1
+                    else:
+                        if base is not None:
+                            raise RuntimeError("stride-1 reader's data gradient does not match the paired input")
+                        gx = torch.zeros((N, H, W, Ci), dtype=torch.float32, device=weight.device).permute(0, 3, 1, 2)
+                        gx[:, :, ::stride[0], ::stride[1]] = small
             else:
                 raise NotImplementedError("data gradient of a strided %dx%d conv" % (KH, KW))
         if need_w:

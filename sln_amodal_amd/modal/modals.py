@@ -283,10 +283,11 @@ class FPN(nn.Module):
         c4 = self.C4(c3)
         c5 = self.C5(c4)
         conv = nn_ops.conv_bn_act
+        fan = lambda c: getattr(c, "_sln_pair", None)     # c2..c4 also feed the next stage's strided pair
         p5 = conv(c5, self.P5_conv1)
-        p4 = nn_ops.upsample2x_add(conv(c4, self.P4_conv1), p5)
-        p3 = nn_ops.upsample2x_add(conv(c3, self.P3_conv1), p4)
-        p2 = nn_ops.upsample2x_add(conv(c2, self.P2_conv1), p3)
+        p4 = nn_ops.upsample2x_add(conv(c4, self.P4_conv1, pair=fan(c4)), p5)
+        p3 = nn_ops.upsample2x_add(conv(c3, self.P3_conv1, pair=fan(c3)), p4)
+        p2 = nn_ops.upsample2x_add(conv(c2, self.P2_conv1, pair=fan(c2)), p3)
         p5 = conv(p5, self.P5_conv2[1], same=True)
         p4 = conv(p4, self.P4_conv2[1], same=True)
         p3 = conv(p3, self.P3_conv2[1], same=True)
@@ -322,6 +323,11 @@ class Bottleneck(nn.Module):
         residual, link, pair = x, {}, None
         if self.downsample is not None:
             pair = {} if self.stride != 1 else None      # conv1 and the downsample: same x, same stride lattice
+            if pair is not None:
+                try:
+                    x._sln_pair = pair                    # a later stride-1 reader of x (the FPN lateral) joins in
+                except Exception:
+                    pass
             residual, link = conv(x, self.downsample[0], self.downsample[1], pair=pair), None
         c12, c23 = {}, {}   # conv1 -> conv2 -> conv3: each output has exactly one reader
         # block output -> next block: inside a stage the next identity block (its conv1, and its

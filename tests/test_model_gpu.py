@@ -353,3 +353,46 @@ def test_config3_full_size_train_step_resnet101_16x1024():
         assert tuple(got.shape) == tuple(want.shape), name
         assert err <= 1e-5, (name, err)
         del x, got, want
+
+
+def test_stage_transition_gradients_merge_into_the_lateral_map():
+    """c2..c4 have three readers: the FPN lateral (stride 1) and the next stage's strided conv1 + downsample.
+    The pair's lattice sum is added in place into the lateral's data gradient (conv_hip PAIR_STATS); the
+    backbone gradients equal the unmerged path's up to the order of the additions."""
+    from sln_amodal_amd import conv_hip
+    from sln_amodal_amd.modal.modals import FPN, ResNet
+    from tests._util import key_init_
+    torch.manual_seed(0)
+    resnet = ResNet("resnet50", stage5=True)
+    fpn = FPN(*resnet.stages(), out_channels=256).eval()
+    key_init_(fpn)
+    fpn = fpn.cuda()
+    for m in fpn.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            for p in m.parameters():
+                p.requires_grad = False
+    g = torch.Generator(device="cuda").manual_seed(1)
+    x = torch.randn(2, 3, 128, 128, device="cuda", generator=g)
+    ups = None
+    grads = []
+    for merged in (True, False):
+        conv_hip.PAIR_STRIDED = merged
+        try:
+            for p in fpn.parameters():
+                p.grad = None
+            outs = fpn(x)
+            if ups is None:
+                ups = [torch.randn(o.shape, device="cuda", generator=g) for o in outs]
+            before = list(conv_hip.PAIR_STATS)
+            sum((o * u).sum() for o, u in zip(outs, ups)).backward()
+            if merged:
+                assert conv_hip.PAIR_STATS[0] == before[0] + 3 and conv_hip.PAIR_STATS[1] == before[1] + 3
+            else:
+                assert conv_hip.PAIR_STATS == before
+        finally:
+            conv_hip.PAIR_STRIDED = True
+        grads.append({n: p.grad.clone() for n, p in fpn.named_parameters() if p.grad is not None})
+    assert grads[0].keys() == grads[1].keys() and len(grads[0]) > 100
+    for n in grads[0]:
+        a, b = grads[0][n], grads[1][n]
+        assert (a - b).norm().item() <= 2e-5 * max(b.norm().item(), 1e-12), n
