@@ -220,7 +220,10 @@ int sln_sumpool2x2_f32(const float *g, int N, int h, int w, int C, float *gtop, 
  *                       every gradient element (float64 accumulation, fixed order: reproducible).
  * sln_sgd_clip_step_f32 c = max_norm / (sqrt(sqnorm) + 1e-6), applied when < 1 (clip_grad_norm);
  *                       d = g*c + wd*p;  buf = momentum*buf + d;  p = p - lr*buf  (dampening 0,
- *                       no nesterov).  Gradients are read, not rewritten.
+ *                       no nesterov).  Gradients are read, not rewritten.  A non-finite sqnorm (an inf /
+ *                       NaN gradient) skips the update of every tensor and adds 1 to *skipped (device
+ *                       int32, may be NULL): the reference's loop `continue`s past a batch it cannot use
+ *                       (model.py:416-418, 433-434); here no host round trip is needed to decide it.
  * ------------------------------------------------------------------------- */
 int sln_grad_sqnorm_f32(const float *const *grads, const int64_t *numel, const int32_t *chunk_tensor,
                         const int64_t *chunk_offset, int n_chunks, int chunk_elems, double *partial,
@@ -228,7 +231,7 @@ int sln_grad_sqnorm_f32(const float *const *grads, const int64_t *numel, const i
 int sln_sgd_clip_step_f32(float *const *params, const float *const *grads, float *const *bufs,
                           const int64_t *numel, const float *weight_decay, const int32_t *chunk_tensor,
                           const int64_t *chunk_offset, int n_chunks, int chunk_elems, const double *sqnorm,
-                          float max_norm, float lr, float momentum, sln_stream_t stream);
+                          float max_norm, float lr, float momentum, int32_t *skipped, sln_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * Inference tail: full-size masks and their COCO run-length encoding.

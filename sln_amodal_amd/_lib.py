@@ -33,7 +33,7 @@ SIGNATURES = {
     "sln_upsample2x_add_f32": (_i, [_p, _p, _i, _i, _i, _i, _p, _p]),
     "sln_sumpool2x2_f32": (_i, [_p, _i, _i, _i, _i, _p, _p]),
     "sln_grad_sqnorm_f32": (_i, [_p, _p, _p, _p, _i, _i, _p, _p, _p]),
-    "sln_sgd_clip_step_f32": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _f, _f, _f, _p]),
+    "sln_sgd_clip_step_f32": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _f, _f, _f, _p, _p]),
     "sln_unmold_masks_u8": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p]),
     "sln_rle_encode_u8": (_i, [_p, _i, C.c_int64, _i, _p, _p, _p]),
     "sln_rle_to_string": (C.c_int64, [_p, C.c_int64, _p, C.c_int64]),

@@ -14,6 +14,7 @@ The scales live on the device (ScaleBook): every tensor role of every layer owns
 the last time it was produced, and records the new amax -- no host round trip.  The first time a
 slot is used it is bootstrapped exactly (an amax pass, then the split).
 """
+import heapq
 import os
 
 import numpy as np
@@ -56,7 +57,7 @@ class _Slot(object):
 
     def __del__(self):
         try:
-            self.book.free.append(self.idx)
+            heapq.heappush(self.book.free, self.idx)
         except Exception:
             pass
 
@@ -79,12 +80,15 @@ class ScaleBook(object):
         self.cursor = torch.zeros(capacity, dtype=torch.int32, device=device)
         self.saturated = torch.zeros(1, dtype=torch.int32, device=device)
         self.n = 0
-        self.free = []               # indices of dead slots
+        self._n_written, self._n_reduced = None, False
+        self.free = []               # indices of dead slots (a heap: the lowest index is reused first, so
+        #                              ranks that free the same layers reuse the same entries whatever the
+        #                              order their garbage collectors ran in)
         self.names = {}              # slot index -> (role key, owner shape): diagnostics (tools/sat_probe.py)
 
     def new_slot(self):
         if self.free:                        # an entry whose layer has died: back to the initial state
-            idx = self.free.pop()
+            idx = heapq.heappop(self.free)
             tables = [self.amax, self.scale, self.hist, self.cursor]
             versions = [t._version for t in tables]
             self.amax[idx] = 0.0
@@ -95,20 +99,32 @@ class ScaleBook(object):
             # check must not trip over the reset of an unrelated, dead entry)
             torch._C._autograd._unsafe_set_version_counter(tables, versions)
             return _Slot(self, idx)
-        if self.n >= self.amax.numel():
+        if self.n >= self.amax.numel() - 2:     # (the last two entries carry the slot count, see update())
             raise RuntimeError("ScaleBook is full (%d tensor slots)" % self.n)
         self.n += 1
         return _Slot(self, self.n - 1)
 
-    def update(self):
+    def update(self, sync=True):
         """Delayed scaling: every slot's next scale from the amax it recorded since the last call.
         Data-parallel replicas take the maximum over all ranks first (one small MAX all-reduce per
         step), so that every rank derives the same scales and the replicas keep computing the same
-        function bit for bit (a rank-local power of two would round the fp16 parts differently)."""
+        function bit for bit (a rank-local power of two would round the fp16 parts differently).
+        sync=False (inference / validation forwards, which one rank may run alone): no collective."""
         if self.n:
             import torch.distributed as dist
-            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-                dist.all_reduce(self.amax[:self.n], op=dist.ReduceOp.MAX)
+            if sync and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                # ONE fixed-size collective over the whole table (128 KB), whatever the ranks' slot counts: its
+                # last two entries carry (n, -n), so that ranks which built different graphs -- whose
+                # element-wise MAX would mix unrelated tensors -- are found by check_ranks() instead of
+                # hanging in a collective of mismatched sizes
+                if self._n_written != self.n:
+                    v = self.amax._version
+                    self.amax[-2] = float(self.n)
+                    self.amax[-1] = -float(self.n)
+                    torch._C._autograd._unsafe_set_version_counter([self.amax], [v])
+                    self._n_written = self.n
+                dist.all_reduce(self.amax, op=dist.ReduceOp.MAX)
+                self._n_reduced = True
             _lib.check(_lib.lib().sln_scale_update_f32(ops._ptr(self.amax), ops._ptr(self.scale), ops._ptr(self.hist),
                                                        ops._ptr(self.cursor), self.n, self.hist.shape[1], SCALE_WINDOW,
                                                        SCALE_TARGET_LOG2, ops._stream()), "sln_scale_update_f32")
@@ -132,16 +148,28 @@ def book(device):
     return b
 
 
-def update_scales():
-    """Call once per step (MaskRCNN.predict does): scales follow the previous step's amax."""
+def update_scales(sync=True):
+    """Call once per step (MaskRCNN.predict does): scales follow the previous step's amax.
+    sync: take the maximum over the data-parallel ranks first (training steps, which every rank runs in
+    lockstep); inference / validation forwards pass False and stay rank-local.
+    A backward pass of a graph built BEFORE this call would de-scale its weight gradient with the new
+    scale of operands that were quantised with the old one: _ConvFn.backward raises in that case."""
+    if hold_scales.depth:
+        return
     for b in _books.values():
-        b.update()
+        b.update(sync)
     SCALE_EPOCH[0] += 1
 
 
-def saturation_count():
-    """Blocks that clamped a value to +-65504 since the start (host sync; tests / monitoring)."""
-    return sum(int(b.saturated.item()) for b in _books.values())
+def check_ranks():
+    """Host-side check (one sync; call it where the loop syncs anyway, e.g. once per epoch) that every
+    data-parallel rank held the same number of scale slots at the last synchronised update."""
+    for b in _books.values():
+        if b._n_reduced:
+            hi, lo = float(b.amax[-2]), -float(b.amax[-1])
+            if hi != lo or hi != b.n:
+                raise RuntimeError("ScaleBook: ranks hold different slot counts (%d..%d, here %d): the "
+                                   "replicas built different graphs" % (lo, hi, b.n))
 
 
 def _slot(owner, key):
@@ -609,6 +637,31 @@ def folded_shift(bias, bn_scale, bn_shift):
     return out
 
 
+def _check_epoch(ctx, parts):
+    """The saved operand parts were quantised with the scales of the epoch the forward ran in; the scale
+    tensors saved next to them are live views of the ScaleBook.  After another update_scales() (a second
+    predict() / detect() between this graph's forward and backward) the two no longer belong together
+    and the weight gradient would be off by a power of two, silently."""
+    if parts == 2 and ctx.scale_epoch != SCALE_EPOCH[0]:
+        raise RuntimeError("conv backward after update_scales(): this graph's forward ran in scale epoch %d, "
+                           "the ScaleBook is at %d (run backward before the next predict()/detect(), or "
+                           "run that forward under conv_hip.hold_scales())" % (ctx.scale_epoch, SCALE_EPOCH[0]))
+
+
+class hold_scales(object):
+    """Context manager: update_scales() is a no-op inside (a validation / detect() pass run while a training
+    graph is still waiting for its backward keeps that graph's scales)."""
+    depth = 0
+
+    def __enter__(self):
+        hold_scales.depth += 1
+        return self
+
+    def __exit__(self, *exc):
+        hold_scales.depth -= 1
+        return False
+
+
 class _ConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, bn_scale, bn_shift, residual, relu, stride, dil, pads, link=None,
@@ -705,6 +758,7 @@ class _ConvFn(torch.autograd.Function):
                    parts)
         ctx.out_hw = (OH, OW)
         ctx.own, ctx.gzslot = own, gzslot
+        ctx.scale_epoch = SCALE_EPOCH[0]
         return y
 
     @staticmethod
@@ -712,6 +766,7 @@ class _ConvFn(torch.autograd.Function):
         xp, weight, scale, y, mask_x, xq = ctx.saved_tensors
         own = ctx.own
         stride, dil, pads, relu, has_bias, has_res, xshape, parts = ctx.cfg
+        _check_epoch(ctx, parts)
         pt, pb, pl, pr = pads
         Co, Ci, KH, KW = weight.shape
         N, _, H, W = xshape
@@ -934,12 +989,14 @@ class _StemFn(torch.autograd.Function):
         ctx.w2 = w2 if ctx.needs_input_grad[0] else None
         ctx.own = weight
         ctx.gzslot = _slot(weight, ("gz", OH, OW)) if parts == 2 else None
+        ctx.scale_epoch = SCALE_EPOCH[0]
         return y
 
     @staticmethod
     def backward(ctx, gy):
         xp, scale, y, xq = ctx.saved_tensors
         N, OH, OW, Co, Ci, KH, KW, K, Kp, parts, relu, has_bias = ctx.cfg
+        _check_epoch(ctx, parts)
         need_w = ctx.needs_input_grad[1]
         want_bias = has_bias and ctx.needs_input_grad[2]
         gx = gw = g_bias = None

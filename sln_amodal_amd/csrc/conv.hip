@@ -1,15 +1,18 @@
-// Implicit-GEMM convolution stack for gfx950 on the bf16 matrix cores with
-// fp32-class accuracy ("split-bf16").
+// Implicit-GEMM convolution stack for gfx950 on the 16-bit matrix cores with fp32-class accuracy
+// ("split operands").
 //
-// Every fp32 operand v is represented as a sum of P bf16 parts,
-//   v ~= v0 + v1 (+ v2),   vi = bf16_rne(v - v0 - ... - v(i-1)),
-// and a product of two operands is accumulated in fp32 (inside the MFMA) from
-// the dominant part pairs:
-//   P = 2 : a0*b0 + a0*b1 + a1*b0                    (~4e-6 relative per layer)
-//   P = 3 : ... + a1*b1 + a0*b2 + a2*b0              (~1e-7, the accuracy of fp32)
-// v_mfma_f32_32x32x16_bf16 issues at 16x the rate of the fp32-input MFMA
-// (MI355X_MICROARCH.md), so 3 / 6 bf16 MFMAs per fp32-equivalent product leave
-// 5.3x / 2.7x the fp32-MFMA roofline.
+// Every fp32 operand v is carried as a sum of P 16-bit parts and a product of two operands is
+// accumulated in fp32 (inside the MFMA) from the dominant part pairs:
+//   P = 2 (default): two fp16 parts of v*s, s a per-tensor power of two (delayed scaling):
+//           h0 = fp16_rne(v*s), h1 = fp16_rne(v*s - h0)  -- 22 significant bits --
+//           products a1*b0 + a0*b1 + a0*b0 on v_mfma_f32_32x32x16_f16, accumulator * 1/(sa*sb):
+//           1-3e-7 relative per layer against fp64, the accuracy of an fp32 GEMM
+//   P = 3: three bf16 parts, vi = bf16_rne(v - v0 - ... - v(i-1)), six products
+//           a2*b0 + a0*b2 + a1*b1 + a1*b0 + a0*b1 + a0*b0 on v_mfma_f32_32x32x16_bf16 (~1e-8, no scales)
+// (two UNSCALED bf16 parts, ~4e-6 per layer, were measured in round 1 and rejected.)
+// The 16-bit MFMA issues at 16x the rate of the fp32-input MFMA (MI355X_MICROARCH.md), so 3 / 6
+// part products per fp32-equivalent product leave 5.3x / 2.7x the fp32-MFMA roofline.  Details of the
+// two formats: "operand formats" below.
 //
 // Data flow of one conv layer (all activations NHWC = [pixels][channels]):
 //   act_split      x fp32 -> xparts [P][M][Cp] bf16 (one HBM-bound pass; the

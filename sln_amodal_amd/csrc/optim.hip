@@ -9,6 +9,7 @@
 //   sqnorm_final_kernel     ordered sum of the partials -> squared total norm (one block)
 //   sgd_clip_kernel         g' = g * min(1, max_norm / (norm + 1e-6));  d = g' + wd * p;
 //                           buf = momentum * buf + d;  p = p - lr * buf
+//                           (nothing at all when the norm is inf / NaN: the step is skipped and counted)
 // HBM-bound: 4 B read in pass 1; 12 B read + 8 B written per element in pass 3.  The clipped
 // gradient is not written back (nothing reads it after the step).  Rounds like the eager sequence
 // (compiled with -ffp-contract=off: one rounding per operation).
@@ -77,8 +78,17 @@ __global__ __launch_bounds__(OPT_THREADS) void sgd_clip_kernel(float *const *__r
                                                                const int32_t *__restrict__ chunk_tensor,
                                                                const int64_t *__restrict__ chunk_offset,
                                                                int chunk_elems, const double *__restrict__ sqnorm,
-                                                               float max_norm, float lr, float momentum) {
+                                                               float max_norm, float lr, float momentum,
+                                                               int32_t *__restrict__ skipped) {
     const int t = threadIdx.x;
+    // A non-finite gradient norm (an inf / NaN anywhere in the step's gradients) skips the whole update --
+    // weights and momentum buffers untouched, counted on the device -- the way the reference's loop
+    // `continue`s past a batch it cannot use (model.py:416-418, 433-434); no host round trip decides it.
+    const double sq = sqnorm[0];
+    if (!(sq >= 0.0 && sq < INFINITY)) {
+        if (skipped && blockIdx.x == 0 && t == 0) atomicAdd(skipped, 1);
+        return;
+    }
     const int ti = chunk_tensor[blockIdx.x];
     const int64_t off = chunk_offset[blockIdx.x];
     float *p = params[ti] + off, *b = bufs[ti] + off;
@@ -86,7 +96,7 @@ __global__ __launch_bounds__(OPT_THREADS) void sgd_clip_kernel(float *const *__r
     const int64_t n = min((int64_t)chunk_elems, numel[ti] - off);
     const float wd = weight_decay[ti];
     // clip_grad_norm: clip_coef = max_norm / (total_norm + 1e-6), applied only when < 1
-    const double coef = (double)max_norm / (sqrt(sqnorm[0]) + 1e-6);
+    const double coef = (double)max_norm / (sqrt(sq) + 1e-6);
     const float cf = coef < 1.0 ? (float)coef : 1.0f;
     if (((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)b)) & 15) == 0) {
         const int64_t n4 = n >> 2;
@@ -126,7 +136,7 @@ extern "C" int sln_sgd_clip_step_f32(float *const *params, const float *const *g
                                      const int64_t *numel, const float *weight_decay, const int32_t *chunk_tensor,
                                      const int64_t *chunk_offset, int n_chunks, int chunk_elems,
                                      const double *sqnorm, float max_norm, float lr, float momentum,
-                                     sln_stream_t stream) {
+                                     int32_t *skipped, sln_stream_t stream) {
     if (n_chunks < 0 || chunk_elems < 1) return SLN_ERR_INVALID_ARG;
     if (n_chunks == 0) return SLN_OK;
     if (!params || !grads || !bufs || !numel || !weight_decay || !chunk_tensor || !chunk_offset || !sqnorm)
@@ -134,6 +144,6 @@ extern "C" int sln_sgd_clip_step_f32(float *const *params, const float *const *g
     sln_enter();
     hipLaunchKernelGGL(sgd_clip_kernel, dim3(n_chunks), dim3(OPT_THREADS), 0, (hipStream_t)stream, params, grads,
                        bufs, numel, weight_decay, chunk_tensor, chunk_offset, chunk_elems, sqnorm, max_norm, lr,
-                       momentum);
+                       momentum, skipped);
     return sln_launch_status();
 }

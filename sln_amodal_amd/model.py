@@ -201,7 +201,9 @@ class MaskRCNN(nn.Module):
         cfg = self.config
         if molded_images.is_cuda:
             from . import conv_hip       # delayed per-tensor operand scales follow the previous step's amax
-            conv_hip.update_scales()
+            # (the MAX over the data-parallel ranks only in training steps, which every rank runs in
+            # lockstep: a detect() / validation pass may run on one rank alone)
+            conv_hip.update_scales(sync=(mode == "training" and torch.is_grad_enabled()))
         B, _, H, W = molded_images.shape
         probs, gloable_lab = self.glm_probs(molded_images)
         maps, rpn_class_logits, rpn_class, rpn_bbox = self.rpn_forward(molded_images)
@@ -372,15 +374,43 @@ class MaskRCNN(nn.Module):
             dist.barrier()
 
     def train_epoch(self, datagenerator, optimizer, steps, grad_sync=None):
-        loss_sum = torch.zeros((), device=self.anchors.device)
+        """`steps` optimiser steps (model.py:370-462).  No host sync inside the loop; the epoch's single
+        sync reads, together with the mean loss, the two device-side health counters of the step:
+          * fp16 x 2 operand blocks that had to clamp a value to +-65504 (conv_hip.saturation_count():
+            the clamped tensor's scale follows its new maximum from the next step on -- the amax is taken
+            before the clamp -- so the count says how many blocks of how many steps ran under-estimated);
+          * optimiser steps skipped on the device for a non-finite gradient norm (ClippedSGD.skipped_steps():
+            the reference's loop `continue`s past batches it cannot use, model.py:416-418, 433-434).  The
+            loss of such a step is left out of the epoch mean instead of turning it into NaN.
+        Both are logged and kept in `self.epoch_health`."""
+        dev = self.anchors.device
+        loss_sum = torch.zeros((), device=dev)
+        finite_steps = torch.zeros((), device=dev)
+        conv_hip = None
+        if self.anchors.is_cuda and nn_ops.BACKEND != "torch":
+            from . import conv_hip
+        sat0 = conv_hip.saturation_count() if conv_hip is not None else 0      # (before the loop: not in it)
+        skip0 = optimizer.skipped_steps() if hasattr(optimizer, "skipped_steps") else 0
         step = 0
         for batch in datagenerator:
             loss, _ = self.train_step(batch, optimizer, grad_sync)
-            loss_sum += loss / steps
+            ok = torch.isfinite(loss)
+            loss_sum += torch.where(ok, loss, torch.zeros_like(loss))
+            finite_steps += ok.to(loss_sum.dtype)
             step += 1
             if step == steps:
                 break
-        return float(loss_sum)  # the one host sync of the epoch
+        mean = float(loss_sum / finite_steps.clamp(min=1))   # the one host sync of the epoch
+        health = {"steps": step, "non_finite_losses": step - int(finite_steps),
+                  "conv_saturated_blocks": (conv_hip.saturation_count() - sat0) if conv_hip is not None else 0,
+                  "skipped_optimizer_steps": (optimizer.skipped_steps() - skip0)
+                  if hasattr(optimizer, "skipped_steps") else 0}
+        if conv_hip is not None:
+            conv_hip.check_ranks()
+        self.epoch_health = health
+        if health["non_finite_losses"] or health["conv_saturated_blocks"] or health["skipped_optimizer_steps"]:
+            log("epoch health: {}".format(health))
+        return mean
 
     # -------------------------------------------------------------- inference
     def mold_inputs(self, images):

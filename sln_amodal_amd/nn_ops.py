@@ -21,6 +21,7 @@ import torch.nn.functional as F
 BACKEND = "auto"  # "auto" | "hip" | "torch"
 PARTS_ONLY = os.environ.get("SLN_PARTS_ONLY", "1") != "0"   # A/B switch of conv_bn_act(parts_only=True)
 CALIBRATING = None   # [count] while synthetic._calibrate runs: conv_bn_act refreshes each frozen BN's statistics
+IN_CALIBRATED_BN = False   # True around conv_bn_act's own F.batch_norm call of a statistics pass
 
 
 def _hip_conv():
@@ -86,7 +87,12 @@ def conv_bn_act(x, conv, bn=None, relu=False, residual=None, same=False, link=No
             bn.running_mean.copy_(y.mean(dim=(0, 2, 3)))
             bn.running_var.copy_(y.var(dim=(0, 2, 3), unbiased=False).clamp(min=1e-6))
         CALIBRATING[0] += 1
-        y = F.batch_norm(y, bn.running_mean, bn.running_var, bn.weight, bn.bias, False, 0.0, bn.eps)
+        global IN_CALIBRATED_BN
+        IN_CALIBRATED_BN = True      # (this BN has its statistics already: synthetic._calibrate's patch skips it)
+        try:
+            y = F.batch_norm(y, bn.running_mean, bn.running_var, bn.weight, bn.bias, False, 0.0, bn.eps)
+        finally:
+            IN_CALIBRATED_BN = False
         if residual is not None:
             y = y + residual
         return F.relu(y) if relu else y

@@ -25,12 +25,70 @@ class ClippedSGD(object):
             g.setdefault("lr", lr)
             g.setdefault("momentum", momentum)
             self.param_groups.append(g)
-        self.lr, self.momentum = float(lr), float(momentum)
         self.state = {}                      # param -> momentum buffer
+        self.skipped = None                  # device int32: steps skipped for a non-finite gradient norm
         self._plan_key, self._plan = None, None
         self._ring, self._turn = [], 0       # pinned staging buffers of the pointer tables
         self.capturing = False               # inside a HIP-graph capture: no event waits (the tables are static)
         self.last_norm = None
+
+    def _hyper(self):
+        """lr / momentum are read from the groups at step time, like torch.optim.SGD (an LR scheduler or
+        `optimizer.param_groups[i]['lr'] = ...` takes effect); the fused kernel applies ONE pair to every
+        tensor, so the groups must agree."""
+        lrs = {float(g["lr"]) for g in self.param_groups if g["params"]}
+        moms = {float(g["momentum"]) for g in self.param_groups if g["params"]}
+        if len(lrs) > 1 or len(moms) > 1:
+            raise ValueError("ClippedSGD applies one lr / momentum to all parameter groups (got lr %s, "
+                             "momentum %s)" % (sorted(lrs), sorted(moms)))
+        return (lrs.pop() if lrs else 0.0), (moms.pop() if moms else 0.0)
+
+    @property
+    def lr(self):
+        return self._hyper()[0]
+
+    @lr.setter
+    def lr(self, value):
+        for g in self.param_groups:
+            g["lr"] = float(value)
+
+    @property
+    def momentum(self):
+        return self._hyper()[1]
+
+    def skipped_steps(self):
+        """Steps whose update was skipped on the device because the gradient norm was inf / NaN (host sync)."""
+        return int(self.skipped.item()) if self.skipped is not None else 0
+
+    def state_dict(self):
+        """Momentum buffers by position in the flattened parameter groups + the groups' hyper-parameters
+        (the layout of torch.optim.SGD.state_dict)."""
+        flat = [p for g in self.param_groups for p in g["params"]]
+        idx = {id(p): i for i, p in enumerate(flat)}
+        groups, k = [], 0
+        for g in self.param_groups:
+            d = {key: v for key, v in g.items() if key != "params"}
+            d["params"] = list(range(k, k + len(g["params"])))
+            k += len(g["params"])
+            groups.append(d)
+        return {"state": {idx[id(p)]: {"momentum_buffer": b} for p, b in self.state.items() if id(p) in idx},
+                "param_groups": groups}
+
+    def load_state_dict(self, sd):
+        flat = [p for g in self.param_groups for p in g["params"]]
+        if len(sd["param_groups"]) != len(self.param_groups):
+            raise ValueError("loaded state dict has a different number of parameter groups")
+        for g, d in zip(self.param_groups, sd["param_groups"]):
+            if len(d["params"]) != len(g["params"]):
+                raise ValueError("loaded state dict contains a parameter group of a different size")
+            g.update({key: v for key, v in d.items() if key != "params"})
+        self.state = {}
+        with torch.no_grad():
+            for i, st in sd["state"].items():
+                p = flat[int(i)]
+                b = st.get("momentum_buffer")
+                if b is not None:
+                    self.state[p] = torch.zeros_like(p, memory_format=torch.preserve_format).copy_(b)
 
     def zero_grad(self, set_to_none=True):
         for g in self.param_groups:
@@ -107,6 +165,9 @@ class ClippedSGD(object):
             stage[1] = torch.cuda.Event()
             stage[1].record()
         sq = torch.empty(1, dtype=torch.float64, device=dev)
+        if self.skipped is None:
+            self.skipped = torch.zeros(1, dtype=torch.int32, device=dev)
+        lr, momentum = self._hyper()
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         L = _lib.lib()
         vp = lambda t: C.c_void_p(t.data_ptr())
@@ -114,7 +175,7 @@ class ClippedSGD(object):
         _lib.check(L.sln_grad_sqnorm_f32(vp(tab[1]), vp(numel), vp(ct), vp(co), nch, CHUNK, vp(partial), vp(sq),
                                          st), "sln_grad_sqnorm_f32")
         _lib.check(L.sln_sgd_clip_step_f32(vp(tab[0]), vp(tab[1]), vp(tab[2]), vp(numel), vp(wd), vp(ct), vp(co),
-                                           nch, CHUNK, vp(sq), float(max_norm), self.lr, self.momentum, st),
+                                           nch, CHUNK, vp(sq), float(max_norm), lr, momentum, vp(self.skipped), st),
                    "sln_sgd_clip_step_f32")
         # caches keyed by the weights' version counters (split weight parts) must see the update
         torch._C._autograd._unsafe_set_version_counter(ps, [p._version + 1 for p in ps])

@@ -49,15 +49,16 @@ def make_batch(config, B, H, W, n_obj=8, seed=1234, device="cuda", anchors_f64=N
 def _calibrate(forward):
     """Run `forward()` while every conv + frozen-BN pair first overwrites the BN's running statistics
     with the statistics of the raw convolution output (so layer k is calibrated on activations
-    normalised by layers < k).  Convolutions stay on the active backend (nn_ops.CALIBRATING); BN layers
-    reached through F.batch_norm directly (the aten backend) are caught by the patch below."""
+    normalised by layers < k).  Convolutions stay on the active backend (nn_ops.CALIBRATING: conv_bn_act
+    refreshes the statistics itself and flags its own F.batch_norm call); BN layers reached through
+    F.batch_norm directly -- not through conv_bn_act -- are calibrated by the patch below."""
     import torch.nn.functional as F
     from . import nn_ops
     orig = F.batch_norm
     count = [0]
 
     def patched(x, rm, rv, w=None, b=None, training=False, momentum=0.1, eps=1e-5):
-        if not training and nn_ops.CALIBRATING is None:
+        if not training and not nn_ops.IN_CALIBRATED_BN:
             with torch.no_grad():
                 rm.copy_(x.mean(dim=(0, 2, 3)))
                 rv.copy_(x.var(dim=(0, 2, 3), unbiased=False).clamp(min=1e-6))

@@ -95,3 +95,63 @@ def test_host_tensors_are_refused():
     p.grad = torch.ones(4)
     with pytest.raises(RuntimeError):
         ClippedSGD([{"params": [p]}], lr=0.1).step(5.0)
+
+
+def test_non_finite_gradient_skips_the_step_on_the_device():
+    """An inf / NaN gradient: no tensor moves, no momentum buffer changes, the device counter says so
+    (the reference's loop `continue`s past unusable batches, model.py:416-418, 433-434)."""
+    from sln_amodal_amd.optim import ClippedSGD
+    ps, gs = _make(5, 1e-3)
+    dev = [torch.nn.Parameter(p.cuda()) for p in ps]
+    opt = ClippedSGD([{"params": dev, "weight_decay": 1e-4}], lr=0.1, momentum=0.9)
+    for p, g in zip(dev, gs[0]):
+        p.grad = g.cuda()
+    opt.step(5.0)
+    before = [p.detach().clone() for p in dev]
+    bufs = [opt.state[p].clone() for p in dev]
+    for bad in (float("nan"), float("inf")):
+        for p, g in zip(dev, gs[1]):
+            p.grad = g.cuda()
+        dev[3].grad[1] = bad
+        n = opt.step(5.0)
+        assert not np.isfinite(float(n))
+        assert all(torch.equal(a, p.detach()) for a, p in zip(before, dev))
+        assert all(torch.equal(b, opt.state[p]) for b, p in zip(bufs, dev))
+    assert opt.skipped_steps() == 2
+    for p, g in zip(dev, gs[2]):                       # the next clean step goes through
+        p.grad = g.cuda()
+    opt.step(5.0)
+    assert opt.skipped_steps() == 2
+    assert not any(torch.equal(a, p.detach()) for a, p in zip(before, dev))
+
+
+def test_param_group_hyperparameters_are_read_at_step_time_and_state_round_trips():
+    from sln_amodal_amd.optim import ClippedSGD
+    ps, gs = _make(9, 1e-3)
+
+    def run(change_lr, reload_at=None):
+        dev = [torch.nn.Parameter(p.cuda()) for p in ps]
+        opt = ClippedSGD([{"params": dev[:5], "weight_decay": 1e-4}, {"params": dev[5:]}], lr=0.1, momentum=0.9)
+        for r in range(3):
+            if r == 1 and change_lr:
+                for g in opt.param_groups:         # what an LR scheduler does
+                    g["lr"] = 0.01
+            if r == reload_at:
+                sd = opt.state_dict()
+                opt = ClippedSGD([{"params": dev[:5], "weight_decay": 1e-4}, {"params": dev[5:]}], lr=0.5, momentum=0.0)
+                opt.load_state_dict(sd)
+            for p, g in zip(dev, gs[r]):
+                p.grad = g.cuda()
+            opt.step(5.0)
+        return [p.detach().clone() for p in dev], opt
+
+    base, _ = run(False)
+    sched, opt = run(True)
+    assert opt.lr == 0.01
+    assert not any(torch.equal(a, b) for a, b in zip(base, sched))
+    # (a change of lr keeps the momentum buffers: compare with the same run reloaded from its state dict)
+    again, _ = run(True, reload_at=2)
+    assert all(torch.equal(a, b) for a, b in zip(sched, again))
+    opt.param_groups[0]["lr"] = 0.3
+    with pytest.raises(ValueError):
+        opt.step(5.0)
