@@ -172,6 +172,11 @@ def check_ranks():
                                    "replicas built different graphs" % (lo, hi, b.n))
 
 
+def saturation_count():
+    """Blocks that clamped a value to +-65504 since the start (host sync; tests / monitoring)."""
+    return sum(int(b.saturated.item()) for b in _books.values())
+
+
 def _slot(owner, key):
     """The scale slot of tensor role `key` of the layer identified by `owner` (its weight Parameter:
     the slot lives on the object, so it dies with the layer)."""
@@ -637,6 +642,26 @@ def folded_shift(bias, bn_scale, bn_shift):
     return out
 
 
+# Parity tests only (tests/test_e2e_gpu.py): callable(owner weight, y) -> bool tensor [n <= N, C, H, W] or None.
+# The ReLU pattern of a layer's output is then FORCED to the given one (a unit that is on keeps its value or
+# gets the smallest positive one, a unit that is off becomes 0), so that a backward pass can be compared with
+# a reference whose units near zero fell the other way -- everything that consumes the output (the next
+# layer, the shortcut, every ReLU mask of the backward pass) sees the patched tensor.
+FORCE_RELU = None
+
+
+def _force_relu(own, y):
+    m = FORCE_RELU(own, y)
+    if m is None:
+        return
+    hit = getattr(y, "_sln_parts", None)
+    n = m.shape[0]
+    with torch.no_grad():
+        y[:n] = torch.where(m, y[:n].clamp_min(1e-30), torch.zeros((), dtype=y.dtype, device=y.device))
+    if hit is not None:      # the epilogue's parts stay valid (a flipped unit is ~1e-7 of the tensor's range)
+        y._sln_parts = ((y._version,) + tuple(hit[0][1:]), hit[1], hit[2])
+
+
 def _check_epoch(ctx, parts):
     """The saved operand parts were quantised with the scales of the epoch the forward ran in; the scale
     tensors saved next to them are live views of the ScaleBook.  After another update_scales() (a second
@@ -692,6 +717,8 @@ class _ConvFn(torch.autograd.Function):
         gzslot = _slot(own, ("gz", OH, OW)) if parts == 2 else None
         y = _fwd(xp, N, H, W, wsrc(weight, parts, False, own), Co, KH, KW, stride, dil, pt, pl, OH, OW, scale,
                  shift, res, relu, cin=Ci, out_parts=FUSE_OUTPUT_SPLIT, xq=xq, yslot=yslot)
+        if FORCE_RELU is not None and relu:
+            _force_relu(own, y)
         need_w = ctx.needs_input_grad[1]
         # identity-shortcut link (Bottleneck.forward): the conv that consumes x (head) and the
         # conv that adds the same x as its residual (tail) share a dict, so that the tail's
@@ -982,6 +1009,8 @@ class _StemFn(torch.autograd.Function):
             scale = scale.detach().contiguous()
         y = _fwd(xp, N, OH, OW, wsrc(w2, parts, False, weight), Co, 1, 1, (1, 1), (1, 1), 0, 0, OH, OW, scale,
                  shift, None, relu, cin=K, xq=xq)
+        if FORCE_RELU is not None and relu:
+            _force_relu(weight, y)
         need_w = ctx.needs_input_grad[1]
         ctx.save_for_backward(xp if need_w else None, scale, y if relu else None, xq if need_w else None)
         ctx.cfg = (N, OH, OW, Co, Ci, KH, KW, K, Kp, parts, relu, bias is not None)

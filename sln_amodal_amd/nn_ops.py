@@ -142,6 +142,9 @@ def conv_bn_act(x, conv, bn=None, relu=False, residual=None, same=False, link=No
     return y
 
 
+FORCE_POOL_ARG = None   # parity tests only: callable(arg [N,OH,OW,C] uint8) -> replacement winning taps or None
+
+
 class _MaxPoolFn(torch.autograd.Function):
     """Clipped-window max-pool on NHWC maps (csrc/maxpool.hip): forward keeps the winning tap per output,
     backward gathers -- every input gradient written once, no memset."""
@@ -156,6 +159,10 @@ class _MaxPoolFn(torch.autograd.Function):
         arg = torch.empty((N, OH, OW, C), dtype=torch.uint8, device=x.device)
         _lib.check(_lib.lib().sln_maxpool_fwd_f32(ops._ptr(xc), N, H, W, C, kernel, stride, pad_top, pad_left, OH, OW,
                                                   ops._ptr(y), ops._ptr(arg), ops._stream()), "sln_maxpool_fwd_f32")
+        if FORCE_POOL_ARG is not None:
+            forced = FORCE_POOL_ARG(arg)
+            if forced is not None:
+                arg = forced.to(torch.uint8).contiguous()
         ctx.save_for_backward(arg)
         ctx.cfg = (N, C, H, W, kernel, stride, pad_top, pad_left, OH, OW)
         return y

@@ -12,6 +12,17 @@ arguments and results, forces the DataLoader to num_workers=0 (so the recorded d
 used) and turns the checkpoint write into a no-op.  Weights are the name-keyed deterministic
 initialisation of tests/_util.e2e_init_ (regenerated from the keys on the test side, not stored).
 
+    python tools/gen_golden_e2e.py --masks   # writes tests/golden/e2e_relu_masks_0.npz only
+
+--masks re-runs scene 0's train step with three more observers: a forward hook on every nn.ReLU of the
+detector (modals.py:276-299, 316, 383, 430, 476) that records the SIGN BITMAP of its output, in call
+order; one on C1's max-pool (modals.py:317) that records the winning tap of every window; and
+`images.requires_grad_(True)` so that the image gradient exists.  Together with full-length slices of
+the C1..C4 weight gradients this lets the GPU test force the reference's discrete choices (which units
+are active, which tap wins) and compare the remaining -- smooth -- arithmetic of the backward pass at
+1e-4 (tests/test_e2e_gpu.py::test_deep_gradients_with_reference_relu_masks).  The run must reproduce
+e2e_train_0's losses exactly (checked).
+
 Third-party stand-ins (harness side, neither is reference code): scipy.misc.imresize -- absent from
 scipy >= 1.3; restated from scipy 1.0's published implementation (bytescale to uint8, PIL resize,
 back to array) -- used by utils.resize_image (identity here: inputs are already IMAGE_MAX_DIM^2) and
@@ -129,7 +140,15 @@ def grab(params, which):
             else params[n].detach().reshape(-1)[:SLICE].clone().numpy() for n in WATCH}
 
 
-def main():
+MASK_WATCH = WATCH + [
+    "fpn.C1.0.bias", "fpn.C2.0.downsample.0.weight", "fpn.C2.1.conv3.weight", "fpn.C3.0.conv1.weight",
+    "fpn.C3.3.conv3.weight", "fpn.C4.0.downsample.0.weight", "fpn.C4.11.conv2.weight", "fpn.C4.22.conv3.weight",
+    "fpn.C5.0.conv1.weight",
+]
+MASK_SLICE = 8192
+
+
+def main(only_masks=False):
     ref_modals, ref_F = ref_harness.install()
     import scipy.misc
     scipy.misc.imresize = imresize
@@ -160,6 +179,10 @@ def main():
     # on every trainable parameter whose name does not contain 'bn'); two clip + step rounds
     # (model.py:441-444) on name-keyed seeded gradients, momentum included in the second.
     model, cfg = build_reference_model(ref_model, ref_config, ref_dl, nn)
+    if only_masks:
+        del model
+        run_mask_scene(locals())
+        return
     rec_opt = {}
 
     def synthetic_epoch(self, datagenerator, optimizer, steps):
@@ -360,5 +383,102 @@ def main():
              final_masks_shape=np.array(r["masks"].shape))
 
 
+def run_mask_scene(env):
+    """Scene 0's reference train step once more, with the observers of --masks (module docstring)."""
+    import torch.nn.functional as F
+    ref_model, ref_config, ref_dl, nn = env["ref_model"], env["ref_config"], env["ref_dl"], env["nn"]
+    ref_train, scenes, tmp, loss_names = env["ref_train"], env["scenes"], env["tmp"], env["loss_names"]
+    real = {k: env[k] for k in ("real_loader", "real_randperm", "real_clip", "real_step", "real_save",
+                                "real_predict", "real_losses")}
+    image, label = scenes[0]
+    model, cfg = build_reference_model(ref_model, ref_config, ref_dl, nn)
+    params = dict(model.named_parameters())
+    ds = StubDataset(ref_train, [image], [label], tmp)
+    rec = {"losses": {}, "relu": [], "pool": None}
+    hooks = []
+    for name, mod in model.named_modules():
+        if name.startswith("GLM_modual"):
+            continue                     # frozen, detached: its units do not shape any gradient
+        if isinstance(mod, nn.ReLU):
+            def hook(m, inp, out, name=name):
+                k = sum(1 for n, _ in rec["relu"] if n == name)
+                rec["relu"].append((name, (out.detach() > 0).numpy()))
+                assert k < 8
+            hooks.append(mod.register_forward_hook(hook))
+        elif isinstance(mod, nn.MaxPool2d) and name == "fpn.C1.4":
+            def pool_hook(m, inp, out):
+                x = inp[0].detach()
+                y, idx = F.max_pool2d(x, m.kernel_size, m.stride, m.padding, return_indices=True)
+                assert torch.equal(y, out.detach())
+                Wp = x.shape[3]
+                ih, iw = idx // Wp, idx % Wp
+                oh = torch.arange(y.shape[2]).view(1, 1, -1, 1)
+                ow = torch.arange(y.shape[3]).view(1, 1, 1, -1)
+                s = m.stride if isinstance(m.stride, int) else m.stride[0]
+                k = m.kernel_size if isinstance(m.kernel_size, int) else m.kernel_size[0]
+                tap = (ih - oh * s) * k + (iw - ow * s)
+                assert int(tap.min()) >= 0 and int(tap.max()) < k * k
+                rec["pool"] = tap.to(torch.uint8).numpy()
+                rec["pool_in_shape"] = tuple(x.shape)
+            hooks.append(mod.register_forward_hook(pool_hook))
+
+    def rec_predict(self, input, mode):
+        input[0].requires_grad_(True)            # observation only: the image gradient then exists
+        rec["images"] = input[0]
+        return real["real_predict"](self, input, mode)
+
+    def rec_clip(parameters, max_norm, *a, **k):
+        rec["grad"] = {n: params[n].grad.detach().reshape(-1)[:MASK_SLICE].clone().numpy() for n in MASK_WATCH}
+        rec["grad_norms"] = {n: float(params[n].grad.norm()) for n in MASK_WATCH}
+        rec["grad_images"] = rec["images"].grad.detach().clone().numpy()
+        return real["real_clip"](parameters, max_norm, *a, **k)
+
+    def wrap_loss(name):
+        def f(*a, **k):
+            r = real["real_losses"][name](*a, **k)
+            rec["losses"][name] = float(r[0] if isinstance(r, tuple) else r)
+            return r
+        return f
+
+    seed = 1000
+    random.seed(seed); np.random.seed(seed); torch.manual_seed(seed)
+    ref_model.MaskRCNN.predict = rec_predict
+    torch.nn.utils.clip_grad_norm_ = rec_clip
+    torch.save = lambda *a, **k: None
+    torch.utils.data.DataLoader = lambda d, **k: real["real_loader"](d, **dict(k, num_workers=0))
+    for n in loss_names:
+        setattr(ref_model, n, wrap_loss(n))
+    try:
+        model.train_model(ds, ds, 0.01, 1, "all")
+    finally:
+        ref_model.MaskRCNN.predict = real["real_predict"]
+        torch.nn.utils.clip_grad_norm_ = real["real_clip"]
+        torch.save = real["real_save"]
+        torch.utils.data.DataLoader = real["real_loader"]
+        for n in loss_names:
+            setattr(ref_model, n, real["real_losses"][n])
+        for h in hooks:
+            h.remove()
+    base = np.load(os.path.join(ROOT, "tests", "golden", "e2e_train_0.npz"))
+    got = np.array([rec["losses"][n] for n in loss_names], dtype=np.float64)
+    assert np.array_equal(got, base["losses"]), (got, base["losses"])
+    for n in WATCH:      # the same step as the e2e_train_0 fixture, bit for bit
+        assert np.array_equal(rec["grad"][n][:SLICE], base["grad/" + n]), n
+    arrs, order, counts = {}, [], {}
+    for name, m in rec["relu"]:
+        k = counts.get(name, 0)
+        counts[name] = k + 1
+        key = "%s#%d" % (name, k)
+        order.append(key)
+        arrs["relu/" + key] = np.packbits(m, axis=None)
+        arrs["relu_shape/" + key] = np.array(m.shape)
+    bits = sum(int(np.prod(arrs["relu_shape/" + k])) for k in order)
+    print("relu calls %d, %.1f M units; pool taps %s" % (len(order), bits / 1e6, rec["pool"].shape))
+    save("e2e_relu_masks_0", relu_order=np.array(order), pool_tap=rec["pool"],
+         pool_in_shape=np.array(rec["pool_in_shape"]), grad_images=rec["grad_images"],
+         names=np.array(MASK_WATCH), grad_norms=np.array([rec["grad_norms"][n] for n in MASK_WATCH]),
+         **{"grad/" + n: v for n, v in rec["grad"].items()}, **arrs)
+
+
 if __name__ == "__main__":
-    main()
+    main(only_masks="--masks" in sys.argv)
