@@ -41,45 +41,108 @@ class InferenceConfig(Amodalfig):
 
 
 class AmodalDataset(object):
-    """Iterable of training batches (dicts, see MaskRCNN.train_step)."""
+    """The dataset of `<name>.npz` ('layer': the uint64 occlusion label, amodal_train.py:238) + `<name>.jpg`
+    pairs.  Two faces:
+      * the reference's per-image methods (`image_ids`, `image_info`, `load_image`, `load_layer2`) that
+        model.Dataset / Functions.load_image_gt call -- host side, numpy;
+      * an iterable of device-resident training BATCHES (dicts, see MaskRCNN.train_step) -- what the
+        train loop consumes.  Per image it follows load_image_gt (Functions.py:675-736) step by step:
+        uint8 squash to IMAGE_MAX_DIM^2 (Pillow BILINEAR = scipy.misc.imresize), nearest zoom of the label
+        with scipy.ndimage.zoom's index map (the label, not its planes, is resized: the decode is per
+        pixel), `random.randint` flip, boxes jittered by `np.random.rand(4)` per instance, class id 1 for
+        every object of the ORIGINAL label; labels stay uint64 on the device (the planes are never built),
+        boxes and RPN targets are computed there."""
 
-    def __init__(self, config, model, root=None, limit=-1, seed=1234, device="cuda", max_objects=8,
-                 rank=0, world=1):
+    def __init__(self, config, model, root=None, limit=-1, seed=1234, device="cuda", max_objects=None,
+                 rank=0, world=1, augment=True):
         self.config, self.model, self.device, self.seed = config, model, device, seed
         self.rank, self.world = rank, world   # data-parallel shard of the file list
-        self.max_objects = max_objects
+        self.augment = augment
         self.files = []
         if root:
             self.files = sorted(glob.glob(os.path.join(root, "**", "*.npz"), recursive=True))
             if limit and limit > 0:
                 self.files = self.files[:limit]
-
-    def _load_real(self, paths):
-        from PIL import Image
-        dim = self.config.IMAGE_MAX_DIM
-        imgs, labs = [], []
-        for p in paths:
-            layer = np.load(p)["layer"].astype(np.uint64)
+        # object slots per image: the label format holds 32 objects; synthetic scenes are drawn with 8
+        self.max_objects = max_objects or (32 if self.files else 8)
+        self.image_info = []
+        for i, p in enumerate(self.files):
             stem = p[:-4]
-            img_path = next((stem + e for e in (".jpg", ".png", ".jpeg") if os.path.exists(stem + e)), None)
-            img = np.asarray(Image.open(img_path).convert("RGB")) if img_path else \
-                np.zeros(layer.shape + (3,), np.uint8)
-            t = torch.from_numpy(img).permute(2, 0, 1)[None].float()
-            imgs.append(torch.nn.functional.interpolate(t, size=(dim, dim), mode="bilinear",
-                                                        align_corners=False)[0])
-            # nearest resize of the label (utils.py:358-362 resize_layer, order 0)
-            ys = (np.arange(dim) * layer.shape[0] / dim).astype(np.int64)
-            xs = (np.arange(dim) * layer.shape[1] / dim).astype(np.int64)
-            labs.append(torch.from_numpy(layer[ys][:, xs].view(np.int64)))
-        mean = torch.tensor(np.asarray(self.config.MEAN_PIXEL), dtype=torch.float32).view(1, 3, 1, 1)
-        images = (torch.stack(imgs) - mean).to(self.device).contiguous(memory_format=torch.channels_last)
-        labels = torch.stack(labs).to(self.device)
-        boxes = extract_bboxes_from_labels(labels, self.max_objects).float()
-        present = (boxes[..., 2] > boxes[..., 0]) & (boxes[..., 3] > boxes[..., 1])
-        ids = present.to(torch.int32)
-        match, bbox = build_rpn_targets((dim, dim, 3), self.model.anchors_f64, ids, boxes, self.config)
+            img = next((stem + e for e in (".jpg", ".png", ".jpeg") if os.path.exists(stem + e)), stem + ".jpg")
+            self.image_info.append({"id": i, "source": "amodal", "path": img, "label": p})
+        self.image_ids = np.arange(len(self.files))
+
+    # ---------------------------------------------------------------- the reference's per-image surface
+    def _layer(self, image_id):
+        info = self.image_info[image_id]
+        return np.load(info["path"][:-4] + ".npz")["layer"].astype(np.uint64)
+
+    def load_image(self, image_id):
+        from PIL import Image
+        info = self.image_info[image_id]
+        if os.path.exists(info["path"]):
+            return np.asarray(Image.open(info["path"]).convert("RGB"))
+        return np.zeros(self._layer(image_id).shape + (3,), np.uint8)
+
+    def load_layer2(self, image_id, config):
+        """[H,W,L,N] bool planes + class ids (all 1), amodal_train.py:236-271."""
+        from .modal.Functions import label_planes_host
+        return label_planes_host(self._layer(image_id), config.NUM_CLASSES - 1)
+
+    # ---------------------------------------------------------------- device-resident batches
+    def _load_real(self, image_ids, draws=None):
+        """Batch dict of the given images.  draws (parity tests): per image {"flip", "jitter" [n,4],
+        "rpn_priority" [A]} replaying the reference's RNG; default: `random` / `np.random` like the
+        reference's worker."""
+        import random
+        from . import utils
+        from .modal.Functions import max_objectID
+        dim, N = self.config.IMAGE_MAX_DIM, self.max_objects
+        imgs, labs, jit, flips = [], [], [], []
+        for k, iid in enumerate(image_ids):
+            d = draws[k] if draws is not None else None
+            layer = self._layer(iid)
+            u8, _window, scale, _pad = utils.resize_image(self.load_image(iid), self.config.IMAGE_MIN_DIM, dim,
+                                                          self.config.IMAGE_PADDING)
+            lab = utils.resize_layer(layer, scale)
+            flip = 0
+            if self.augment:
+                flip = random.randint(0, 1) if d is None else int(d["flip"])
+            if flip:
+                u8, lab = u8[:, ::-1], lab[:, ::-1]
+            imgs.append(torch.from_numpy(np.ascontiguousarray(u8)))
+            labs.append(torch.from_numpy(np.ascontiguousarray(lab).view(np.int64)))
+            # object count of the ORIGINAL label (load_layer2 runs before the resize): one draw of
+            # np.random.rand(4) per object, in order, like utils.extract_bboxes
+            lo = np.unique(layer & np.uint64(0xFFFFFFFF))
+            tops = set(int(v).bit_length() - 1 for v in lo if v)
+            n = 0
+            while n in tops:
+                n += 1
+            if n > N:
+                raise ValueError("image %s has %d objects, the batch holds %d slots" % (iid, n, N))
+            u = np.zeros((N, 4), np.float64)
+            u[:n] = np.random.rand(n, 4) if d is None else np.asarray(d["jitter"], np.float64).reshape(n, 4)
+            jit.append((n, u))
+            flips.append(flip)
+        dev = self.device
+        mean = torch.tensor(np.asarray(self.config.MEAN_PIXEL), dtype=torch.float32, device=dev)
+        images = (torch.stack(imgs).to(dev).float() - mean).permute(0, 3, 1, 2).contiguous(
+            memory_format=torch.channels_last)
+        labels = torch.stack(labs).to(dev)
+        tight = extract_bboxes_from_labels(labels, N)
+        u = torch.from_numpy(np.stack([j[1] for j in jit])).to(dev)
+        boxes = utils.jitter_boxes(tight, u)
+        counts = torch.tensor([j[0] for j in jit], device=dev)
+        ids = (torch.arange(N, device=dev)[None, :] < counts[:, None]).to(torch.int32)
+        boxes = torch.where(ids[..., None] > 0, boxes, torch.zeros_like(boxes)).float()
+        pr = None
+        if draws is not None and all("rpn_priority" in d for d in draws):
+            pr = torch.stack([torch.as_tensor(d["rpn_priority"]) for d in draws]).to(dev)
+        match, bbox = build_rpn_targets((dim, dim, 3), self.model.anchors_f64, ids, boxes, self.config,
+                                        priority=pr)
         return {"images": images, "image_metas": None, "gt_class_ids": ids, "gt_boxes": boxes,
-                "gt_layer": labels, "rpn_match": match.unsqueeze(2), "rpn_bbox": bbox}
+                "gt_layer": labels, "rpn_match": match.unsqueeze(2), "rpn_bbox": bbox, "flipped": flips}
 
     def __iter__(self):
         B, dim, step = self.config.BATCH_SIZE, self.config.IMAGE_MAX_DIM, 0
@@ -87,7 +150,7 @@ class AmodalDataset(object):
             if self.files:
                 # disjoint shards: global step `step` covers files [step*world*B, (step+1)*world*B)
                 idx = [((step * self.world + self.rank) * B + i) % len(self.files) for i in range(B)]
-                yield self._load_real([self.files[i] for i in idx])
+                yield self._load_real(idx)
             else:
                 yield synthetic.make_batch(self.config, B, dim, dim, n_obj=self.max_objects,
                                            seed=self.seed + step, device=self.device,

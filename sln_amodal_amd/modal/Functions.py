@@ -323,6 +323,72 @@ def unmold_image(normalized_images, config):
 
 
 ############################################################
+#  Data generator (host side, one image: Functions.py:675-736)
+############################################################
+
+def label_planes_host(layer, num_layers):
+    """AmodalDataset.load_layer2 (amodal_train.py:236-271) on the host, closed form per pixel: object i
+    (count = max_objectID, Functions.py:1074-1079: the first shift s at which no label's low word has its
+    HIGHEST set bit at s -- the highest low-word bit + 1 unless the tops have a gap) is visible where bit i
+    of the label is set -> plane 0; where bit 32 + i is set it is occluded, at depth
+    rank = popcount(high word & ((1 << i) - 1)) -> plane min(rank + 1, L - 1).
+    layer [H,W] uint64 -> ([H,W,L,N] bool, class_ids [N] int32 all 1) like the reference."""
+    layer = np.ascontiguousarray(layer).astype(np.uint64)
+    lo = (layer & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    hi = (layer >> np.uint64(32)).astype(np.uint32)
+    tops = set(int(v).bit_length() - 1 for v in np.unique(lo) if v)
+    n = 0
+    while n in tops:
+        n += 1
+    H, W = layer.shape
+    L = max(int(num_layers), 1)
+    planes = np.zeros((H, W, L, n), dtype=bool)
+    for i in range(n):
+        planes[:, :, 0, i] |= ((lo >> np.uint32(i)) & np.uint32(1)).astype(bool)
+        occ = ((hi >> np.uint32(i)) & np.uint32(1)).astype(bool)
+        if occ.any():
+            below = hi & np.uint32((1 << i) - 1)
+            rank = np.zeros(below.shape, dtype=np.int64)
+            for b in range(i):
+                rank += (below >> np.uint32(b)) & np.uint32(1)
+            tgt = np.minimum(rank + 1, L - 1)
+            for l in range(L):
+                planes[:, :, l, i] |= occ & (tgt == l)
+    return planes, np.ones([n], dtype=np.int32)
+
+
+def load_image_gt(dataset, config, image_id, augment=False, use_mini_mask=False, draws=None):
+    """Functions.py:675-736 for one image: dataset.load_image + dataset.load_layer2, the squash to
+    IMAGE_MAX_DIM^2 (utils.resize_image / resize_layer), the random horizontal flip
+    (`random.randint(0, 1)`, Functions.py:713), jittered boxes of the amodal masks (utils.extract_bboxes,
+    np.random.rand(4) per instance) and the image meta.  draws = {"flip": 0|1, "jitter": [N,4]} replays
+    recorded draws.  Returns (image uint8 [D,D,3], image_meta, class_ids [N], bbox int32 [N,4],
+    mask_layers uint8 [D,D,N,L]) -- what the reference returns."""
+    import random
+    from .. import utils
+    if use_mini_mask:
+        raise NotImplementedError("USE_MINI_MASK is False on the amodal path (config.py)")
+    image = dataset.load_image(image_id)
+    mask_layers, class_ids = dataset.load_layer2(image_id, config)
+    shape = image.shape
+    image, window, scale, padding = utils.resize_image(image, min_dim=config.IMAGE_MIN_DIM,
+                                                       max_dim=config.IMAGE_MAX_DIM,
+                                                       padding=config.IMAGE_PADDING)
+    mask_layers = utils.resize_layer(mask_layers, scale, padding)
+    if augment:
+        flip = random.randint(0, 1) if draws is None else int(draws["flip"])
+        if flip:
+            image = np.fliplr(image)
+            mask_layers = np.fliplr(mask_layers)
+    amodal_mask = np.sum(mask_layers, axis=2)
+    bbox = utils.extract_bboxes(amodal_mask, None if draws is None else draws["jitter"])
+    active_class_ids = np.ones([128], dtype=np.int32)
+    image_meta = compose_image_meta(image_id, shape, window, active_class_ids)
+    mask_layers = (np.swapaxes(mask_layers, 2, 3) > 0).astype("uint8")
+    return image, image_meta, class_ids, bbox, mask_layers
+
+
+############################################################
 #  RPN targets
 ############################################################
 

@@ -25,7 +25,7 @@ import torch.nn.functional as F
 from . import nn_ops, utils
 from .modal import loss as L
 from .modal.Functions import (build_rpn_targets, compose_image_meta, detection_layer,  # noqa: F401
-                              detection_target_layer, log, mold_image, proposal_layer)
+                              detection_target_layer, load_image_gt, log, mold_image, proposal_layer)
 from .modal.deeplabv2 import DeepLabV2_ResNet101_MSC
 from .modal.modals import (FPN, RPN, Classifier, Mask, ResNet, pyramid_roi_align_image)
 
@@ -39,6 +39,47 @@ LAYER_REGEX = {
     "layer": r"(mask.*)|(layer_decoder.*)",
     "all": ".*",
 }
+
+
+class Dataset(torch.utils.data.Dataset):
+    """model.Dataset (model.py:30-119): one training sample per index, on the host, as the reference's
+    8-tuple (images [3,H,W] f32 mean-subtracted, image_metas, rpn_match [A,1] i32, rpn_bbox [T,4] f32,
+    gt_class_ids [N] i32, gt_boxes [N,4] f32 pixels, gt_layer [L,N,H,W] u8, image_raw [3,H,W] in [0,1]).
+    `dataset` provides load_image / load_layer2 / image_ids (amodal_train.AmodalDataset).  The batched,
+    device-resident equivalent the train loop consumes is AmodalDataset's own iterator; this class is
+    the drop-in surface (and the host-side statement of the same semantics)."""
+
+    def __init__(self, dataset, config, augment=True):
+        self.image_ids = np.copy(dataset.image_ids)
+        self.dataset, self.config, self.augment = dataset, config, augment
+        self.anchors = utils.generate_pyramid_anchors(config.RPN_ANCHOR_SCALES, config.RPN_ANCHOR_RATIOS,
+                                                      config.BACKBONE_SHAPES, config.BACKBONE_STRIDES,
+                                                      config.RPN_ANCHOR_STRIDE)
+
+    def __getitem__(self, image_index, draws=None):
+        image_id = self.image_ids[image_index]
+        image, image_metas, gt_class_ids, gt_boxes, gt_layer = load_image_gt(
+            self.dataset, self.config, image_id, augment=self.augment,
+            use_mini_mask=self.config.USE_MINI_MASK, draws=draws)
+        if not np.any(gt_class_ids > 0):
+            return None
+        # RPN targets: float64 anchor matching (Functions.py:739-847); np.random.choice drops the surplus
+        # positives / negatives -> uniform priorities here (or the replayed keep-priorities of `draws`)
+        pr = None if draws is None or "rpn_priority" not in draws else torch.as_tensor(draws["rpn_priority"])[None]
+        match, bbox = build_rpn_targets(image.shape, torch.from_numpy(self.anchors),
+                                        torch.from_numpy(gt_class_ids)[None], torch.from_numpy(gt_boxes)[None].float(),
+                                        self.config, priority=pr)
+        if gt_boxes.shape[0] > self.config.MAX_GT_INSTANCES:
+            ids = np.random.choice(np.arange(gt_boxes.shape[0]), self.config.MAX_GT_INSTANCES, replace=False)
+            gt_class_ids, gt_boxes, gt_layer = gt_class_ids[ids], gt_boxes[ids], gt_layer[:, :, ids]
+        images = mold_image(image.astype(np.float32), self.config)
+        image_raw = torch.from_numpy(image.copy().transpose(2, 0, 1) / 255)
+        return (torch.from_numpy(images.transpose(2, 0, 1)).float(), torch.from_numpy(image_metas),
+                match[0].unsqueeze(1), bbox[0], torch.from_numpy(gt_class_ids), torch.from_numpy(gt_boxes).float(),
+                torch.from_numpy(gt_layer.transpose(3, 2, 0, 1)), image_raw)
+
+    def __len__(self):
+        return self.image_ids.shape[0]
 
 
 class MaskRCNN(nn.Module):

@@ -57,6 +57,140 @@ def compute_overlaps(boxes1, boxes2):
     return inter / (a2[None, :] + a1[:, None] - inter)
 
 
+############################################################
+#  Dataset side: image / label resize, jittered boxes (utils.py:28-54, 170-362)
+############################################################
+
+def zoom_nearest_index(n_in, n_out):
+    """Source index of every output sample of scipy.ndimage.zoom(order=0, mode='constant') along one axis
+    -- what utils.resize_layer (utils.py:358-362) applies to the label planes: output o reads input
+    floor(o * step + 0.5) with step = (n_in - 1) / (n_out - 1) formed in float64 first (scipy computes it
+    once and multiplies).  -1 = the constant fill (0): where the float64 product o * step lands above
+    n_in - 1 -- it can, by one ulp, at the LAST sample -- scipy's 'constant' mode treats the coordinate
+    as outside the array, so that row / column of the resized planes is empty.  Kept: the planes must
+    equal the reference's, quirk included."""
+    if n_out <= 0:
+        return np.zeros(0, dtype=np.int64)
+    if n_out == 1 or n_in <= 1:
+        return np.zeros(n_out, dtype=np.int64)
+    step = np.float64(n_in - 1) / np.float64(n_out - 1)
+    cc = np.arange(n_out, dtype=np.float64) * step
+    idx = np.floor(cc + 0.5).astype(np.int64)
+    return np.where(cc > np.float64(n_in - 1), -1, np.clip(idx, 0, n_in - 1))
+
+
+def take_zoom(a, ys, xs):
+    """a[ys][:, xs] with -1 entries of the index maps reading the constant fill 0."""
+    out = a[np.maximum(ys, 0)][:, np.maximum(xs, 0)]
+    if (ys < 0).any():
+        out[ys < 0] = 0
+    if (xs < 0).any():
+        out[:, xs < 0] = 0
+    return out
+
+
+def zoom_output_size(n_in, factor):
+    """Length scipy.ndimage.zoom gives an axis of n_in samples: round(n_in * factor), half to even."""
+    return int(round(n_in * factor))
+
+
+def resize_image(image, min_dim=None, max_dim=None, padding=False):
+    """utils.py:351-356: the image is SQUASHED to max_dim x max_dim by scipy.misc.imresize -- for a uint8
+    image that is Pillow's BILINEAR resize (reducing-aware, 8-bit fixed point) -- whatever its aspect
+    ratio; window = the whole square, scale = (max_dim / h, max_dim / w), no padding."""
+    from PIL import Image
+    h, w = image.shape[:2]
+    u8 = np.ascontiguousarray(image)
+    if u8.dtype != np.uint8:
+        raise TypeError("resize_image expects the uint8 image the dataset loads")
+    if (h, w) != (max_dim, max_dim):
+        u8 = np.asarray(Image.fromarray(u8).resize((max_dim, max_dim), Image.BILINEAR))
+    return u8, (0, 0, max_dim, max_dim), (max_dim / h, max_dim / w), [(0, 0), (0, 0), (0, 0)]
+
+
+def resize_layer(mask, scale, padding=None):
+    """utils.py:358-362: nearest-neighbour zoom of [H, W, ...] planes (or of the uint64 label itself: the
+    decode is per pixel, so decoding the resized label equals resizing the decoded planes)."""
+    h, w = mask.shape[:2]
+    ys = zoom_nearest_index(h, zoom_output_size(h, scale[0]))
+    xs = zoom_nearest_index(w, zoom_output_size(w, scale[1]))
+    return take_zoom(mask, ys, xs)
+
+
+def extract_bboxes(mask, jitter=None):
+    """utils.py:28-54: tight boxes of [H, W, N] masks (y2 / x2 exclusive), each perturbed by
+    (u * 2 - 1) * (h, w, h, w) / 15 with u = np.random.rand(4) drawn per instance IN ORDER (also for empty
+    instances), negatives clamped to 0, truncated to int32.  jitter [N, 4]: replayed draws."""
+    n = mask.shape[-1]
+    boxes = np.zeros([n, 4], dtype=np.int32)
+    for i in range(n):
+        m = mask[:, :, i]
+        cols = np.where(np.any(m, axis=0))[0]
+        rows = np.where(np.any(m, axis=1))[0]
+        if cols.shape[0]:
+            x1, x2 = cols[[0, -1]]
+            y1, y2 = rows[[0, -1]]
+            x2 += 1
+            y2 += 1
+        else:
+            x1, x2, y1, y2 = 0, 0, 0, 0
+        u = np.random.rand(4) if jitter is None else np.asarray(jitter[i], np.float64)
+        box = np.array([y1, x1, y2, x2]) + (u * 2 - 1) * (y2 - y1, x2 - x1, y2 - y1, x2 - x1) / 15
+        box[box < 0] = 0
+        boxes[i] = box
+    return boxes.astype(np.int32)
+
+
+def jitter_boxes(tight, u):
+    """The same perturbation on tensors: tight [..., 4] integer boxes, u [..., 4] uniform draws (float64)
+    -> int32 boxes; float64 arithmetic in the reference's order, so a replayed draw gives its box."""
+    t = tight.to(torch.float64)
+    hw = torch.stack([t[..., 2] - t[..., 0], t[..., 3] - t[..., 1]] * 2, dim=-1)
+    box = t + (u.to(torch.float64) * 2 - 1) * hw / 15
+    return torch.where(box < 0, torch.zeros_like(box), box).to(torch.int32)
+
+
+class Dataset(object):
+    """The slice of utils.Dataset (utils.py:170-300) the training path touches: an image list with
+    `image_info` / `image_ids`, `load_image` (RGB uint8) and an empty `load_mask`."""
+
+    def __init__(self, class_map=None):
+        self._image_ids = []
+        self.image_info = []
+        self.class_info = [{"source": "", "id": 0, "name": "BG"}]
+
+    def add_class(self, source, class_id, class_name):
+        for info in self.class_info:
+            if info["source"] == source and info["id"] == class_id:
+                return
+        self.class_info.append({"source": source, "id": class_id, "name": class_name})
+
+    def add_image(self, source, image_id, path, **kwargs):
+        info = {"id": image_id, "source": source, "path": path}
+        info.update(kwargs)
+        self.image_info.append(info)
+
+    def prepare(self, class_map=None):
+        self.num_classes = len(self.class_info)
+        self.class_ids = np.arange(self.num_classes)
+        self.num_images = len(self.image_info)
+        self._image_ids = np.arange(self.num_images)
+
+    @property
+    def image_ids(self):
+        return self._image_ids
+
+    def source_image_link(self, image_id):
+        return self.image_info[image_id]["path"]
+
+    def load_image(self, image_id):
+        from PIL import Image
+        return np.asarray(Image.open(self.image_info[image_id]["path"]).convert("RGB"))
+
+    def load_mask(self, image_id):
+        return np.empty([0, 0, 0]), np.empty([0], np.int32)
+
+
 def reLayerMask(mask_amodal, mask_invis, min_size=64):
     """Encoder of the on-disk uint64 'layer' label (utils.py:531-547): low word bit i = object i
     visible, high word bit i = object i present but occluded; at most 32 objects; followed by the

@@ -173,3 +173,39 @@ def check_fpn_rpn_grads(device, tight, deep_tol):
         grad_close(fp[n].grad, g["fpn_g/" + n], float(g["fpn_gn/" + n]), n, deep_tol if deep else tight)
     for n in [str(s) for s in g["rpn_names"]]:
         grad_close(rp[n].grad, g["rpn_g/" + n], float(g["rpn_gn/" + n]), n, tight)
+
+
+# ------------------------------------------------------------------ real-data loader (f4)
+def write_loader_scene(tmp, g, name="img0"):
+    """The fixture's image (lossless PNG) + label as the dataset's `<name>.png` / `<name>.npz` pair."""
+    import os
+    from PIL import Image
+    Image.fromarray(g["image_u8"]).save(os.path.join(str(tmp), name + ".png"))
+    np.savez(os.path.join(str(tmp), name + ".npz"), layer=g["label"])
+
+
+def loader_draws(g, A):
+    """The reference's recorded draws as AmodalDataset / model.Dataset replay arguments: the flip, the
+    jitter uniforms per instance, and keep-priorities for build_rpn_targets (the anchors np.random.choice
+    dropped get priority 0)."""
+    pr = torch.ones(A)
+    for i in range(int(g["n_choice"])):
+        pr[torch.from_numpy(g["choice%d" % i]).long()] = 0
+    return {"flip": int(g["flip"]), "jitter": g["jitter"], "rpn_priority": pr}
+
+
+def loader_config(dim):
+    from sln_amodal_amd.config import Config
+
+    class C(Config):
+        NAME = "loader"
+        IMAGE_MAX_DIM = dim
+        IMAGE_MIN_DIM = dim
+        NUM_CLASSES = 1 + 1
+
+    return C()
+
+
+def unpack(g, key):
+    shape = tuple(int(v) for v in g[key + "_shape"])
+    return np.unpackbits(g[key])[:int(np.prod(shape))].reshape(shape)

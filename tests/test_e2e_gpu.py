@@ -429,3 +429,101 @@ def test_deep_gradients_with_reference_relu_masks(steps):
     worst["images"] = float(np.linalg.norm(gi - want) / np.linalg.norm(want))
     print("relative L2 gradient errors with forced switches:", {k: "%.1e" % v for k, v in worst.items()})
     assert worst["images"] <= 1e-4, worst["images"]
+
+
+# ------------------------------------------------------------------ f4: on-disk formats on the device
+def test_reference_layout_checkpoint_loads_into_the_gpu_model_and_reproduces_the_reference_step(tmp_path):
+    """SURVEY 8(f4) / model.py:287-302, 366: a checkpoint in the reference's layout -- a plain state_dict
+    with exactly the reference's 1432 keys and shapes (tests/golden/state_dict_keys.json), values
+    name-keyed like the e2e fixtures' -- written with torch.save, found by find_last, loaded by
+    load_weights into a DIFFERENTLY initialised model that already lives on the GPU: every key is
+    consumed, none is missing, and the loaded model reproduces the reference's train step of
+    e2e_train_0 (six losses at 1e-4, RPN outputs 1e-4)."""
+    import json
+    import os
+    from sln_amodal_amd.config import Config
+    from sln_amodal_amd.model import MaskRCNN
+    from tests._util import GOLDEN, e2e_init_
+    keys = json.load(open(os.path.join(GOLDEN, "state_dict_keys.json")))
+
+    class Holder(object):                    # just enough of a module for the name-keyed initialiser
+        def __init__(self):
+            self.sd = {k: (torch.zeros(shape, dtype=torch.int64) if k.endswith("num_batches_tracked")
+                           else torch.zeros(shape)) for k, shape in keys.items()}
+
+        def state_dict(self):
+            return self.sd
+
+    h = Holder()
+    e2e_init_(h)
+
+    class C(Config):
+        NAME = "e2e"
+        IMAGE_MAX_DIM = 128
+        IMAGE_MIN_DIM = 128
+        STRICT_IMAGE_DIVISIBILITY = True
+
+    ckpt_dir = tmp_path / "e2e"
+    os.makedirs(ckpt_dir)
+    path = str(ckpt_dir / "mask_rcnn_e2e_0005.pth")
+    torch.save(h.sd, path)
+    torch.manual_seed(123)
+    m = MaskRCNN(C(), str(tmp_path)).apply_amodal_heads().cuda()
+    assert m.find_last()[1] == path
+    before = m.fpn.C4[5].conv3.weight.detach().clone()
+    res = m.load_state_dict(torch.load(path, map_location="cpu"), strict=True)     # every key, both ways
+    assert not res.missing_keys and not res.unexpected_keys
+    torch.manual_seed(124)
+    m = MaskRCNN(C(), str(tmp_path)).apply_amodal_heads().cuda()
+    m.load_weights(path)                                                           # the reference's entry point
+    assert not torch.equal(before, m.fpn.C4[5].conv3.weight.detach())
+    assert all(p.is_cuda for p in m.parameters())
+    m.set_trainable(".*", exclusive_off=False)
+    for p in m.GLM_modual.parameters():
+        p.requires_grad = False
+    g = golden("e2e_train_0")
+    params = dict(m.named_parameters())
+    for n in [str(s) for s in g["names"]]:
+        assert np.array_equal(params[n].detach().reshape(-1)[:256].cpu().numpy(), g["before/" + n]), n
+    inp, pr = _inputs([g])
+    with torch.no_grad():
+        out = m.predict(inp, mode="training", priorities=_with_reference_proposals([g], pr))
+        loss, parts = m.compute_losses(out, dev(g["rpn_match"]), dev(g["rpn_bbox_target"]))
+    assert rel(out["rpn_class_logits"][0], g["rpn_class_logits"][0]) < 1e-4
+    _check_forward(out, g)
+    for name, want in zip([str(n) for n in g["loss_names"]], g["losses"]):
+        assert abs(float(parts[LOSS_KEYS[name]]) - want) <= 1e-4, name
+
+
+@pytest.mark.parametrize("scene", [0, 1])
+def test_real_data_loader_batch_matches_reference_load_image_gt(scene, tmp_path):
+    """AmodalDataset's device-resident batch (what train_model consumes) against the reference's
+    load_image_gt / model.Dataset item (Functions.py:675-736, model.py:80-116; tools/gen_golden_loader.py)
+    for a non-square uint8 image + `.npz` label, the recorded flip / jitter / anchor draws replayed:
+    the molded image equal (uint8 Pillow squash, then the mean), the label planes -- decoded on the device
+    from the resized uint64 label -- equal, boxes / class ids / RPN targets equal."""
+    from sln_amodal_amd import amodal_train, ops
+    from sln_amodal_amd.model import MaskRCNN
+    from tests._parity import loader_config, loader_draws, unpack, write_loader_scene
+    g = golden("loader_%d" % scene)
+    cfg = loader_config(int(g["dim"]))
+    cfg.ARCHITECTURE = "resnet50"
+    write_loader_scene(tmp_path, g)
+    m = MaskRCNN(cfg, str(tmp_path)).cuda()
+    ds = amodal_train.AmodalDataset(cfg, m, root=str(tmp_path), device="cuda")
+    batch = ds._load_real([0], draws=[loader_draws(g, m.anchors.shape[0])])
+    assert batch["flipped"] == [int(g["flip"])]
+    assert np.array_equal(batch["images"][0].cpu().numpy(), g["images"])
+    n = g["gt_boxes"].shape[0]
+    assert np.array_equal(batch["gt_class_ids"][0, :n].cpu().numpy(), g["gt_class_ids"])
+    assert int(batch["gt_class_ids"][0, n:].sum()) == 0
+    assert np.array_equal(batch["gt_boxes"][0, :n].cpu().numpy(), g["gt_boxes"])
+    planes = ops.label_decode(batch["gt_layer"], cfg.NUM_CLASSES - 1, n)[0]          # [L,N,H,W]
+    assert np.array_equal(planes.cpu().numpy(), unpack(g, "gt_layer"))
+    assert np.array_equal(batch["rpn_match"][0].cpu().numpy(), g["rpn_match"])
+    assert np.allclose(batch["rpn_bbox"][0].cpu().numpy(), g["rpn_bbox"], rtol=1e-6, atol=1e-6)
+    # the iterator draws its own flips / jitter and yields the same structure
+    cfg.BATCH_SIZE = 2
+    it = iter(ds)
+    b2 = next(it)
+    assert b2["images"].shape == (2, 3, 128, 128) and b2["gt_layer"].dtype == torch.int64

@@ -202,3 +202,61 @@ def test_checkpoint_round_trip_and_find_last(tmp_path):
     assert b.epoch == 0
     b.set_log_dir("/logs/coco20171029/mask_rcnn_coco_0007.pth")
     assert b.epoch == 7
+
+
+@pytest.mark.parametrize("scene", [0, 1])
+def test_load_image_gt_and_dataset_item_match_reference(scene, tmp_path):
+    """f4 / SURVEY 8(b): Functions.load_image_gt and model.Dataset.__getitem__ on a non-square uint8 image +
+    `.npz` label against the reference's own (tools/gen_golden_loader.py), with its recorded flip / jitter
+    / anchor draws replayed: resized image, label planes, boxes, class ids, image meta, RPN targets."""
+    from types import SimpleNamespace
+    from sln_amodal_amd import amodal_train, utils
+    from sln_amodal_amd.model import Dataset
+    from sln_amodal_amd.modal.Functions import load_image_gt
+    from tests._parity import loader_config, loader_draws, unpack, write_loader_scene
+    g = golden("loader_%d" % scene)
+    cfg = loader_config(int(g["dim"]))
+    write_loader_scene(tmp_path, g)
+    anchors = utils.generate_pyramid_anchors(cfg.RPN_ANCHOR_SCALES, cfg.RPN_ANCHOR_RATIOS, cfg.BACKBONE_SHAPES,
+                                             cfg.BACKBONE_STRIDES, cfg.RPN_ANCHOR_STRIDE)
+    ds = amodal_train.AmodalDataset(cfg, SimpleNamespace(anchors_f64=torch.from_numpy(anchors)),
+                                    root=str(tmp_path), device="cpu")
+    assert list(ds.image_ids) == [0]
+    assert np.array_equal(ds.load_image(0), g["image_u8"])
+    draws = loader_draws(g, anchors.shape[0])
+    image, meta, ids, bbox, layers = load_image_gt(ds, cfg, 0, augment=True, draws=draws)
+    assert image.dtype == np.uint8 and np.array_equal(image, g["out_image_u8"])
+    assert np.array_equal(meta, g["out_meta"])
+    assert np.array_equal(ids, g["out_class_ids"])
+    assert bbox.dtype == np.int32 and np.array_equal(bbox, g["out_bbox"])
+    assert layers.dtype == np.uint8 and np.array_equal(layers, unpack(g, "out_mask_layers"))
+    item = Dataset(ds, cfg, augment=True).__getitem__(0, draws=draws)
+    images, image_metas, rpn_match, rpn_bbox, gt_class_ids, gt_boxes, gt_layer, image_raw = item
+    assert np.array_equal(images.numpy(), g["images"])
+    assert np.array_equal(image_metas.numpy(), g["image_metas"])
+    assert np.array_equal(rpn_match.numpy(), g["rpn_match"])
+    assert np.allclose(rpn_bbox.numpy(), g["rpn_bbox"], rtol=1e-6, atol=1e-6)
+    assert np.array_equal(gt_class_ids.numpy(), g["gt_class_ids"])
+    assert np.array_equal(gt_boxes.numpy(), g["gt_boxes"])
+    assert np.array_equal(gt_layer.numpy(), unpack(g, "gt_layer"))
+    assert np.allclose(image_raw.numpy(), g["out_image_u8"].transpose(2, 0, 1) / 255)
+
+
+def test_zoom_index_map_is_scipys():
+    """utils.zoom_nearest_index restates scipy.ndimage.zoom(order=0)'s sample map (what utils.resize_layer
+    applies, utils.py:358-362), including the constant fill of a last sample whose float64 coordinate lands
+    one ulp above the array."""
+    import scipy.ndimage
+    from sln_amodal_amd import utils
+    rng = np.random.RandomState(0)
+    fills = 0
+    for _ in range(300):
+        n_in, dim = int(rng.randint(1, 1300)), int(rng.choice([64, 128, 513, 800, 1024]))
+        a = np.arange(n_in, dtype=np.float64) + 1
+        z = scipy.ndimage.zoom(a, zoom=[dim / n_in], order=0)
+        idx = utils.zoom_nearest_index(n_in, utils.zoom_output_size(n_in, dim / n_in))
+        fills += int((idx < 0).sum())
+        assert np.array_equal(z, np.where(idx < 0, 0, a[np.maximum(idx, 0)])), (n_in, dim)
+    m = rng.rand(37, 53, 2, 3) > 0.5
+    sc = (128 / 37, 128 / 53)
+    assert np.array_equal(scipy.ndimage.zoom(m, zoom=[sc[0], sc[1], 1, 1], order=0), utils.resize_layer(m, sc))
