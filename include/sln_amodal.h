@@ -313,6 +313,15 @@ int64_t sln_rle_from_string(const char *s, int64_t len, uint32_t *counts, int64_
  *     (optional): y is written as computed, but y_parts and colsum hold y*post_scale[c]
  *     (product rounded to fp32 first) -- the previous layer's frozen-BN scale when the
  *     fp32 gradient itself is still needed (it is that layer's shortcut gradient).
+ *     Parts-only operands (parts = 2, Cout % 8 == 0): the outputs of a bottleneck's convolutions
+ *     (modal/modals.py:264-301, modal/resnet_deeplab.py:26-71) are read by convolutions, by the next
+ *     shortcut and as ReLU masks only, so their fp32 copy is never written (y = NULL, y_parts set:
+ *     4 B per element instead of 8) and their other two readers take the parts instead:
+ *     residual_parts [2][M][Cout_pad] + residual_scale (device scalar): the shortcut, added as
+ *     (h0 + h1) / s -- the value the next convolution reads of the same tensor (exclusive with
+ *     `residual`); mask_part0 [M][Cout_pad]: part 0 of the tensor whose ReLU pattern masks the output
+ *     (h0 > 0; exclusive with `mask`).  sln_conv_grad_prep_f32 takes the pattern the same way
+ *     (y_part0 instead of y).  SLN_ERR_UNSUPPORTED outside the fp16 x 2 fixed-feature epilogue.
  * sln_conv2d_wgrad_f32        gw [Cout][KH][KW][Cin] fp32 (zeroed by the callee) =
  *     sum over output pixels of gz[pix][co] * x[pix @ tap][ci]; split-K over pixel
  *     ranges, summed in range order through a caller-lent workspace (or with fp32
@@ -382,8 +391,8 @@ int sln_col2im_f32(const float *cols, int N, int H, int W, int C, int KH, int KW
                    int pad_top, int pad_left, int OH, int OW, int K_pad, float *gx, sln_stream_t stream);
 int sln_act_split_f32(const float *x, int64_t M, int C, int C_pad, int parts, uint16_t *out,
                       const float *q_scale, float *q_amax, int32_t *q_saturated, sln_stream_t stream);
-int sln_conv_grad_prep_f32(const float *gy, const float *y, const float *scale, int64_t M, int C,
-                           int C_pad, int parts, float *gu, uint16_t *gz_parts, float *gbias,
+int sln_conv_grad_prep_f32(const float *gy, const float *y, const uint16_t *y_part0, const float *scale,
+                           int64_t M, int C, int C_pad, int parts, float *gu, uint16_t *gz_parts, float *gbias,
                            const float *q_scale, float *q_amax, int32_t *q_saturated,
                            sln_stream_t stream);
 int sln_scale_update_f32(float *amax, float *scale, float *history, int32_t *cursor, int n,
@@ -402,7 +411,8 @@ int sln_conv2d_fwd_ms_f32(const uint16_t *x_parts, int nseg, const int32_t *seg_
                           int relu, const float *mask, const float *post_scale, float *y,
                           uint16_t *y_parts, float *colsum, const float *x_scale,
                           const float *w_scale, const float *y_q_scale, float *y_q_amax,
-                          int32_t *y_q_saturated, sln_stream_t stream);
+                          int32_t *y_q_saturated, const uint16_t *residual_parts, const float *residual_scale,
+                          const uint16_t *mask_part0, sln_stream_t stream);
 /* Tile edge (128 or 256) of the forward kernel the two functions above use for M output pixels,
  * Cout channels, K = KH*KW*Cin and `parts`: host-side rule, no GPU work (csrc/conv.hip). */
 int sln_conv_fwd_tile(int64_t M, int Cout, int64_t K, int parts);

@@ -96,7 +96,6 @@ class AmodalDataset(object):
         reference's worker."""
         import random
         from . import utils
-        from .modal.Functions import max_objectID
         dim, N = self.config.IMAGE_MAX_DIM, self.max_objects
         imgs, labs, jit, flips = [], [], [], []
         for k, iid in enumerate(image_ids):
@@ -110,7 +109,7 @@ class AmodalDataset(object):
                 flip = random.randint(0, 1) if d is None else int(d["flip"])
             if flip:
                 u8, lab = u8[:, ::-1], lab[:, ::-1]
-            imgs.append(torch.from_numpy(np.ascontiguousarray(u8)))
+            imgs.append(torch.from_numpy(np.array(u8)))          # (a writable, contiguous copy)
             labs.append(torch.from_numpy(np.ascontiguousarray(lab).view(np.int64)))
             # object count of the ORIGINAL label (load_layer2 runs before the resize): one draw of
             # np.random.rand(4) per object, in order, like utils.extract_bboxes
@@ -126,8 +125,10 @@ class AmodalDataset(object):
             jit.append((n, u))
             flips.append(flip)
         dev = self.device
-        mean = torch.tensor(np.asarray(self.config.MEAN_PIXEL), dtype=torch.float32, device=dev)
-        images = (torch.stack(imgs).to(dev).float() - mean).permute(0, 3, 1, 2).contiguous(
+        # mold_image (Functions.py:654-660): uint8 -> float32, minus the float64 mean pixel (the difference is
+        # formed in float64 and rounded to float32 once, by the later .float())
+        mean = torch.tensor(np.asarray(self.config.MEAN_PIXEL, np.float64), dtype=torch.float64, device=dev)
+        images = (torch.stack(imgs).to(dev).double() - mean).float().permute(0, 3, 1, 2).contiguous(
             memory_format=torch.channels_last)
         labels = torch.stack(labs).to(dev)
         tight = extract_bboxes_from_labels(labels, N)

@@ -39,6 +39,11 @@ LINK_STATS = [0, 0]   # shortcut gradients handed over by tails / consumed by he
 PAIR_STATS = [0, 0]   # strided data-gradient pairs merged on the lattice / merged into a stride-1 reader's gradient
 PAIR_STRIDED = os.environ.get("SLN_PAIR_STRIDED", "1") != "0"             # A/B switch
 FUSE_OUTPUT_SPLIT = True   # conv epilogue writes the output's parts (skips the next act_split)
+# conv_bn_act(parts_only=True) on the autograd path (a bottleneck's conv outputs: read by convolutions, by the
+# next shortcut and as ReLU masks only): the fp32 copy is not written, the shortcut and the masks are taken
+# from the parts.  "0": A/B switch (fp32 + parts, 8 + 4 B per block-output element instead of 4 + 4)
+PARTS_ONLY_TRAIN = os.environ.get("SLN_PARTS_ONLY_TRAIN", "1") != "0"
+PO_STATS = [0, 0, 0]   # outputs produced as parts only / shortcuts read from parts / masks read from part 0
 # weight gradients: split-K partial sums through a workspace + ordered reduce (bit-reproducible) instead of
 # fp32 atomics; "0" restores the atomics for A/B runs
 DETERMINISTIC_WGRAD = os.environ.get("SLN_DETERMINISTIC_WGRAD", "1") != "0"
@@ -364,6 +369,41 @@ def _act_split(xc2d, M, C, parts, slot):
     return out
 
 
+_NAN = {}
+
+
+def _placeholder(shape, device):
+    """What stands in the autograd graph for an activation that exists as parts only: a zero-stride view of
+    one NaN (no memory; anything that mistakes it for data turns into NaN at once).  The parts travel on
+    the tensor object (`_sln_parts`, `_sln_po`)."""
+    n = _NAN.get(device)
+    if n is None:
+        n = _NAN[device] = torch.full((1,), float("nan"), dtype=torch.float32, device=device)
+    return n.expand(shape)
+
+
+def parts_only_of(t):
+    """(parts [2, M, C_pad], scale) of a parts-only activation, None for an ordinary tensor."""
+    po = getattr(t, "_sln_po", None)
+    if po is None:
+        return None
+    if po[2] != SCALE_EPOCH[0]:
+        raise RuntimeError("a parts-only activation outlived update_scales(): it cannot be split again")
+    return po[0], po[1]
+
+
+def materialize(t):
+    """fp32 [N,C,H,W] (NHWC in memory) value of a parts-only activation, (h0 + h1) / s -- what its readers
+    see; an ordinary tensor is returned as it is.  Debugging, tests, and readers outside the conv stack."""
+    po = parts_only_of(t)
+    if po is None:
+        return t
+    parts, q = po
+    N, C, H, W = t.shape
+    v = (parts[0].view(torch.float16).float() + parts[1].view(torch.float16).float()) / q
+    return v[:, :C].reshape(N, H, W, C).permute(0, 3, 1, 2)
+
+
 def act_parts(x, parts=None, owner=None, key=None):
     """x logical [N,C,H,W] (NHWC in memory) -> (parts [P, N*H*W, C_pad], scale or None).  Cached on
     the tensor object: one activation often feeds several convs (block input -> conv1 +
@@ -373,6 +413,9 @@ def act_parts(x, parts=None, owner=None, key=None):
     hit = getattr(x, "_sln_parts", None)
     if hit is not None and hit[0] == (x._version, parts, SCALE_EPOCH[0]):
         return hit[1], hit[2]
+    if getattr(x, "_sln_po", None) is not None:
+        raise RuntimeError("a parts-only activation (%d x fp16, scale epoch %s) cannot be re-split as %d parts in "
+                           "epoch %d" % (2, x._sln_po[2], parts, SCALE_EPOCH[0]))
     xc = _nhwc(x.detach())
     N, C, H, W = xc.shape
     slot = None
@@ -428,11 +471,12 @@ def wsrc(weight, parts=None, flip_swap=False, owner=None):
 
 def _fwd(xparts, N, H, W, w, Cout, KH, KW, stride, dil, pt, pl, OH, OW, scale, shift, residual,
          relu, cin=None, out_parts=False, mask=None, want_y=True, want_colsum=False, post_scale=None,
-         xq=None, yslot=None):
+         xq=None, yslot=None, res_parts=None, mask_parts=None):
     """One launch of the forward kernel.  w = wsrc(weight, parts, flip_swap, owner).  mask /
     want_y=False / want_colsum: the epilogue extras of sln_conv2d_fwd_ms_f32 (a data gradient that
     is consumed only as the previous layer's prepared gradient).  xq: the activation parts' scale
-    tensor (PARTS = 2); yslot: the scale slot of the output's own parts.  Returns y, or
+    tensor (PARTS = 2); yslot: the scale slot of the output's own parts.  res_parts = (parts, scale) /
+    mask_parts = parts: the residual / the ReLU pattern of a tensor that exists as parts only.  Returns y, or
     (y_or_None, parts, colsum) when any extra is used; the parts' scale is yslot.scale."""
     import ctypes as C
     dev = xparts.device
@@ -441,7 +485,16 @@ def _fwd(xparts, N, H, W, w, Cout, KH, KW, stride, dil, pt, pl, OH, OW, scale, s
     wparts, wq = _split_weights(weight, flip, P, owner, layout)
     cin = cin or xparts.shape[2]
     y = torch.empty((N, OH, OW, Cout), dtype=torch.float32, device=dev).permute(0, 3, 1, 2) if want_y else None
-    plain = mask is None and want_y and not want_colsum and post_scale is None
+    plain = mask is None and mask_parts is None and want_y and not want_colsum and post_scale is None
+    if (res_parts is not None or mask_parts is not None) and (P != 2 or Cout % 8 or layout == TILED256):
+        # (the fixed-feature epilogue only: whole 16-B row groups, not the round-1 256^2 kernel)
+        if res_parts is not None:
+            rq = res_parts[1]
+            rv = (res_parts[0][0].view(torch.float16).float() + res_parts[0][1].view(torch.float16).float()) / rq
+            residual, res_parts = rv[:, :Cout].contiguous(), None
+        if mask_parts is not None:
+            mask = (mask_parts[0].view(torch.float16)[:, :Cout] > 0).float().contiguous()
+            mask_parts = None
     if out_parts and P == 2:
         if yslot is None:
             raise RuntimeError("two-part output split needs a scale slot")
@@ -463,16 +516,24 @@ def _fwd(xparts, N, H, W, w, Cout, KH, KW, stride, dil, pt, pl, OH, OW, scale, s
         stride[0], stride[1], dil[0], dil[1], pt, pl, pb, pr, ops._ptr(scale), ops._ptr(shift),
         ops._ptr(residual), 1 if relu else 0, ops._ptr(mask), ops._ptr(post_scale), ops._ptr(y),
         ops._ptr(yp), ops._ptr(cs), ops._ptr(xq), ops._ptr(wq), *_q3(yslot if yp is not None and P == 2 else None),
+        ops._ptr(res_parts[0]) if res_parts is not None else None,
+        ops._ptr(res_parts[1]) if res_parts is not None else None,
+        ops._ptr(mask_parts) if mask_parts is not None else None,
         ops._stream()), "sln_conv2d_fwd_ms_f32")
+    if res_parts is not None:
+        PO_STATS[1] += 1
+    if mask_parts is not None:
+        PO_STATS[2] += 1
     _prof_end(e0, 2.0 * N * OH * OW * Cout * KH * KW * cin,
               _fwd_kernel_name(layout, P),
               "fwd N%d %dx%d C%d->%d k%d s%d d%d" % (N, H, W, cin, Cout, KH, stride[0], dil[0]),
-              _nbytes(xparts, wparts, residual, mask), _nbytes(y, yp))
+              _nbytes(xparts, wparts, residual, mask, res_parts[0] if res_parts is not None else None) +
+              (_nbytes(mask_parts) // 2 if mask_parts is not None else 0), _nbytes(y, yp))
     if fresh:   # first use of this output's slot: exact amax pass over y, then the split
         yp = _act_split(_nhwc(y), N * OH * OW, Cout, P, yslot)
     if yp is not None and y is not None and post_scale is None:
         y._sln_parts = ((y._version, P, SCALE_EPOCH[0]), yp, yslot.scale if P == 2 else None)
-    if mask is not None or not want_y or want_colsum:
+    if mask is not None or mask_parts is not None or not want_y or want_colsum:
         return y, yp, cs
     return y
 
@@ -553,9 +614,20 @@ def conv_bn_act_ms(x, conv, bn, relu, residual, pads, parts_only=False):
         alloc = torch.empty if Co % 8 == 0 else torch.zeros
         yp = alloc((parts, M, _pad8(Co)), dtype=torch.bfloat16, device=dev)
     # (a fresh slot bootstraps its scale from the fp32 output: that one time it is written)
-    y = None if (parts_only and yp is not None) else torch.empty((M, Co), dtype=torch.float32, device=dev)
+    y = None if (parts_only and yp is not None and parts == 2) else \
+        torch.empty((M, Co), dtype=torch.float32, device=dev)
     seg = (C.c_int32 * (3 * len(x.segs)))(*[v for s_ in x.segs for v in s_])
     res = residual.y if residual is not None else None
+    rparts = rq = None
+    if residual is not None and res is None:          # a parts-only shortcut: added from its parts
+        if residual.parts is None or residual.parts.shape[0] != 2:
+            raise ValueError("parts-only residual without fp16 x 2 parts")
+        if parts == 2 and Co % 8 == 0 and layout != TILED256 and tuple(residual.parts.shape[1:]) == (M, Co):
+            rparts, rq = residual.parts, residual.q
+            PO_STATS[1] += 1
+        else:
+            res = ((residual.parts[0].view(torch.float16).float() + residual.parts[1].view(torch.float16).float())
+                   / residual.q)[:, :Co].contiguous()
     if res is not None and tuple(res.shape) != (M, Co):
         raise ValueError("residual does not match the convolution output")
     e0 = _prof_begin()
@@ -563,10 +635,11 @@ def conv_bn_act_ms(x, conv, bn, relu, residual, pads, parts_only=False):
         ops._ptr(xp), len(x.segs), seg, xp.shape[2], ops._ptr(wp), layout, parts, Co, KH, KW, sh, sw, dh, dw,
         pt, pl, pb, pr, ops._ptr(scale), ops._ptr(shift), ops._ptr(res), 1 if relu else 0, None, None,
         ops._ptr(y), ops._ptr(yp), None, ops._ptr(xq), ops._ptr(wq),
-        *_q3(yslot if yp is not None else None), ops._stream()), "sln_conv2d_fwd_ms_f32")
+        *_q3(yslot if yp is not None else None), ops._ptr(rparts), ops._ptr(rq), None, ops._stream()),
+        "sln_conv2d_fwd_ms_f32")
     _prof_end(e0, flops, _fwd_kernel_name(layout, parts),
               "fwd ms%s C%d->%d k%d s%d d%d" % ("+".join("%dx%d" % (h, w) for _, h, w in x.segs), Ci, Co, KH, sh, dh),
-              _nbytes(xp, wp, res), _nbytes(y, yp))
+              _nbytes(xp, wp, res, rparts), _nbytes(y, yp))
     if fresh:
         yp = _act_split(y, M, Co, parts, yslot)
     out = MultiScale(osegs, y, yp)
@@ -581,7 +654,13 @@ def _grad_prep(gy, y, scale, want_gu, want_bias, parts, slot=None):
     M, Cp = N * H * W, _pad8(C)
     gz = torch.empty((parts, M, Cp), dtype=torch.bfloat16, device=gy.device)
     gu = gy
-    write_gu = want_gu and y is not None
+    y16 = None
+    if y is not None and y.dtype == torch.bfloat16:     # the layer's output exists as parts only: [2, M, Cp]
+        if parts != 2 or tuple(y.shape[1:]) != (M, Cp):
+            raise RuntimeError("parts-only ReLU pattern does not match the gradient")
+        y16, y = y, None
+        PO_STATS[2] += 1
+    write_gu = want_gu and (y is not None or y16 is not None)
     if write_gu:
         gu = torch.empty((N, H, W, C), dtype=torch.float32, device=gy.device).permute(0, 3, 1, 2)
     gb = torch.empty((C,), dtype=torch.float32, device=gy.device) if want_bias else None
@@ -590,7 +669,7 @@ def _grad_prep(gy, y, scale, want_gu, want_bias, parts, slot=None):
 
     def launch(dst):
         _lib.check(_lib.lib().sln_conv_grad_prep_f32(
-            ops._ptr(gy), ops._ptr(y), ops._ptr(scale), M, C, Cp, parts,
+            ops._ptr(gy), ops._ptr(y), ops._ptr(y16), ops._ptr(scale), M, C, Cp, parts,
             ops._ptr(gu) if write_gu else None, ops._ptr(dst), ops._ptr(gb), *_q3(slot if parts == 2 else None),
             ops._stream()), "sln_conv_grad_prep_f32")
     if parts == 2 and slot.fresh:
@@ -654,8 +733,17 @@ def _force_relu(own, y):
     m = FORCE_RELU(own, y)
     if m is None:
         return
-    hit = getattr(y, "_sln_parts", None)
     n = m.shape[0]
+    po = getattr(y, "_sln_po", None)
+    if po is not None:       # parts only: the pattern is the sign of part 0
+        N, C, H, W = y.shape
+        h = po[0].view(torch.int16).view(2, N, H, W, po[0].shape[2])[..., :C]
+        mm = m.permute(0, 2, 3, 1)
+        one, zero = torch.ones((), dtype=torch.int16, device=h.device), torch.zeros((), dtype=torch.int16, device=h.device)
+        h[0, :n] = torch.where(mm, torch.where(h[0, :n] > 0, h[0, :n], one), zero)   # (bits 1 = the least fp16)
+        h[1, :n] = torch.where(mm, h[1, :n], zero)
+        return
+    hit = getattr(y, "_sln_parts", None)
     with torch.no_grad():
         y[:n] = torch.where(m, y[:n].clamp_min(1e-30), torch.zeros((), dtype=y.dtype, device=y.device))
     if hit is not None:      # the epilogue's parts stay valid (a flipped unit is ~1e-7 of the tensor's range)
@@ -690,7 +778,7 @@ class hold_scales(object):
 class _ConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, bn_scale, bn_shift, residual, relu, stride, dil, pads, link=None,
-                chain_in=None, chain_out=None, owner=None, pair=None):
+                chain_in=None, chain_out=None, owner=None, pair=None, parts_only=False):
         parts = PARTS
         if PARTS_NOGRAD and not any(ctx.needs_input_grad):
             parts = PARTS_NOGRAD
@@ -708,15 +796,33 @@ class _ConvFn(torch.autograd.Function):
             shift = shift.detach().contiguous()
         if scale is not None:
             scale = scale.detach().contiguous()
-        res = _nhwc(residual.detach()) if residual is not None else None
+        res_po = parts_only_of(residual) if residual is not None else None
+        res = _nhwc(residual.detach()) if (residual is not None and res_po is None) else None
         # scale slots (PARTS = 2) live on the layer's persistent weight object: `owner` when the weight
         # passed in is a temporary view of it (Linear / deconv reshapes)
         own = owner if owner is not None else weight
         xp, xq = act_parts(x, parts, owner=own)
+        x_po = getattr(x, "_sln_po", None) is not None
         yslot = _slot(own, ("y", OH, OW)) if (parts == 2 and FUSE_OUTPUT_SPLIT) else None
         gzslot = _slot(own, ("gz", OH, OW)) if parts == 2 else None
-        y = _fwd(xp, N, H, W, wsrc(weight, parts, False, own), Co, KH, KW, stride, dil, pt, pl, OH, OW, scale,
-                 shift, res, relu, cin=Ci, out_parts=FUSE_OUTPUT_SPLIT, xq=xq, yslot=yslot)
+        # parts-only output: this layer's readers are convolutions, a shortcut add and ReLU masks (the caller
+        # says so); needs a scale with a history (the first step bootstraps it from the fp32 output) and the
+        # fixed-feature epilogue
+        po = bool(parts_only and PARTS_ONLY_TRAIN and parts == 2 and FUSE_OUTPUT_SPLIT and not yslot.fresh and
+                  Co % 8 == 0 and
+                  weights_layout(N * OH * OW, Co, xp.shape[2], KH * KW, parts, xp.shape[1]) != TILED256)
+        if po:
+            _, yp_, _ = _fwd(xp, N, H, W, wsrc(weight, parts, False, own), Co, KH, KW, stride, dil, pt, pl, OH, OW,
+                             scale, shift, res, relu, cin=Ci, out_parts=True, want_y=False, xq=xq, yslot=yslot,
+                             res_parts=res_po)
+            y = _placeholder((N, Co, OH, OW), xp.device)
+            y._sln_parts = ((y._version, parts, SCALE_EPOCH[0]), yp_, yslot.scale)
+            y._sln_po = (yp_, yslot.scale, SCALE_EPOCH[0])
+            PO_STATS[0] += 1
+        else:
+            yp_ = None
+            y = _fwd(xp, N, H, W, wsrc(weight, parts, False, own), Co, KH, KW, stride, dil, pt, pl, OH, OW, scale,
+                     shift, res, relu, cin=Ci, out_parts=FUSE_OUTPUT_SPLIT, xq=xq, yslot=yslot, res_parts=res_po)
         if FORCE_RELU is not None and relu:
             _force_relu(own, y)
         need_w = ctx.needs_input_grad[1]
@@ -778,8 +884,10 @@ class _ConvFn(torch.autograd.Function):
         # the producer's ReLU mask is this layer's own input: saved here as an input tensor
         # (the shared dict must not hold activations: a dict -> output -> grad_fn -> ctx -> dict
         # cycle through the C++ graph would never be collected)
-        mask_x = x if (ctx.chain_in is not None and chain_in["relu"]) else None
-        ctx.save_for_backward(xp if need_w else None, weight, scale, y if relu else None, mask_x,
+        # (a parts-only tensor's ReLU pattern is the sign of its part 0: the parts themselves are saved -- bf16
+        # dtype marks them in backward -- no fp32 copy of the activation exists anywhere)
+        mask_x = (xp if x_po else x) if (ctx.chain_in is not None and chain_in["relu"]) else None
+        ctx.save_for_backward(xp if need_w else None, weight, scale, (yp_ if po else y) if relu else None, mask_x,
                               xq if need_w else None)
         ctx.cfg = (stride, dil, pads, relu, bias is not None, residual is not None, (N, Ci, H, W),
                    parts)
@@ -837,6 +945,11 @@ class _ConvFn(torch.autograd.Function):
         else:
             gz, g_res, g_bias = _grad_prep(gy, y, scale, want_res, want_bias, parts, slot=ctx.gzslot)
             gzq = ctx.gzslot.scale if parts == 2 else None
+
+        def mask_kw(m):      # the producer's ReLU pattern: its fp32 output, or its parts (part 0's sign)
+            if m is None:
+                return {}
+            return dict(mask_parts=m) if m.dtype == torch.bfloat16 else dict(mask=_nhwc(m))
         if ctx.link_tail is not None and g_res is not None:
             ctx.link_tail["idgrad"] = g_res     # consumed by the head's data gradient below
             g_res = None
@@ -864,10 +977,9 @@ class _ConvFn(torch.autograd.Function):
                 ci = ctx.chain_in
                 _, gz_up, gb_up = _fwd(gz, N, OH, OW, wt, Ci, KH, KW, (1, 1), dil, dil[0] * (KH - 1) - pt,
                                        dil[1] * (KW - 1) - pl, H, W, None, None, _nhwc(ci.pop("partial")), False,
-                                       cin=Co, out_parts=True,
-                                       mask=_nhwc(mask_x) if mask_x is not None else None, want_y=False,
+                                       cin=Co, out_parts=True, want_y=False,
                                        want_colsum=ci["want_bias"], post_scale=ci["scale"],
-                                       yslot=ci["gz_slot"], **qs)
+                                       yslot=ci["gz_slot"], **mask_kw(mask_x), **qs)
                 ci["gz"], ci["gbias"] = gz_up, gb_up
                 ci["gzq"] = ci["gz_slot"].scale if parts == 2 else None
                 gx = None
@@ -877,9 +989,9 @@ class _ConvFn(torch.autograd.Function):
                 gx, gz_up, gb_up = _fwd(gz, N, OH, OW, wt, Ci, KH, KW, (1, 1), dil, dil[0] * (KH - 1) - pt,
                                         dil[1] * (KW - 1) - pl, H, W, None, None,
                                         _nhwc(id_grad) if id_grad is not None else None, False, cin=Co,
-                                        out_parts=True, mask=_nhwc(mask_x), want_y=True,
+                                        out_parts=True, want_y=True,
                                         want_colsum=ci["want_bias"], post_scale=ci["scale"],
-                                        yslot=ci["gz_slot"], **qs)
+                                        yslot=ci["gz_slot"], **mask_kw(mask_x), **qs)
                 ci["gz"], ci["gbias"], ci["gu_ref"], ci["gu_version"] = gz_up, gb_up, gx, gx._version
                 ci["gzq"] = ci["gz_slot"].scale if parts == 2 else None
                 CHAIN_STATS[0] += 1
@@ -887,8 +999,9 @@ class _ConvFn(torch.autograd.Function):
                 ci = ctx.chain_in
                 _, gz_up, gb_up = _fwd(gz, N, OH, OW, wt, Ci, KH, KW, (1, 1), dil, dil[0] * (KH - 1) - pt,
                                        dil[1] * (KW - 1) - pl, H, W, ci["scale"], None, None, False, cin=Co,
-                                       out_parts=True, mask=_nhwc(mask_x) if mask_x is not None else None,
-                                       want_y=False, want_colsum=ci["want_bias"], yslot=ci["gz_slot"], **qs)
+                                       out_parts=True,
+                                       want_y=False, want_colsum=ci["want_bias"], yslot=ci["gz_slot"],
+                                       **mask_kw(mask_x), **qs)
                 ci["gz"], ci["gbias"] = gz_up, gb_up
                 ci["gzq"] = ci["gz_slot"].scale if parts == 2 else None
                 gx = _dummy_grad(weight.device).expand(N, Ci, H, W)   # never read: see chain_out above
@@ -957,7 +1070,7 @@ class _ConvFn(torch.autograd.Function):
                       "wgrad N%d %dx%d C%d->%d k%d s%d d%d" % (N, H, W, Ci, Co, KH, stride[0], dil[0]),
                       _nbytes(gz, xp), _nbytes(gw_t))
             gw = gw_t if own_layout else gw_t.permute(0, 3, 1, 2)  # logical [Co,Ci,KH,KW]
-        return gx, gw, g_bias, None, None, g_res, None, None, None, None, None, None, None, None, None
+        return gx, gw, g_bias, None, None, g_res, None, None, None, None, None, None, None, None, None, None
 
 
 class _StemFn(torch.autograd.Function):
@@ -1083,11 +1196,12 @@ def _dummy_grad(device):
 
 
 def conv_bn_act(x, conv, bn, relu, residual, pads, weight=None, link=None, chain_in=None, chain_out=None,
-                stride=None, pair=None):
+                stride=None, pair=None, parts_only=False):
     from .nn_ops import bn_affine
     scale = shift = None
     if bn is not None:
         scale, shift = bn_affine(bn)
     return _ConvFn.apply(x, conv.weight if weight is None else weight, conv.bias, scale, shift,
                          residual, bool(relu), tuple(stride or conv.stride), tuple(conv.dilation), tuple(pads),
-                         link if LINK_SHORTCUT_GRAD else None, chain_in, chain_out, conv.weight, pair)
+                         link if LINK_SHORTCUT_GRAD else None, chain_in, chain_out, conv.weight, pair,
+                         bool(parts_only))

@@ -16,6 +16,9 @@ FAST = [f for f in sorted(os.listdir(HERE)) if f.endswith(".hip") and f not in E
 COMMON = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall",
           "-Wno-unused-function", "-fgpu-rdc" if False else "-fno-gpu-rdc"]
 EXACT_FLAGS = ["-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math"]
+# conv.hip: the epilogue's slab loop must unroll completely whatever the number of epilogue variants inlined
+# into it (its index selects accumulator REGISTERS; a rolled loop would put the 128 accumulators in scratch)
+FAST_FLAGS = ["-mllvm", "-pragma-unroll-threshold=131072", "-Werror=pass-failed"]
 
 
 def _stale(out, deps):
@@ -32,7 +35,7 @@ def build(force=False, verbose=False):
         obj = os.path.join(HERE, name.replace(".hip", ".o"))
         objs.append(obj)
         if force or _stale(obj, [src] + hdrs):
-            flags = COMMON + (EXACT_FLAGS if name in EXACT else [])
+            flags = COMMON + (EXACT_FLAGS if name in EXACT else FAST_FLAGS)
             cmd = [hipcc, "-c", "-x", "hip", src, "-o", obj] + flags
             if verbose:
                 print(" ".join(cmd))

@@ -257,8 +257,26 @@ __global__ __launch_bounds__(256) void col2im_kernel(const float *__restrict__ c
 // A thread keeps one channel quad and walks rows (no index division, bias sums stay in
 // registers until the end); two rows are in flight per iteration.
 __device__ __forceinline__ void grad_prep_row(const float *__restrict__ gy, const float *__restrict__ y,
-                                              long m, int c, int C, bool vec, float g[4]) {
+                                              const __bf16 *__restrict__ y16, int Cp, long m, int c, int C,
+                                              bool vec, float g[4]) {
+    // ReLU pattern: the layer's fp32 output y, or part 0 of an output that exists as parts only (y16, rows of
+    // Cp 16-bit words: h0 > 0)
     g[0] = g[1] = g[2] = g[3] = 0.f;
+    if (y16) {
+        const h16x4 k4 = *(const h16x4 *)(y16 + m * Cp + c);      // (c + 3 < Cp: Cp % 8 == 0, c % 4 == 0)
+        if (vec) {
+            const float4 v = *(const float4 *)(gy + m * C + c);
+            g[0] = v.x; g[1] = v.y; g[2] = v.z; g[3] = v.w;
+        } else {
+            for (int j = 0; j < 4; ++j)
+                if (c + j < C) g[j] = gy[m * C + c + j];
+        }
+        if (!(k4.x > (_Float16)0)) g[0] = 0.f;
+        if (!(k4.y > (_Float16)0)) g[1] = 0.f;
+        if (!(k4.z > (_Float16)0)) g[2] = 0.f;
+        if (!(k4.w > (_Float16)0)) g[3] = 0.f;
+        return;
+    }
     if (vec) {
         const float4 v = *(const float4 *)(gy + m * C + c);
         g[0] = v.x; g[1] = v.y; g[2] = v.z; g[3] = v.w;
@@ -311,6 +329,7 @@ __device__ __forceinline__ void grad_prep_emit(float g[4], long m, int c, int C,
 template <int P>
 __global__ __launch_bounds__(256) void grad_prep_kernel(const float *__restrict__ gy,
                                                         const float *__restrict__ y,
+                                                        const __bf16 *__restrict__ y16,
                                                         const float *__restrict__ scale, long M, int C,
                                                         int Cp, float *__restrict__ gu,
                                                         __bf16 *__restrict__ parts,
@@ -337,14 +356,14 @@ __global__ __launch_bounds__(256) void grad_prep_kernel(const float *__restrict_
             long m = (long)blockIdx.x * R + r0;
             for (; m + rstep < M; m += 2 * rstep) {
                 float g0[4], g1[4];
-                grad_prep_row(gy, y, m, c, C, vec, g0);
-                grad_prep_row(gy, y, m + rstep, c, C, vec, g1);
+                grad_prep_row(gy, y, y16, Cp, m, c, C, vec, g0);
+                grad_prep_row(gy, y, y16, Cp, m + rstep, c, C, vec, g1);
                 grad_prep_emit<P>(g0, m, c, C, Cp, vec, sc, acc, pstride, gu, parts, qs, amx, sat);
                 grad_prep_emit<P>(g1, m + rstep, c, C, Cp, vec, sc, acc, pstride, gu, parts, qs, amx, sat);
             }
             if (m < M) {
                 float g0[4];
-                grad_prep_row(gy, y, m, c, C, vec, g0);
+                grad_prep_row(gy, y, y16, Cp, m, c, C, vec, g0);
                 grad_prep_emit<P>(g0, m, c, C, Cp, vec, sc, acc, pstride, gu, parts, qs, amx, sat);
             }
         }
@@ -640,6 +659,11 @@ struct ConvParams {
     // record of the output's own parts
     const float *x_scale, *w_scale;
     SplitScale yq;
+    // P = 2, fixed-feature epilogue only: operands that exist as PARTS ONLY (a bottleneck's conv outputs have no
+    // reader but convolutions, the next shortcut and ReLU masks: their fp32 copy is never written)
+    const __bf16 *res_parts;    // [2][M][Cop] parts of the residual (value (h0 + h1) / *res_scale) or null
+    const float *res_scale;     // device scalar (NULL = 1)
+    const __bf16 *mask_part0;   // [M][Cop] part 0 of the tensor whose ReLU pattern masks the output (h0 > 0) or null
     long x_part_stride, w_part_stride, y_part_stride;
     int Cop;
     int Cin, Cout, KH, KW, sh, sw, dh, dw, pt, pl, relu;
@@ -797,9 +821,11 @@ __device__ __forceinline__ void epilogue_slab(const ConvParams &p, const float *
 // (stamps, tools/conv_stamps.py: the slab calls themselves, not their barriers or the store drain) -- more
 // than the whole k-loop of a K = 256 layer; 17-40 k with this one.  Same arithmetic per element as
 // epilogue_slab + split4<2> (bit-identical y, parts and column sums up to their summation order).
-template <int NCOLQ, int LD, int NTHREADS, bool RES, bool PARTS>
+template <int NCOLQ, int LD, int NTHREADS, int RES, bool PARTS>
 __device__ __forceinline__ void epilogue_slab_f16(const ConvParams &p, const float *stage, int m_base, int n0,
                                                   int t, float *s_colsum, float alpha, float yqs, float &amx) {
+    // RES: 0 no residual, 1 fp32 residual, 2 residual from its two fp16 parts ((h0 + h1) / s_res: what the
+    // next convolution reads of the same tensor -- a block output that exists as parts only)
     constexpr int RG = NTHREADS / NCOLQ;
     constexpr int NQ = 64 / RG;
     const int c = n0 + 4 * (t & (NCOLQ - 1));
@@ -813,8 +839,12 @@ __device__ __forceinline__ void epilogue_slab_f16(const ConvParams &p, const flo
     if (p.shift) sf = *(const float4 *)(p.shift + c);
     const long o0 = (long)(m_base + row0) * p.Cout + c;
     const long ostep = (long)RG * p.Cout;
-    float4 res4[NQ];
-    if (RES) {
+    const long q0 = (long)(m_base + row0) * p.Cop + c;       // the same element in a [M][Cop] parts row
+    const long pstep = (long)RG * p.Cop;
+    float4 res4[RES == 1 ? NQ : 1];
+    h16x4 rp0[RES == 2 ? NQ : 1], rp1[RES == 2 ? NQ : 1];
+    float rinv = 1.f;
+    if (RES == 1) {
         const float *r = p.residual + o0;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
@@ -822,19 +852,31 @@ __device__ __forceinline__ void epilogue_slab_f16(const ConvParams &p, const flo
             r += ostep;
         }
     }
-    // backward extras (uniform per launch): the producer's ReLU mask, a scale applied to the parts and
-    // column sums only, per-channel sums of what the parts hold (the previous layer's bias gradient)
+    if (RES == 2) {
+        rinv = 1.0f / (p.res_scale ? *p.res_scale : 1.f);
+        const __bf16 *r0 = p.res_parts + q0, *r1 = r0 + p.y_part_stride;
+        const h16x4 z4 = {};
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const bool ok = (m_base + row0 + RG * q) < p.M;
+            rp0[q] = ok ? *(const h16x4 *)r0 : z4;
+            rp1[q] = ok ? *(const h16x4 *)r1 : z4;
+            r0 += pstep; r1 += pstep;
+        }
+    }
+    // backward extras (uniform per launch): the producer's ReLU mask (its fp32 output, or part 0 of an output
+    // that exists as parts only), a scale applied to the parts and column sums only, per-channel sums of what
+    // the parts hold (the previous layer's bias gradient)
     const float *mk = p.mask ? p.mask + o0 : nullptr;
+    const __bf16 *mk16 = p.mask_part0 ? p.mask_part0 + q0 : nullptr;
     float4 ps4 = make_float4(1.f, 1.f, 1.f, 1.f);
     if (p.post_scale) ps4 = *(const float4 *)(p.post_scale + c);
     float csum[4] = {0.f, 0.f, 0.f, 0.f};
     float *yp = p.y ? p.y + o0 : nullptr;
     __bf16 *p0 = nullptr, *p1 = nullptr;
-    long pstep = 0;
     if (PARTS) {
-        p0 = p.yparts + (long)(m_base + row0) * p.Cop + c;
+        p0 = p.yparts + q0;
         p1 = p0 + p.y_part_stride;
-        pstep = (long)RG * p.Cop;
     }
     const float *sg = stage + row0 * LD + 4 * (t & (NCOLQ - 1));
     const bool relu = p.relu != 0;
@@ -843,8 +885,15 @@ __device__ __forceinline__ void epilogue_slab_f16(const ConvParams &p, const flo
         if (m_base + row0 + RG * q < p.M) {
             const float4 a4 = *(const float4 *)(sg + q * RG * LD);
             float v[4] = {a4.x * sc.x + sf.x, a4.y * sc.y + sf.y, a4.z * sc.z + sf.z, a4.w * sc.w + sf.w};
-            if (RES) {
+            if (RES == 1) {
                 v[0] += res4[q].x; v[1] += res4[q].y; v[2] += res4[q].z; v[3] += res4[q].w;
+            }
+            if (RES == 2) {
+                const h16x4 a0 = rp0[q], a1 = rp1[q];
+                v[0] += ((float)a0.x + (float)a1.x) * rinv;
+                v[1] += ((float)a0.y + (float)a1.y) * rinv;
+                v[2] += ((float)a0.z + (float)a1.z) * rinv;
+                v[3] += ((float)a0.w + (float)a1.w) * rinv;
             }
             if (relu) {
 #pragma unroll
@@ -856,6 +905,13 @@ __device__ __forceinline__ void epilogue_slab_f16(const ConvParams &p, const flo
                 if (!(k4.y > 0.f)) v[1] = 0.f;
                 if (!(k4.z > 0.f)) v[2] = 0.f;
                 if (!(k4.w > 0.f)) v[3] = 0.f;
+            }
+            if (mk16) {
+                const h16x4 k4 = *(const h16x4 *)mk16;
+                if (!(k4.x > (_Float16)0)) v[0] = 0.f;
+                if (!(k4.y > (_Float16)0)) v[1] = 0.f;
+                if (!(k4.z > (_Float16)0)) v[2] = 0.f;
+                if (!(k4.w > (_Float16)0)) v[3] = 0.f;
             }
             if (yp) *(float4 *)yp = make_float4(v[0], v[1], v[2], v[3]);
             if (p.post_scale) {
@@ -878,6 +934,7 @@ __device__ __forceinline__ void epilogue_slab_f16(const ConvParams &p, const flo
         }
         if (yp) yp += ostep;
         if (mk) mk += ostep;
+        if (mk16) mk16 += pstep;
         if (PARTS) { p0 += pstep; p1 += pstep; }
     }
     if (p.colsum) {   // the row groups share a column: combine in LDS first
@@ -893,13 +950,15 @@ __device__ __forceinline__ void epilogue_any(const ConvParams &p, const float *s
                                              float *s_colsum, float alpha, float yqs, float &amx, bool &sat,
                                              bool fast) {
     if (P == 2 && fast) {
-        if (p.residual) {
-            if (p.yparts) epilogue_slab_f16<NCOLQ, LD, NTHREADS, true, true>(p, stage, m_base, n0, t, s_colsum, alpha, yqs, amx);
-            else epilogue_slab_f16<NCOLQ, LD, NTHREADS, true, false>(p, stage, m_base, n0, t, s_colsum, alpha, yqs, amx);
+#define SLN_EPI(R, Q) epilogue_slab_f16<NCOLQ, LD, NTHREADS, R, Q>(p, stage, m_base, n0, t, s_colsum, alpha, yqs, amx)
+        if (p.res_parts) {
+            if (p.yparts) SLN_EPI(2, true); else SLN_EPI(2, false);
+        } else if (p.residual) {
+            if (p.yparts) SLN_EPI(1, true); else SLN_EPI(1, false);
         } else {
-            if (p.yparts) epilogue_slab_f16<NCOLQ, LD, NTHREADS, false, true>(p, stage, m_base, n0, t, s_colsum, alpha, yqs, amx);
-            else epilogue_slab_f16<NCOLQ, LD, NTHREADS, false, false>(p, stage, m_base, n0, t, s_colsum, alpha, yqs, amx);
+            if (p.yparts) SLN_EPI(0, true); else SLN_EPI(0, false);
         }
+#undef SLN_EPI
     } else {
         epilogue_slab<P, NCOLQ, LD, NTHREADS>(p, stage, m_base, n0, t, s_colsum, alpha, yqs, amx, sat);
     }
@@ -2358,13 +2417,15 @@ extern "C" int sln_col2im_f32(const float *cols, int N, int H, int W, int C, int
     return sln_launch_status();
 }
 
-extern "C" int sln_conv_grad_prep_f32(const float *gy, const float *y, const float *scale, int64_t M,
+extern "C" int sln_conv_grad_prep_f32(const float *gy, const float *y, const uint16_t *y_part0,
+                                      const float *scale, int64_t M,
                                       int C, int C_pad, int parts, float *gu, uint16_t *gz_parts,
                                       float *gbias, const float *q_scale, float *q_amax,
                                       int32_t *q_saturated, sln_stream_t stream) {
     sln_enter();
     if (M < 0 || C < 1 || C_pad < C || (C_pad & 7) || parts < 2 || parts > 3) return SLN_ERR_INVALID_ARG;
     if (!gy || (!gz_parts && !(parts == 2 && q_amax))) return SLN_ERR_INVALID_ARG;
+    if (y_part0 && (y || parts != 2)) return SLN_ERR_INVALID_ARG;   // one ReLU pattern; fp16 parts only
     hipStream_t st = (hipStream_t)stream;
     if (gz_parts && gbias && hipMemsetAsync(gbias, 0, sizeof(float) * C, st) != hipSuccess) return SLN_ERR_LAUNCH;
     if (M == 0) return SLN_OK;
@@ -2374,11 +2435,11 @@ extern "C" int sln_conv_grad_prep_f32(const float *gy, const float *y, const flo
     if (grid > 2048) grid = 2048;
     const SplitScale q = {q_scale, q_amax, q_saturated};
     if (parts == 2)
-        hipLaunchKernelGGL(grad_prep_kernel<2>, dim3((unsigned)grid), dim3(256), 0, st, gy, y, scale, (long)M,
-                           C, C_pad, gu, (__bf16 *)gz_parts, gbias, q);
+        hipLaunchKernelGGL(grad_prep_kernel<2>, dim3((unsigned)grid), dim3(256), 0, st, gy, y,
+                           (const __bf16 *)y_part0, scale, (long)M, C, C_pad, gu, (__bf16 *)gz_parts, gbias, q);
     else
-        hipLaunchKernelGGL(grad_prep_kernel<3>, dim3((unsigned)grid), dim3(256), 0, st, gy, y, scale, (long)M,
-                           C, C_pad, gu, (__bf16 *)gz_parts, gbias, q);
+        hipLaunchKernelGGL(grad_prep_kernel<3>, dim3((unsigned)grid), dim3(256), 0, st, gy, y,
+                           (const __bf16 *)nullptr, scale, (long)M, C, C_pad, gu, (__bf16 *)gz_parts, gbias, q);
     return sln_launch_status();
 }
 
@@ -2420,8 +2481,11 @@ extern "C" int sln_conv2d_fwd_ms_f32(const uint16_t *x_parts, int nseg, const in
                                      const float *mask, const float *post_scale, float *y,
                                      uint16_t *y_parts, float *colsum, const float *x_scale,
                                      const float *w_scale, const float *y_q_scale, float *y_q_amax,
-                                     int32_t *y_q_saturated, sln_stream_t stream) {
+                                     int32_t *y_q_saturated, const uint16_t *residual_parts,
+                                     const float *residual_scale, const uint16_t *mask_part0,
+                                     sln_stream_t stream) {
     sln_enter();
+    if ((residual_parts && residual) || (mask_part0 && mask)) return SLN_ERR_INVALID_ARG;
     if (!x_parts || !w_parts || (!y && !y_parts) || !seg_nhw || nseg < 1 || nseg > SLN_MAX_SEG || Cin < 1 || Cout < 1 ||
         KH < 1 || KW < 1 || stride_h < 1 || stride_w < 1 || dil_h < 1 || dil_w < 1)
         return SLN_ERR_INVALID_ARG;
@@ -2455,6 +2519,8 @@ extern "C" int sln_conv2d_fwd_ms_f32(const uint16_t *x_parts, int nseg, const in
     p.yparts = (__bf16 *)y_parts; p.mask = mask; p.colsum = colsum; p.post_scale = post_scale;
     p.x_scale = x_scale; p.w_scale = w_scale;
     p.yq.scale = y_q_scale; p.yq.amax = y_q_amax; p.yq.saturated = y_q_saturated;
+    p.res_parts = (const __bf16 *)residual_parts; p.res_scale = residual_scale;
+    p.mask_part0 = (const __bf16 *)mask_part0;
     p.Cop = (Cout + 7) / 8 * 8;
     p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW;
     p.sh = stride_h; p.sw = stride_w; p.dh = dil_h; p.dw = dil_w; p.pt = pad_top; p.pl = pad_left;
@@ -2470,6 +2536,12 @@ extern "C" int sln_conv2d_fwd_ms_f32(const uint16_t *x_parts, int nseg, const in
     // the 256x256 kernel DMAs the weights in its own LDS-image order, the 128x128 kernel reads rows
     if (w_layout != sln_conv_fwd_weights_layout(M, Cout, Cin, KH * KW, parts, Min)) return SLN_ERR_INVALID_ARG;
     p.w_tiled = w_layout;
+    if (residual_parts || mask_part0) {
+        // parts-only operands of the epilogue exist in the fixed-feature slab only: fp16 x 2, whole 16-B row
+        // groups, and not the round-1 256^2 kernel (operands beyond the 4-GiB buffer range)
+        if (parts != 2 || (Cout & 7) || w_layout == SLN_WEIGHTS_TILED256) return SLN_ERR_UNSUPPORTED;
+        p.dbg &= ~16;
+    }
     const long gm2 = sln_div_up(M, T2), gn2 = sln_div_up(Cout, T2);
     const long nb2 = gm2 * gn2;
     if (use256) {
@@ -2521,7 +2593,7 @@ extern "C" int sln_conv2d_fwd_f32(const uint16_t *x_parts, int N, int H, int W, 
     return sln_conv2d_fwd_ms_f32(x_parts, 1, seg, Cin, w_parts, w_layout, parts, Cout, KH, KW, stride_h, stride_w,
                                  dil_h, dil_w, pad_top, pad_left, pad_bottom, pad_right, scale, shift,
                                  residual, relu, nullptr, nullptr, y, y_parts, nullptr, x_scale, w_scale,
-                                 y_q_scale, y_q_amax, y_q_saturated, stream);
+                                 y_q_scale, y_q_amax, y_q_saturated, nullptr, nullptr, nullptr, stream);
 }
 
 // Which weight-gradient kernel sln_conv2d_wgrad_f32 uses: 256 = conv_wgrad256_kernel (one (tap, 256 Cout

@@ -321,6 +321,11 @@ class Bottleneck(nn.Module):
     def forward(self, x):
         conv = nn_ops.conv_bn_act
         residual, link, pair = x, {}, None
+        # Every tensor this block produces is read by convolutions, by a shortcut add and as a ReLU mask only
+        # (the block output too: the next block, the next stage's strided pair, an FPN lateral), so none of
+        # them needs an fp32 copy in HBM (nn_ops.conv_bn_act parts_only); `parts_only_output = False` on the
+        # module makes the block hand out an ordinary tensor (stand-alone use)
+        po = True
         if self.downsample is not None:
             pair = {} if self.stride != 1 else None      # conv1 and the downsample: same x, same stride lattice
             if pair is not None:
@@ -328,17 +333,18 @@ class Bottleneck(nn.Module):
                     x._sln_pair = pair                    # a later stride-1 reader of x (the FPN lateral) joins in
                 except Exception:
                     pass
-            residual, link = conv(x, self.downsample[0], self.downsample[1], pair=pair), None
+            residual, link = conv(x, self.downsample[0], self.downsample[1], pair=pair, parts_only=po), None
         c12, c23 = {}, {}   # conv1 -> conv2 -> conv3: each output has exactly one reader
         # block output -> next block: inside a stage the next identity block (its conv1, and its
         # shortcut through `link`) is the only reader; the dict travels on the tensor object and a
         # second reader is detected in backward (conv_hip._ConvFn)
         cx_in = getattr(x, "_sln_chain", None) if link is not None else None
         cx_out = {}
-        out = conv(x, self.conv1, self.bn1, relu=True, link=link, chain_in=cx_in, chain_out=c12, pair=pair)
-        out = conv(out, self.conv2, self.bn2, relu=True, same=True, chain_in=c12, chain_out=c23)
+        out = conv(x, self.conv1, self.bn1, relu=True, link=link, chain_in=cx_in, chain_out=c12, pair=pair,
+                   parts_only=po)
+        out = conv(out, self.conv2, self.bn2, relu=True, same=True, chain_in=c12, chain_out=c23, parts_only=po)
         out = conv(out, self.conv3, self.bn3, relu=True, residual=residual, link=link, chain_in=c23,
-                   chain_out=cx_out)
+                   chain_out=cx_out, parts_only=po and getattr(self, "parts_only_output", False))
         if cx_out.get("active"):
             out._sln_chain = cx_out
         return out
@@ -375,6 +381,9 @@ class ResNet(nn.Module):
     def forward(self, x):
         for stage in self.stages():
             x = stage(x)
+        if x.is_cuda:      # stand-alone use: a real tensor (inside FPN the stages are called one by one)
+            from .. import conv_hip
+            x = conv_hip.materialize(x)
         return x
 
     def stages(self):
@@ -390,6 +399,8 @@ class ResNet(nn.Module):
         self.inplanes = planes * block.expansion
         for _ in range(1, blocks):
             layers.append(block(self.inplanes, planes))
+        for b in layers:       # inside a stage every block output has known readers (Bottleneck.forward)
+            b.parts_only_output = True
         return nn.Sequential(*layers)
 
 

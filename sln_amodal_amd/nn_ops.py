@@ -77,7 +77,9 @@ def conv_bn_act(x, conv, bn=None, relu=False, residual=None, same=False, link=No
           (one as input, one as residual); HIP backend only, see conv_hip._ConvFn.
     chain_out / chain_in: dict shared by a conv (chain_out) and the ONLY conv that reads its
           output (chain_in): lets the reader's backward prepare this layer's gradient.
-    parts_only: (packed, forward-only GLM scales) the output feeds convolutions only: no fp32 copy.
+    parts_only: the output is read by convolutions, as the next shortcut and as a ReLU mask only (a bottleneck's
+          convolutions): no fp32 copy is written, the result is a placeholder that carries the parts
+          (conv_hip.parts_only_of / materialize).  HIP backend, fp16 x 2 operands; ignored elsewhere.
     pair: dict shared by the two strided 1x1 convs that read the same x (a stage's first block)."""
     if CALIBRATING is not None and bn is not None:
         # statistics pass (synthetic.calibrate_*): the raw convolution on the same backend, its output's
@@ -120,7 +122,8 @@ def conv_bn_act(x, conv, bn=None, relu=False, residual=None, same=False, link=No
             w2 = conv.weight.permute(0, 2, 3, 1).reshape(conv.out_channels, kh * kw * C, 1, 1)
             return hip.conv_bn_act(xr, conv, bn, relu, None, (0, 0, 0, 0), weight=w2, stride=(1, 1))
         return hip.conv_bn_act(x, conv, bn, relu, residual, (pt, pb, pl, pr), link=link,
-                               chain_in=chain_in, chain_out=chain_out, pair=pair)
+                               chain_in=chain_in, chain_out=chain_out, pair=pair,
+                               parts_only=parts_only and PARTS_ONLY)
     if hip is not None and not isinstance(x, hip.MultiScale) and hip.is_stem(conv, x) and residual is None:
         return hip.stem_conv_bn_act(x, conv, bn, relu, (pt, pb, pl, pr))   # 3-channel 7x7/2 stems
     if BACKEND != "torch" and x.is_cuda:

@@ -563,14 +563,16 @@ def _relu_margin(net64, x64):
     return worst
 
 
-@pytest.mark.parametrize("parts", [3, 2])
-def test_bottleneck_stack_gradients_match_fp64_in_both_formats(parts, monkeypatch):
+@pytest.mark.parametrize("parts,po_out", [(3, False), (2, False), (2, True)])
+def test_bottleneck_stack_gradients_match_fp64_in_both_formats(parts, po_out, monkeypatch):
     """Three bottlenecks (every backward fusion on), two training-style passes so that the PARTS = 2
     chains are active in the second: dx and every weight gradient against an fp64 copy of the stack,
     relative L2 <= 2e-5.  ONE ReLU unit whose pre-activation is within the formats' ~2e-7 forward
     error of zero switches and costs ~5e-3 here (seen with seed 21: fp64 0.0 vs 1.2e-7), so the input
     is drawn until the fp64 stack has no pre-activation closer to zero than 1e-6 of its layer's
-    maximum (5x the forward error) -- the test is about the backward arithmetic, not about that cliff."""
+    maximum (5x the forward error) -- the test is about the backward arithmetic, not about that cliff.
+    po_out: the first two block outputs exist as parts only, like inside a ResNet stage (no fp32 copy: the
+    next shortcut is added from the parts, the ReLU masks are part 0's sign) -- same bounds."""
     from sln_amodal_amd import conv_hip, nn_ops
     from sln_amodal_amd.modal.modals import Bottleneck
     from tests._util import key_init_
@@ -587,6 +589,9 @@ def test_bottleneck_stack_gradients_match_fp64_in_both_formats(parts, monkeypatc
         return net_
 
     net, ref = build(), build().double()
+    if po_out:
+        net[0].parts_only_output = net[1].parts_only_output = True
+    po0 = list(conv_hip.PO_STATS)
     nn_ops.BACKEND = "torch"
     try:
         for seed in range(100, 400):
@@ -611,6 +616,11 @@ def test_bottleneck_stack_gradients_match_fp64_in_both_formats(parts, monkeypatc
         y = net(x)
         y.backward(up)
     assert conv_hip.CHAIN_STATS[0] > 0 and conv_hip.CHAIN_STATS[0] == conv_hip.CHAIN_STATS[1]
+    made, shortcuts, masks = [a - b for a, b in zip(conv_hip.PO_STATS, po0)]
+    if parts == 2:      # second pass: conv1 / conv2 / downsample of every block (+ two block outputs)
+        assert made == 7 + (2 if po_out else 0) and shortcuts == 1 + (2 if po_out else 0) and masks >= made - 1
+    else:
+        assert made == shortcuts == masks == 0
     got = {k: p.grad.double() for k, p in net.named_parameters() if p.grad is not None}
     assert ((y.double() - yr).abs().max() / yr.abs().max()).item() < 5e-6
     rl2 = lambda a, b: ((a - b).norm() / b.norm()).item()
