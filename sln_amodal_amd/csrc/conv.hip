@@ -944,12 +944,165 @@ __device__ __forceinline__ void epilogue_slab_f16(const ConvParams &p, const flo
     }
 }
 
+// The slab with EIGHT channels per thread, for outputs that carry parts and whose rows are whole 32-B groups
+// (Cout % 8 == 0: every backbone / head layer): a part's store is then 16 B per lane -- half the store
+// instructions of the four-channel slab for the same bytes.  These epilogues are bound by the number of memory
+// instructions they issue, not by bytes or arithmetic (tools/hbm_layers.py: on the 128^2 kernel a parts-only
+// output, 2 x 8-B stores per four elements, took 18 % longer than an fp32-only one, 1 x 16-B store, for the
+// same 4 B per element; MI355X_MICROARCH.md "store-ISSUE-bound" tails).  Thread t owns columns
+// 8*(t % NCOL8)..+7 of rows t/NCOL8 + RG*q.  Same arithmetic per element as epilogue_slab_f16.
+typedef __attribute__((ext_vector_type(8))) _Float16 h16x8_t;
+template <int NCOL8, int LD, int NTHREADS, int RES>
+__device__ __forceinline__ void epilogue_slab_w8(const ConvParams &p, const float *stage, int m_base, int n0,
+                                                 int t, float *s_colsum, float alpha, float yqs, float &amx) {
+    constexpr int RG = NTHREADS / NCOL8;
+    constexpr int NQ = 64 / RG;
+    const int cg = t & (NCOL8 - 1);
+    const int c = n0 + 8 * cg;
+    if (c >= p.Cout) return;
+    const int row0 = t / NCOL8;
+    float sc[8], sf[8], ps8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sc[e] = alpha; sf[e] = 0.f; ps8[e] = 1.f; }
+    if (p.scale) {
+        const float4 s0 = *(const float4 *)(p.scale + c), s1 = *(const float4 *)(p.scale + c + 4);
+        sc[0] = s0.x * alpha; sc[1] = s0.y * alpha; sc[2] = s0.z * alpha; sc[3] = s0.w * alpha;
+        sc[4] = s1.x * alpha; sc[5] = s1.y * alpha; sc[6] = s1.z * alpha; sc[7] = s1.w * alpha;
+    }
+    if (p.shift) {
+        const float4 s0 = *(const float4 *)(p.shift + c), s1 = *(const float4 *)(p.shift + c + 4);
+        sf[0] = s0.x; sf[1] = s0.y; sf[2] = s0.z; sf[3] = s0.w; sf[4] = s1.x; sf[5] = s1.y; sf[6] = s1.z; sf[7] = s1.w;
+    }
+    if (p.post_scale) {
+        const float4 s0 = *(const float4 *)(p.post_scale + c), s1 = *(const float4 *)(p.post_scale + c + 4);
+        ps8[0] = s0.x; ps8[1] = s0.y; ps8[2] = s0.z; ps8[3] = s0.w; ps8[4] = s1.x; ps8[5] = s1.y; ps8[6] = s1.z; ps8[7] = s1.w;
+    }
+    const long o0 = (long)(m_base + row0) * p.Cout + c;      // (Cop == Cout here)
+    const long ostep = (long)RG * p.Cout;
+    float4 ra[RES == 1 ? NQ : 1], rb[RES == 1 ? NQ : 1];
+    h16x8_t rp0[RES == 2 ? NQ : 1], rp1[RES == 2 ? NQ : 1];
+    float rinv = 1.f;
+    if (RES == 1) {
+        const float *r = p.residual + o0;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const bool ok = (m_base + row0 + RG * q) < p.M;
+            ra[q] = ok ? *(const float4 *)r : make_float4(0.f, 0.f, 0.f, 0.f);
+            rb[q] = ok ? *(const float4 *)(r + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            r += ostep;
+        }
+    }
+    if (RES == 2) {
+        rinv = 1.0f / (p.res_scale ? *p.res_scale : 1.f);
+        const __bf16 *r0 = p.res_parts + o0, *r1 = r0 + p.y_part_stride;
+        const h16x8_t z8 = {};
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const bool ok = (m_base + row0 + RG * q) < p.M;
+            rp0[q] = ok ? *(const h16x8_t *)r0 : z8;
+            rp1[q] = ok ? *(const h16x8_t *)r1 : z8;
+            r0 += ostep; r1 += ostep;
+        }
+    }
+    const float *mk = p.mask ? p.mask + o0 : nullptr;
+    const __bf16 *mk16 = p.mask_part0 ? p.mask_part0 + o0 : nullptr;
+    float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float *yp = p.y ? p.y + o0 : nullptr;
+    __bf16 *p0 = p.yparts + o0, *p1 = p0 + p.y_part_stride;
+    const float *sg = stage + row0 * LD + 8 * cg;
+    const bool relu = p.relu != 0;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        if (m_base + row0 + RG * q < p.M) {
+            const float4 a0 = *(const float4 *)(sg + q * RG * LD), a1 = *(const float4 *)(sg + q * RG * LD + 4);
+            float v[8] = {a0.x * sc[0] + sf[0], a0.y * sc[1] + sf[1], a0.z * sc[2] + sf[2], a0.w * sc[3] + sf[3],
+                          a1.x * sc[4] + sf[4], a1.y * sc[5] + sf[5], a1.z * sc[6] + sf[6], a1.w * sc[7] + sf[7]};
+            if (RES == 1) {
+                v[0] += ra[q].x; v[1] += ra[q].y; v[2] += ra[q].z; v[3] += ra[q].w;
+                v[4] += rb[q].x; v[5] += rb[q].y; v[6] += rb[q].z; v[7] += rb[q].w;
+            }
+            if (RES == 2) {
+                const h16x8_t b0 = rp0[q], b1 = rp1[q];
+                v[0] += ((float)b0.s0 + (float)b1.s0) * rinv; v[1] += ((float)b0.s1 + (float)b1.s1) * rinv;
+                v[2] += ((float)b0.s2 + (float)b1.s2) * rinv; v[3] += ((float)b0.s3 + (float)b1.s3) * rinv;
+                v[4] += ((float)b0.s4 + (float)b1.s4) * rinv; v[5] += ((float)b0.s5 + (float)b1.s5) * rinv;
+                v[6] += ((float)b0.s6 + (float)b1.s6) * rinv; v[7] += ((float)b0.s7 + (float)b1.s7) * rinv;
+            }
+            if (relu) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            if (mk) {
+                const float4 k0 = *(const float4 *)mk, k1 = *(const float4 *)(mk + 4);
+                if (!(k0.x > 0.f)) v[0] = 0.f;
+                if (!(k0.y > 0.f)) v[1] = 0.f;
+                if (!(k0.z > 0.f)) v[2] = 0.f;
+                if (!(k0.w > 0.f)) v[3] = 0.f;
+                if (!(k1.x > 0.f)) v[4] = 0.f;
+                if (!(k1.y > 0.f)) v[5] = 0.f;
+                if (!(k1.z > 0.f)) v[6] = 0.f;
+                if (!(k1.w > 0.f)) v[7] = 0.f;
+            }
+            if (mk16) {
+                const h16x8_t k8 = *(const h16x8_t *)mk16;
+                if (!(k8.s0 > (_Float16)0)) v[0] = 0.f;
+                if (!(k8.s1 > (_Float16)0)) v[1] = 0.f;
+                if (!(k8.s2 > (_Float16)0)) v[2] = 0.f;
+                if (!(k8.s3 > (_Float16)0)) v[3] = 0.f;
+                if (!(k8.s4 > (_Float16)0)) v[4] = 0.f;
+                if (!(k8.s5 > (_Float16)0)) v[5] = 0.f;
+                if (!(k8.s6 > (_Float16)0)) v[6] = 0.f;
+                if (!(k8.s7 > (_Float16)0)) v[7] = 0.f;
+            }
+            if (yp) {
+                *(float4 *)yp = make_float4(v[0], v[1], v[2], v[3]);
+                *(float4 *)(yp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            }
+            if (p.post_scale) {
+                // rounded to fp32 before the split (no contraction into split4's subtraction): the same
+                // value sln_conv_grad_prep_f32 would split
+#pragma clang fp contract(off)
+                v[0] = v[0] * ps8[0]; v[1] = v[1] * ps8[1]; v[2] = v[2] * ps8[2]; v[3] = v[3] * ps8[3];
+                v[4] = v[4] * ps8[4]; v[5] = v[5] * ps8[5]; v[6] = v[6] * ps8[6]; v[7] = v[7] * ps8[7];
+            }
+            if (p.colsum) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) csum[e] += v[e];
+            }
+            amx = amax4(amax4(amx, v), v + 4);
+            bf16x4 lo[2], hi[2];
+            (void)split4<2>(make_float4(v[0], v[1], v[2], v[3]), lo, yqs);
+            (void)split4<2>(make_float4(v[4], v[5], v[6], v[7]), hi, yqs);
+            bf16x8 w0, w1;
+            w0.s0 = lo[0].x; w0.s1 = lo[0].y; w0.s2 = lo[0].z; w0.s3 = lo[0].w;
+            w0.s4 = hi[0].x; w0.s5 = hi[0].y; w0.s6 = hi[0].z; w0.s7 = hi[0].w;
+            w1.s0 = lo[1].x; w1.s1 = lo[1].y; w1.s2 = lo[1].z; w1.s3 = lo[1].w;
+            w1.s4 = hi[1].x; w1.s5 = hi[1].y; w1.s6 = hi[1].z; w1.s7 = hi[1].w;
+            *(bf16x8 *)p0 = w0;
+            *(bf16x8 *)p1 = w1;
+        }
+        if (yp) yp += ostep;
+        if (mk) mk += ostep;
+        if (mk16) mk16 += ostep;
+        p0 += ostep; p1 += ostep;
+    }
+    if (p.colsum) {   // the row groups share a column: combine in LDS first
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            if (csum[e] != 0.f) atomicAdd(&s_colsum[8 * cg + e], csum[e]);
+    }
+}
+
 // Dispatch of a slab: the fixed-feature version whenever the rows are whole 16-B groups.
 template <int P, int NCOLQ, int LD, int NTHREADS>
 __device__ __forceinline__ void epilogue_any(const ConvParams &p, const float *stage, int m_base, int n0, int t,
                                              float *s_colsum, float alpha, float yqs, float &amx, bool &sat,
                                              bool fast) {
-    if (P == 2 && fast) {
+    if (P == 2 && fast && p.yparts && (p.Cout & 7) == 0 && !(p.dbg & 32)) {      // (dbg 32: A/B against the 4-wide slab)
+        if (p.res_parts) epilogue_slab_w8<NCOLQ / 2, LD, NTHREADS, 2>(p, stage, m_base, n0, t, s_colsum, alpha, yqs, amx);
+        else if (p.residual) epilogue_slab_w8<NCOLQ / 2, LD, NTHREADS, 1>(p, stage, m_base, n0, t, s_colsum, alpha, yqs, amx);
+        else epilogue_slab_w8<NCOLQ / 2, LD, NTHREADS, 0>(p, stage, m_base, n0, t, s_colsum, alpha, yqs, amx);
+    } else if (P == 2 && fast) {
 #define SLN_EPI(R, Q) epilogue_slab_f16<NCOLQ, LD, NTHREADS, R, Q>(p, stage, m_base, n0, t, s_colsum, alpha, yqs, amx)
         if (p.res_parts) {
             if (p.yparts) SLN_EPI(2, true); else SLN_EPI(2, false);

@@ -42,11 +42,12 @@ class _Bottleneck(nn.Module):
             self.shortcut = _ConvBnReLU(in_ch, out_ch, 1, stride, 0, 1, False)
 
     def forward(self, x):
-        sc = self.shortcut(x) if self.has_shortcut else x
-        # reduce and the 3x3 feed one convolution each and nothing else (frozen net: no ReLU mask to keep):
-        # on the packed HIP path their fp32 copies are not written
+        # Frozen net: every tensor of a block is read by convolutions and by the next shortcut add only (the
+        # last block's output by the four ASPP branches), so on the packed HIP path no fp32 copy of any of
+        # them is written -- the shortcut is added from the parts (nn_ops.conv_bn_act parts_only)
+        sc = self.shortcut(x, parts_only=True) if self.has_shortcut else x
         h = self.conv3x3(self.reduce(x, parts_only=True), parts_only=True)
-        return self.increase(h, residual=sc, relu=True)  # relu(increase(h) + shortcut)
+        return self.increase(h, residual=sc, relu=True, parts_only=True)  # relu(increase(h) + shortcut)
 
 
 class _ResLayer(nn.Sequential):
