@@ -47,6 +47,9 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 #define BM 128
 #define BN 128
 #define BK 32
+#ifndef SLN_FWD128_BLOCKS
+#define SLN_FWD128_BLOCKS 3     // resident blocks per CU the 128^2 forward kernel is compiled for (48 KB LDS each)
+#endif
 
 // ---------------------------------------------------------------- operand formats
 // P = 3: three bf16 parts, six part products per fp32 product (see the top of the file).
@@ -1011,6 +1014,7 @@ __device__ __forceinline__ void epilogue_slab_w8(const ConvParams &p, const floa
     __bf16 *p0 = p.yparts + o0, *p1 = p0 + p.y_part_stride;
     const float *sg = stage + row0 * LD + 8 * cg;
     const bool relu = p.relu != 0;
+    const bool nt = (p.dbg & 64) != 0;       // experiment: non-temporal output stores
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         if (m_base + row0 + RG * q < p.M) {
@@ -1055,8 +1059,15 @@ __device__ __forceinline__ void epilogue_slab_w8(const ConvParams &p, const floa
                 if (!(k8.s7 > (_Float16)0)) v[7] = 0.f;
             }
             if (yp) {
-                *(float4 *)yp = make_float4(v[0], v[1], v[2], v[3]);
-                *(float4 *)(yp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+                const f32x4_t y0 = {v[0], v[1], v[2], v[3]}, y1 = {v[4], v[5], v[6], v[7]};
+                if (nt) {
+                    __builtin_nontemporal_store(y0, (f32x4_t *)yp);
+                    __builtin_nontemporal_store(y1, (f32x4_t *)(yp + 4));
+                } else {
+                    *(f32x4_t *)yp = y0;
+                    *(f32x4_t *)(yp + 4) = y1;
+                }
             }
             if (p.post_scale) {
                 // rounded to fp32 before the split (no contraction into split4's subtraction): the same
@@ -1078,8 +1089,13 @@ __device__ __forceinline__ void epilogue_slab_w8(const ConvParams &p, const floa
             w0.s4 = hi[0].x; w0.s5 = hi[0].y; w0.s6 = hi[0].z; w0.s7 = hi[0].w;
             w1.s0 = lo[1].x; w1.s1 = lo[1].y; w1.s2 = lo[1].z; w1.s3 = lo[1].w;
             w1.s4 = hi[1].x; w1.s5 = hi[1].y; w1.s6 = hi[1].z; w1.s7 = hi[1].w;
-            *(bf16x8 *)p0 = w0;
-            *(bf16x8 *)p1 = w1;
+            if (nt) {
+                __builtin_nontemporal_store(w0, (bf16x8 *)p0);
+                __builtin_nontemporal_store(w1, (bf16x8 *)p1);
+            } else {
+                *(bf16x8 *)p0 = w0;
+                *(bf16x8 *)p1 = w1;
+            }
         }
         if (yp) yp += ostep;
         if (mk) mk += ostep;
@@ -1124,7 +1140,7 @@ __device__ __forceinline__ bool epilogue_is_plain(const ConvParams &p) {
 // BNT = 128: waves 2x2, each 64x64 (2x2 MFMA tiles).  BNT = 64 (Cout <= 64: the C2 stage): waves 4x1,
 // each 32x64 (1x2 tiles) -- half the B tile and half the MFMAs of a 128-wide tile that would be half empty.
 template <int P, int BNT>
-__global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvParams p) {
+__global__ __launch_bounds__(256, BNT == 128 ? SLN_FWD128_BLOCKS : 1) void conv_fwd_kernel(const ConvParams p) {
     constexpr int NI = BNT == 128 ? 2 : 1;        // 32-row MFMA tiles per wave along M
     constexpr int NBI = BNT / 64;                 // 64-row staging passes of the B tile
     constexpr int SLD = BNT + 4;                  // staging slab row stride (floats)
