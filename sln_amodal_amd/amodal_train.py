@@ -261,18 +261,24 @@ def main(argv=None):
             model.train_model(data, None, learning_rate=lr, epochs=epochs, layers=layers,
                               grad_sync=(lambda ps: reducer.finish()) if world > 1 else None)
     elif args.command == "evaluate":
-        n = 0
+        # one batched predict(mode='inference') per BATCH_SIZE images (the reference: one image at a time,
+        # amodal_train.py:403-466); the per-image loop is only the hand-off to the COCO result list
+        n, limit = 0, max(1, min(args.limit, 2 if args.synthetic else args.limit))
         for batch in data:
-            img = (batch["images"][0].permute(1, 2, 0).cpu().numpy() + config.MEAN_PIXEL).clip(0, 255)
-            res = model.detect([img.astype(np.uint8)], keep_device=True)
-            k = res[0]["rois"].shape[0] if res else 0
-            coco = build_coco_results(None, [n], res[0]["rois"], res[0]["class_ids"], res[0]["scores"],
-                                      res[0]["masks_device"]) if k else []
-            if rank == 0:
-                print("image %d: %d detections, %d RLE bytes" % (
-                    n, k, sum(len(r["segmentation"]["counts"]) for r in coco)))
-            n += 1
-            if n >= max(1, min(args.limit, 2 if args.synthetic else args.limit)):
+            k_img = min(batch["images"].shape[0], limit - n)
+            imgs = [(batch["images"][b].permute(1, 2, 0).cpu().numpy() + config.MEAN_PIXEL).clip(0, 255)
+                    .astype(np.uint8) for b in range(k_img)]
+            res = {r["image_index"]: r for r in model.detect(imgs, keep_device=True, batch_size=k_img)}
+            for b in range(k_img):
+                r = res.get(b)
+                k = r["rois"].shape[0] if r is not None else 0
+                coco = build_coco_results(None, [n], r["rois"], r["class_ids"], r["scores"],
+                                          r["masks_device"]) if k else []
+                if rank == 0:
+                    print("image %d: %d detections, %d RLE bytes" % (
+                        n, k, sum(len(c["segmentation"]["counts"]) for c in coco)))
+                n += 1
+            if n >= limit:
                 break
     else:
         raise SystemExit("'{}' is not recognized. Use 'train' or 'evaluate'".format(args.command))

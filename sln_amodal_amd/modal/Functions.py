@@ -299,6 +299,36 @@ def refine_detections(rois, probs, deltas, window, config):
     return result, keep
 
 
+def refine_detections_batched(rois, valid, probs, deltas, window, config, max_instances=100):
+    """refine_detections (Functions.py:453-557, USE_NMS = False: the reference default) for B images at once,
+    fixed capacity, no host sync: rois [B,R,4] normalised with `valid` [B,R] bool (proposal slots beyond an
+    image's count are not detections), probs [B,R,C], deltas [B,R,C,4], window (y1,x1,y2,x2) pixels.
+    Per image exactly the reference's choice -- foreground rois, the 100 best scores, descending, ties in roi
+    order (its two stable sorts) -- as rows [B,100,(y1,x1,y2,x2,class_id,score)], ZERO rows behind the
+    per-image count (unmold_detections stops at the first class id 0, model.py:762-764), and counts [B]."""
+    B, R = rois.shape[0], rois.shape[1]
+    class_scores, class_ids = torch.max(probs, dim=2)
+    idx = class_ids.unsqueeze(2).unsqueeze(3).expand(B, R, 1, 4)
+    deltas_specific = torch.gather(deltas, 2, idx).squeeze(2)
+    refined = coordinate_convert(rois.reshape(-1, 4), deltas_specific.reshape(-1, 4), config)
+    refined = torch.round(clip_to_window(window, refined)).view(B, R, 4)
+    keep = (class_ids > 0) & valid
+    if config.DETECTION_MIN_CONFIDENCE and config.USE_NMS:
+        keep = keep & (class_scores >= config.DETECTION_MIN_CONFIDENCE)
+    key = torch.where(keep, class_scores, torch.full_like(class_scores, float("-inf")))
+    order = torch.sort(key, dim=1, descending=True, stable=True)[1][:, :max_instances]
+    count = keep.sum(dim=1).clamp(max=max_instances).to(torch.int32)
+    live = torch.arange(order.shape[1], device=rois.device)[None, :] < count[:, None]
+    g = lambda t: torch.gather(t, 1, order)
+    det = torch.cat((torch.gather(refined, 1, order.unsqueeze(2).expand(-1, -1, 4)),
+                     g(class_ids).unsqueeze(2).float(), g(class_scores).unsqueeze(2)), dim=2)
+    det = torch.where(live.unsqueeze(2), det, torch.zeros_like(det))
+    if det.shape[1] < max_instances:
+        det = torch.cat((det, det.new_zeros(B, max_instances - det.shape[1], 6)), dim=1)
+        live = torch.cat((live, live.new_zeros(B, max_instances - live.shape[1])), dim=1)
+    return det, live, count
+
+
 def parse_image_meta(meta):
     return meta[:, 0], meta[:, 1:4], meta[:, 4:8], meta[:, 8:]
 

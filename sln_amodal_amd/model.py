@@ -25,7 +25,8 @@ import torch.nn.functional as F
 from . import nn_ops, utils
 from .modal import loss as L
 from .modal.Functions import (build_rpn_targets, compose_image_meta, detection_layer,  # noqa: F401
-                              detection_target_layer, load_image_gt, log, mold_image, proposal_layer)
+                              detection_target_layer, load_image_gt, log, mold_image, parse_image_meta,
+                              proposal_layer, refine_detections_batched)
 from .modal.deeplabv2 import DeepLabV2_ResNet101_MSC
 from .modal.modals import (FPN, RPN, Classifier, Mask, ResNet, pyramid_roi_align_image)
 
@@ -307,25 +308,56 @@ class MaskRCNN(nn.Module):
         }
 
     def _predict_inference(self, rpn_rois, num_rois, maps, probs, image_metas, scale):
-        """Batch-1 inference tail (model.py:576-628), including the reference's
-        quirk of cropping the GLM map with PIXEL-coordinate boxes (model.py:588-594,
-        SURVEY.md M9) -- kept for bug-compatibility of `evaluate`."""
+        """Inference tail (model.py:576-628) for B images at once, fixed capacity, no device -> host copy:
+        every proposal slot goes through the classifier (slots beyond an image's count carry box_ind = -1:
+        zero crops, excluded from the detections), refine_detections_batched keeps the reference's top 100
+        per image, the mask head runs on [B, 100] detection boxes.  Includes the reference's quirk of
+        cropping the GLM map with PIXEL-coordinate boxes (model.py:588-594) -- kept for
+        bug-compatibility of `evaluate`.  Returns [detections [B,100,6], mrcnn_mask [B,100,C,32,32]]; rows
+        behind an image's count (`self.last_num_detections` [B], device) are zero.  USE_NMS = True (not the
+        reference's default) takes the per-image path of refine_detections with its host syncs."""
         cfg = self.config
-        n = int(num_rois[0])
-        rois = rpn_rois[:1, :n]
-        _, mrcnn_class, mrcnn_bbox = self.classifier(maps, rois)
-        detections, keep = detection_layer(cfg, rois, mrcnn_class, mrcnn_bbox, image_metas)
-        if len(detections) == 0:
-            return [], []
-        detections[detections < 0] = 0.0
-        detections[detections > 1024] = 1024
-        cls_feature = pyramid_roi_align_image([detections[:, :4].contiguous().unsqueeze(0), probs], 16,
-                                              (65, 65), istrain=False).detach()
-        detection_boxes = (detections[:, :4] / scale).unsqueeze(0)
-        mrcnn_mask, _ = self.mask(maps, detection_boxes, cls_feature)
+        B, R = rpn_rois.shape[0], rpn_rois.shape[1]
+        dev = rpn_rois.device
+        valid = torch.arange(R, device=dev)[None, :] < num_rois[:, None].to(torch.int64)
+        box_ind = torch.arange(B, dtype=torch.int32, device=dev).repeat_interleave(R)
+        box_ind = torch.where(valid.reshape(-1), box_ind, torch.full_like(box_ind, -1))
+        _, mrcnn_class, mrcnn_bbox = self.classifier(maps, rpn_rois, box_ind)
+        nc = mrcnn_class.shape[1]
+        _, _, window, _ = parse_image_meta(np.asarray(image_metas))
+        win = [float(v) for v in window[0]]
+        if cfg.USE_NMS:
+            dets = []
+            for b in range(B):
+                n = int(num_rois[b])
+                d, _ = detection_layer(cfg, rpn_rois[b:b + 1, :n], mrcnn_class.view(B, R, nc)[b, :n],
+                                       mrcnn_bbox.view(B, R, nc, 4)[b, :n], image_metas)
+                row = rpn_rois.new_zeros(R, 6)          # (per-class NMS keeps what survives: no cap)
+                if len(d):
+                    row[:d.shape[0]] = d
+                dets.append(row)
+            detections = torch.stack(dets)
+            live = detections[:, :, 4] > 0
+            count = live.sum(dim=1).to(torch.int32)
+        else:
+            detections, live, count = refine_detections_batched(
+                rpn_rois, valid, mrcnn_class.view(B, R, nc), mrcnn_bbox.view(B, R, nc, 4), win, cfg,
+                max_instances=100)             # (Functions.py:526-532 hard-codes the top 100)
+        # model.py:590-591 clamps the whole rows to [0, 1024] (class id and score included: harmless); the
+        # bound is the image size here, so that IMAGE_MAX_DIM != 1024 keeps its meaning
+        detections = detections.clamp(min=0.0, max=float(max(cfg.IMAGE_SHAPE[:2])))
+        D = detections.shape[1]
+        det_ind = torch.arange(B, dtype=torch.int32, device=dev).repeat_interleave(D)
+        det_ind = torch.where(live.reshape(-1), det_ind, torch.full_like(det_ind, -1))
+        cls_feature = pyramid_roi_align_image([detections[:, :, :4].contiguous(), probs], cfg.MASK_POOL_SIZE,
+                                              (65, 65), istrain=False, box_ind=det_ind).detach()
+        detection_boxes = detections[:, :, :4] / scale
+        mrcnn_mask, _ = self.mask(maps, detection_boxes, cls_feature, det_ind)
         mrcnn_mask = mrcnn_mask.contiguous()
         mrcnn_mask[:, 1] = torch.sigmoid(mrcnn_mask[:, 1:].sum(dim=1))
-        return [detections.unsqueeze(0), mrcnn_mask.unsqueeze(0)]
+        mrcnn_mask = torch.where(live.reshape(-1, 1, 1, 1), mrcnn_mask, torch.zeros_like(mrcnn_mask))
+        self.last_num_detections = count
+        return [detections, mrcnn_mask.view(B, D, *mrcnn_mask.shape[1:])]
 
     # -------------------------------------------------------------- training
     def compute_losses(self, out, rpn_match, rpn_bbox):
@@ -475,32 +507,49 @@ class MaskRCNN(nn.Module):
                                             np.zeros([cfg.NUM_CLASSES], dtype=np.int32)))
         return np.stack(molded), np.stack(metas), np.stack(windows)
 
-    def detect(self, images, mode="inference", priorities=None, keep_device=False):
+    def detect(self, images, mode="inference", priorities=None, keep_device=False, batch_size=None):
         """List of HxWx3 images -> list of dicts(rois, class_ids, scores, masks)
-        (model.py:464-514).  priorities: per-image list of predict() overrides (parity tests feed the
-        reference's proposals).  On the GPU the tail (box transform, zero-area filter, mask resize +
-        threshold + paste) runs on the device; keep_device=True additionally returns the masks as the
-        device tensor "masks_device" [N,W,H] (column-major per mask, ready for mask_rle.encode) and
-        skips the [H,W,N] host copy ("masks" is None)."""
+        (model.py:464-514).  The reference runs one image per predict(); here `batch_size` images (default:
+        all of them, config.BATCH_SIZE at most) go through ONE batched predict(mode='inference') and only
+        the per-image hand-off to the host (unmold) is a loop.  priorities: predict() overrides, either one
+        dict for the whole call ({"rpn_rois" [B,1000,4], "num_rois" [B]}) or a per-image list of
+        batch-1 dicts (parity tests feed the reference's proposals).  On the GPU the tail (box transform,
+        zero-area filter, mask resize + threshold + paste) runs on the device; keep_device=True
+        additionally returns the masks as the device tensor "masks_device" [N,W,H] (column-major per mask,
+        ready for mask_rle.encode) and skips the [H,W,N] host copy ("masks" is None).  Images without a
+        detection are left out of the result list, like the reference's `continue`; "image_index" says which
+        input a result belongs to."""
         results = []
+        if not len(images):
+            return results
+        step = int(batch_size or min(len(images), max(1, int(getattr(self.config, "BATCH_SIZE", 1)))))
         with torch.no_grad():
-            for i, image in enumerate(images):
-                molded, metas, windows = self.mold_inputs([image])
+            for i0 in range(0, len(images), step):
+                chunk = images[i0:i0 + step]
+                molded, metas, windows = self.mold_inputs(chunk)
                 x = torch.from_numpy(molded.transpose(0, 3, 1, 2)).float().to(self.anchors.device)
-                detections, mrcnn_mask = self.predict([x, metas], mode=mode,
-                                                      priorities=priorities[i] if priorities else None)
-                if len(detections) == 0:
-                    continue
-                if detections.is_cuda:
-                    results.append(self.unmold_detections_device(detections[0], mrcnn_mask[0], image.shape,
-                                                                 windows[0], keep_device))
-                    continue
-                det = detections[0].cpu().numpy()
-                msk = mrcnn_mask[0].permute(0, 2, 3, 1).cpu().numpy()
-                rois, class_ids, scores, masks = self.unmold_detections(det, msk, image.shape,
-                                                                        windows[0])
-                results.append({"rois": rois, "class_ids": class_ids, "scores": scores,
-                                "masks": masks})
+                pr = None
+                if isinstance(priorities, dict):
+                    pr = {k: v[i0:i0 + step] for k, v in priorities.items()}
+                elif priorities:
+                    ps = priorities[i0:i0 + step]
+                    pr = {k: torch.cat([p[k] for p in ps]) for k in ps[0]}
+                detections, mrcnn_mask = self.predict([x, metas], mode=mode, priorities=pr)
+                counts = self.last_num_detections.cpu().numpy()       # the hand-off to the host starts here
+                for b, image in enumerate(chunk):
+                    n = int(counts[b])
+                    if n == 0:
+                        continue
+                    if detections.is_cuda:
+                        results.append(dict(self.unmold_detections_device(detections[b, :n], mrcnn_mask[b, :n],
+                                                                          image.shape, windows[b], keep_device),
+                                            image_index=i0 + b))
+                        continue
+                    det = detections[b, :n].cpu().numpy()
+                    msk = mrcnn_mask[b, :n].permute(0, 2, 3, 1).cpu().numpy()
+                    rois, class_ids, scores, masks = self.unmold_detections(det, msk, image.shape, windows[b])
+                    results.append({"rois": rois, "class_ids": class_ids, "scores": scores, "masks": masks,
+                                    "image_index": i0 + b})
         return results
 
     def unmold_detections_device(self, detections, mrcnn_mask, image_shape, window, keep_device=False):

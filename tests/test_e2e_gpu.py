@@ -527,3 +527,114 @@ def test_real_data_loader_batch_matches_reference_load_image_gt(scene, tmp_path)
     it = iter(ds)
     b2 = next(it)
     assert b2["images"].shape == (2, 3, 128, 128) and b2["gt_layer"].dtype == torch.int64
+
+
+# ------------------------------------------------------------------ batched inference (configs[1], evaluate)
+def test_batched_inference_reproduces_each_reference_detect_fixture():
+    """predict(mode='inference') over B = 2 images (the reference is batch 1, model.py:576-628): each image's
+    rows equal its own e2e_detect fixture exactly as the batch-1 path's do -- boxes / class ids exact, scores
+    1e-5, mask logits 1e-4 -- rows behind the per-image count are zero, and detect() on the two images gives
+    the reference's final boxes and full-size masks per image."""
+    gs = [golden("e2e_detect_0"), golden("e2e_detect_1")]
+    m, cfg = e2e_model("cuda")
+    cfg.DETECTION_MIN_CONFIDENCE = 0
+    molded = torch.cat([dev(g["molded"]) for g in gs])
+    rr = torch.zeros((2, 1000, 4), device="cuda")
+    num = torch.zeros((2,), dtype=torch.int32, device="cuda")
+    for b, g in enumerate(gs):
+        k = g["rpn_rois"].shape[1]
+        rr[b, :k] = torch.from_numpy(g["rpn_rois"][0]).cuda()
+        num[b] = k
+    pr = {"rpn_rois": rr, "num_rois": num}
+    metas = np.concatenate([g["image_metas"] for g in gs])
+    with torch.no_grad():
+        detections, mrcnn_mask = m.predict([molded, metas], mode="inference", priorities=pr)
+    counts = m.last_num_detections.cpu().numpy()
+    assert detections.shape == (2, 100, 6) and mrcnn_mask.shape[:2] == (2, 100)
+    for b, g in enumerate(gs):
+        want = g["detections"]
+        n = want.shape[0]
+        assert counts[b] == n
+        det = detections[b].cpu().numpy()
+        assert np.array_equal(det[:n, :5], want[:, :5])
+        assert np.allclose(det[:n, 5], want[:, 5], rtol=0, atol=1e-5)
+        assert not det[n:].any() and not mrcnn_mask[b, n:].any()
+        assert rel(mrcnn_mask[b, :n], g["mrcnn_mask"]) < 1e-4
+    res = m.detect([g["image_u8"] for g in gs], priorities=pr)
+    assert len(res) == 2
+    for r, g in zip(res, gs):
+        assert np.array_equal(r["rois"], g["final_rois"]) and np.array_equal(r["class_ids"], g["final_class_ids"])
+        assert np.allclose(r["scores"], g["final_scores"], rtol=0, atol=1e-5)
+        shape = tuple(int(v) for v in g["final_masks_shape"])
+        want_masks = np.unpackbits(g["final_masks"])[:int(np.prod(shape))].reshape(shape)
+        assert r["masks"].shape == shape and (r["masks"] != want_masks).mean() < 1e-4
+
+
+def test_config2_batched_inference_resnet50_8x800_without_host_sync():
+    """BASELINE configs[1]: ResNet-50 + FPN SLN forward-only, 8 x 800x800 (800 is not a multiple of 64: the
+    reference's build() rejects it, model.py:153-157; the shapes are consistent).  The whole
+    predict(mode='inference') -- GLM, backbone, RPN, proposals + NMS, classifier over 8 x 1000 proposal slots,
+    top-100 detections, mask head -- runs under torch's sync debug mode "error": no device -> host copy, no
+    `int(num_rois[0])`.  Then the hand-off: unmold_detections_device + RLE per image.  An image run alone
+    gives the rows it has inside the batch (boxes / ids equal; scores 1e-5: the per-tensor fp16 scales of
+    a batch of one differ from a batch of eight)."""
+    from sln_amodal_amd import mask_rle
+    from sln_amodal_amd.config import Config
+    from sln_amodal_amd.model import MaskRCNN
+    from tests._util import e2e_init_
+
+    class C(Config):
+        NAME = "c2"
+        IMAGE_MAX_DIM = 800
+        IMAGE_MIN_DIM = 800
+        ARCHITECTURE = "resnet50"
+        DETECTION_MIN_CONFIDENCE = 0
+
+    cfg = C()
+    m = MaskRCNN(cfg, "/tmp/sln_logs").apply_amodal_heads()
+    e2e_init_(m)
+    m = m.cuda()
+    gen = torch.Generator().manual_seed(5)
+    imgs = [torch.randint(0, 256, (800, 800, 3), generator=gen, dtype=torch.uint8).numpy() for _ in range(8)]
+    molded, metas, windows = m.mold_inputs(imgs)
+    x = torch.from_numpy(molded.transpose(0, 3, 1, 2)).float().cuda()
+    with torch.no_grad():
+        m.predict([x, metas], mode="inference")            # (first call: scale bootstraps, constant caches)
+        torch.cuda.synchronize()
+        torch.cuda.set_sync_debug_mode("error")
+        try:
+            detections, mrcnn_mask = m.predict([x, metas], mode="inference")
+        finally:
+            torch.cuda.set_sync_debug_mode("default")
+    counts = m.last_num_detections.cpu().numpy()
+    assert detections.shape == (8, 100, 6) and mrcnn_mask.shape == (8, 100, 2, 32, 32)
+    det = detections.cpu().numpy()
+    assert (counts > 0).all() and (counts <= 100).all()
+    for b in range(8):
+        n = int(counts[b])
+        assert not det[b, n:].any()
+        assert (det[b, :n, 4] == 1).all() and (det[b, :n, :4] >= 0).all() and (det[b, :n, :4] <= 800).all()
+        assert (np.diff(det[b, :n, 5]) <= 0).all()                    # descending scores
+    # the hand-off per image: full-size masks on the device + their RLE
+    total = 0
+    for b in range(8):
+        n = int(counts[b])
+        out = m.unmold_detections_device(detections[b, :n], mrcnn_mask[b, :n], imgs[b].shape, windows[b],
+                                         keep_device=True)
+        k = out["rois"].shape[0]
+        assert out["masks_device"].shape == (k, 800, 800)
+        if k:
+            rles = mask_rle.encode(out["masks_device"])
+            i = k // 2
+            back = mask_rle.decode_counts(mask_rle.from_string(rles[i]["counts"]), 800, 800)
+            assert np.array_equal(back, out["masks_device"][i].cpu().numpy().T)
+        total += k
+    assert total > 0
+    with torch.no_grad():
+        d1, _ = m.predict([x[3:4], metas[3:4]], mode="inference")
+    n = int(counts[3])
+    assert int(m.last_num_detections[0]) == n
+    one = d1[0].cpu().numpy()
+    key = lambda a: a[np.lexsort(a[:, :4].T[::-1])]
+    assert np.array_equal(key(one[:n, :5]), key(det[3, :n, :5]))
+    assert np.allclose(np.sort(one[:n, 5]), np.sort(det[3, :n, 5]), rtol=0, atol=1e-5)
