@@ -721,6 +721,10 @@ def folded_shift(bias, bn_scale, bn_shift):
     return out
 
 
+# Data-parallel training (parallel.GradientAllReducer): callable(parameter, shape) -> the tensor the layer's
+# weight gradient should be written into (the parameter's slot of a flat all-reduce bucket), or None.
+GRAD_SINK = None
+
 # Parity tests only (tests/test_e2e_gpu.py): callable(owner weight, y) -> bool tensor [n <= N, C, H, W] or None.
 # The ReLU pattern of a layer's output is then FORCED to the given one (a unit that is on keeps its value or
 # gets the smallest positive one, a unit that is off becomes 0), so that a backward pass can be compared with
@@ -1055,8 +1059,15 @@ class _ConvFn(torch.autograd.Function):
             # with the workspace the reduce pass writes the parameter's own [Co,Ci,KH,KW] order (no layout
             # copy in AccumulateGrad); the atomic path produces [Co,KH,KW,Ci]
             own_layout = ws is not None
-            gw_t = torch.empty((Co, Ci, KH, KW) if own_layout else (Co, KH, KW, Ci), dtype=torch.float32,
-                               device=weight.device)
+            gw_t = None
+            if own_layout and GRAD_SINK is not None and own.is_leaf and own.data_ptr() == weight.data_ptr() and \
+                    tuple(own.shape) == (Co, Ci, KH, KW):
+                # the parameter's slot of its all-reduce bucket: autograd adopts the view as .grad (no pack /
+                # unpack copies around the collective)
+                gw_t = GRAD_SINK(own, (Co, Ci, KH, KW))
+            if gw_t is None:
+                gw_t = torch.empty((Co, Ci, KH, KW) if own_layout else (Co, KH, KW, Ci), dtype=torch.float32,
+                                   device=weight.device)
             e0 = _prof_begin()
             _lib.check(_lib.lib().sln_conv2d_wgrad_f32(
                 ops._ptr(gz), Co, gz.shape[2], ops._ptr(xp), N, H, W, Ci, xp.shape[2], parts, KH, KW,

@@ -48,11 +48,18 @@ def broadcast_parameters(module, src=0):
 
 
 class GradientAllReducer(object):
-    """Bucketed, backward-overlapped gradient averaging.
+    """Bucketed, backward-overlapped gradient averaging over persistent flat buckets.
 
-    attach() registers post-accumulate-grad hooks; when the last gradient of a
-    bucket lands, the bucket is packed and its all-reduce launched asynchronously.
-    finish() (call after backward, before clipping) waits, averages and unpacks.
+    Every bucket owns one flat fp32 buffer for the life of the reducer; parameter i of the bucket has a
+    fixed slot in it.  attach() registers post-accumulate-grad hooks and -- on the HIP conv stack -- a
+    gradient SINK: the weight-gradient reduce pass (wgrad_reduce_kernel) then writes a layer's gradient
+    straight into its slot, and autograd adopts that view as `p.grad`, so the large gradients are never
+    packed or copied back.  What does not arrive in its slot (biases, a few re-laid-out weights: a few
+    hundred KB) is moved there by one multi-tensor copy per bucket when the bucket is launched.  When the
+    last gradient of a bucket has landed, its all-reduce is launched asynchronously; buckets go out
+    strictly in bucket order on every rank.  finish() (after backward, before clipping) waits, averages in
+    place and leaves every `p.grad` a view of its slot.  `stats` counts, per finish(), how many gradient
+    bytes were already in place and how many had to be copied.
     Calling the object with a parameter list does the same without hooks."""
 
     def __init__(self, params, bucket_bytes=64 << 20):
@@ -70,16 +77,51 @@ class GradientAllReducer(object):
             self.buckets.append(cur)
         self._owner = {id(p): bi for bi, b in enumerate(self.buckets) for p in b}
         self._pending = [len(b) for b in self.buckets]
-        self._flat = [None] * len(self.buckets)
+        self._flat = [None] * len(self.buckets)      # persistent flat storage, allocated at first use
+        self._slot = {}                              # id(p) -> (bucket, offset)
+        for bi, b in enumerate(self.buckets):
+            off = 0
+            for p in b:
+                self._slot[id(p)] = (bi, off)
+                off += (p.numel() + 3) // 4 * 4      # 16-B aligned slots (vector loads in the optimiser)
+        self._size = [sum((p.numel() + 3) // 4 * 4 for p in b) for b in self.buckets]
         self._work = [None] * len(self.buckets)
         self._next = 0          # collectives are issued strictly in bucket order on every rank
         self._hooks = []
+        self.stats = {"in_place_bytes": 0, "copied_bytes": 0, "copied_tensors": 0}
+
+    # ------------------------------------------------------------------ slots
+    def _storage(self, bi):
+        if self._flat[bi] is None:
+            p0 = self.buckets[bi][0]
+            self._flat[bi] = torch.zeros(self._size[bi], dtype=p0.dtype, device=p0.device)
+        return self._flat[bi]
+
+    def slot_view(self, p):
+        """The parameter's slot as a tensor of the parameter's shape (contiguous)."""
+        bi, off = self._slot[id(p)]
+        return self._storage(bi)[off:off + p.numel()].view(p.shape)
+
+    def _sink(self, p, shape):
+        """conv_hip.GRAD_SINK: where the weight gradient of parameter p should be written, or None.  Only
+        while p holds no gradient yet (a second backward before the step must ACCUMULATE, not overwrite) and
+        only for gradients in the parameter's own contiguous layout."""
+        if id(p) not in self._slot or p.grad is not None or tuple(shape) != tuple(p.shape) or \
+                not p.is_contiguous():
+            return None
+        return self.slot_view(p)
 
     def attach(self):
         if self.world == 1:
             return self
         for p in self.params:
             self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+        if self.params and self.params[0].is_cuda:
+            try:
+                from . import conv_hip
+                conv_hip.GRAD_SINK = self._sink
+            except ImportError:
+                pass
         return self
 
     def detach(self):
@@ -89,10 +131,15 @@ class GradientAllReducer(object):
         for h in self._hooks:
             h.remove()
         self._hooks = []
+        try:
+            from . import conv_hip
+            if getattr(conv_hip.GRAD_SINK, "__self__", None) is self:
+                conv_hip.GRAD_SINK = None
+        except ImportError:
+            pass
         for w in self._work:
             if w is not None:
                 w.wait()
-        self._flat = [None] * len(self.buckets)
         self._work = [None] * len(self.buckets)
         self._pending = [len(b) for b in self.buckets]
         self._next = 0
@@ -109,9 +156,25 @@ class GradientAllReducer(object):
             self._next += 1
 
     def _launch(self, bi):
-        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.buckets[bi]]
-        flat = torch.cat([g.reshape(-1) for g in grads])
-        self._flat[bi] = flat
+        flat = self._storage(bi)
+        src, dst, missing = [], [], []
+        for p in self.buckets[bi]:
+            view = self.slot_view(p)
+            g = p.grad
+            if g is None:
+                missing.append(view)                 # no gradient on this rank: its slot contributes zeros
+            elif g.data_ptr() == view.data_ptr() and g.is_contiguous():
+                self.stats["in_place_bytes"] += g.numel() * g.element_size()
+            else:
+                src.append(g.detach())
+                dst.append(view)
+                self.stats["copied_bytes"] += g.numel() * g.element_size()
+                self.stats["copied_tensors"] += 1
+        with torch.no_grad():
+            if missing:
+                torch._foreach_zero_(missing)
+            if dst:
+                torch._foreach_copy_(dst, src)       # one multi-tensor launch (layout conversion included)
         self._work[bi] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
 
     def finish(self):
@@ -122,17 +185,11 @@ class GradientAllReducer(object):
             self._next += 1
         for bi, bucket in enumerate(self.buckets):
             self._work[bi].wait()
-            flat = self._flat[bi]
-            flat.div_(self.world)
-            off = 0
+            self._flat[bi].div_(self.world)
             for p in bucket:
-                n = p.numel()
-                if p.grad is None:
-                    p.grad = flat[off:off + n].view_as(p).clone()
-                else:
-                    p.grad.copy_(flat[off:off + n].view_as(p))
-                off += n
-            self._flat[bi] = None
+                view = self.slot_view(p)
+                if p.grad is None or p.grad.data_ptr() != view.data_ptr() or not p.grad.is_contiguous():
+                    p.grad = view                    # (no copy: the averaged gradient lives in the slot)
             self._work[bi] = None
         self._pending = [len(b) for b in self.buckets]
         self._next = 0

@@ -53,6 +53,17 @@ def _worker(rank, world, port, out):
     for _ in range(3):
         loss, _parts = m.train_step(batch, opt, lambda params: red.finish())
     assert bool(torch.isfinite(loss))
+    # flat buckets: the convolution weight gradients (nearly all of the bytes) were written by the reduce pass
+    # straight into their bucket slots -- no pack before and no copy back after the collective -- and every
+    # gradient the optimiser read was a view of its slot
+    st = red.stats
+    total = st["in_place_bytes"] + st["copied_bytes"]
+    print("rank", rank, "gradient bytes in place %d, copied %d in %d tensors" %
+          (st["in_place_bytes"], st["copied_bytes"], st["copied_tensors"]), flush=True)
+    assert total == 3 * sum(p.numel() * 4 for p in red.params)
+    assert st["in_place_bytes"] >= 0.80 * total, st
+    for p in red.params:
+        assert p.grad is None or p.grad.data_ptr() == red.slot_view(p).data_ptr()
     flat = torch.cat([p.detach().reshape(-1).double() for p in m.parameters()] +
                      [b.detach().reshape(-1).double() for b in m.buffers()])
     # the replicas must also COMPUTE the same thing (stale per-rank caches of weight parts or BN affines
