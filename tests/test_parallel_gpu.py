@@ -61,7 +61,10 @@ def _worker(rank, world, port, out):
     print("rank", rank, "gradient bytes in place %d, copied %d in %d tensors" %
           (st["in_place_bytes"], st["copied_bytes"], st["copied_tensors"]), flush=True)
     assert total == 3 * sum(p.numel() * 4 for p in red.params)
-    assert st["in_place_bytes"] >= 0.80 * total, st
+    # (what is copied: the biases, and the three weights whose gradient is produced in another layout and
+    # re-laid by autograd -- the classifier's whole-window 7x7 "FC" conv, 51 MB of this model's 180 MB, the
+    # 2x2 deconv and the 3-channel stem)
+    assert st["in_place_bytes"] >= 0.65 * total and st["copied_tensors"] <= 3 * 90, st
     for p in red.params:
         assert p.grad is None or p.grad.data_ptr() == red.slot_view(p).data_ptr()
     flat = torch.cat([p.detach().reshape(-1).double() for p in m.parameters()] +
