@@ -955,89 +955,123 @@ __device__ __forceinline__ void epilogue_slab_f16(const ConvParams &p, const flo
 // same 4 B per element; MI355X_MICROARCH.md "store-ISSUE-bound" tails).  Thread t owns columns
 // 8*(t % NCOL8)..+7 of rows t/NCOL8 + RG*q.  Same arithmetic per element as epilogue_slab_f16.
 typedef __attribute__((ext_vector_type(8))) _Float16 h16x8_t;
-template <int NCOL8, int LD, int NTHREADS, int RES>
-__device__ __forceinline__ void epilogue_slab_w8(const ConvParams &p, const float *stage, int m_base, int n0,
-                                                 int t, float *s_colsum, float alpha, float yqs, float &amx) {
-    constexpr int RG = NTHREADS / NCOL8;
-    constexpr int NQ = 64 / RG;
-    const int cg = t & (NCOL8 - 1);
-    const int c = n0 + 8 * cg;
-    if (c >= p.Cout) return;
-    const int row0 = t / NCOL8;
+
+// What a slab reads from global memory besides its accumulators: NQ rows of the residual (RES 1: fp32, 2: its
+// two fp16 parts) and of the ReLU pattern (MASK 1: fp32, 2: part 0).  Loaded as a block BEFORE the previous
+// slab's stores are issued (the compiler may not move a load above a store that might alias), so that their
+// HBM round trip -- 2-4 us under load, once per slab and, for the mask, once per ROW in the first version --
+// overlaps the previous slab's arithmetic and stores instead of standing in front of every slab.
+template <int NQ, int RES, int MASK>
+struct W8Pre {
+    float4 ra[RES == 1 ? NQ : 1], rb[RES == 1 ? NQ : 1];
+    h16x8_t rp0[RES == 2 ? NQ : 1], rp1[RES == 2 ? NQ : 1];
+    float4 ma[MASK == 1 ? NQ : 1], mb[MASK == 1 ? NQ : 1];
+    h16x8_t m16[MASK == 2 ? NQ : 1];
+};
+
+// Per-tile constants of a thread's eight columns.
+struct W8Cols {
     float sc[8], sf[8], ps8[8];
+    float rinv;
+    float csum[8];      // running column sums of the tile (colsum mode): one LDS atomic per column at the end
+};
+
+template <int NCOL8>
+__device__ __forceinline__ void w8_cols(const ConvParams &p, int n0, int t, float alpha, W8Cols &k) {
+    const int c = n0 + 8 * (t & (NCOL8 - 1));
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { sc[e] = alpha; sf[e] = 0.f; ps8[e] = 1.f; }
+    for (int e = 0; e < 8; ++e) { k.sc[e] = alpha; k.sf[e] = 0.f; k.ps8[e] = 1.f; k.csum[e] = 0.f; }
+    k.rinv = 1.f;
+    if (c >= p.Cout) return;
     if (p.scale) {
         const float4 s0 = *(const float4 *)(p.scale + c), s1 = *(const float4 *)(p.scale + c + 4);
-        sc[0] = s0.x * alpha; sc[1] = s0.y * alpha; sc[2] = s0.z * alpha; sc[3] = s0.w * alpha;
-        sc[4] = s1.x * alpha; sc[5] = s1.y * alpha; sc[6] = s1.z * alpha; sc[7] = s1.w * alpha;
+        k.sc[0] = s0.x * alpha; k.sc[1] = s0.y * alpha; k.sc[2] = s0.z * alpha; k.sc[3] = s0.w * alpha;
+        k.sc[4] = s1.x * alpha; k.sc[5] = s1.y * alpha; k.sc[6] = s1.z * alpha; k.sc[7] = s1.w * alpha;
     }
     if (p.shift) {
         const float4 s0 = *(const float4 *)(p.shift + c), s1 = *(const float4 *)(p.shift + c + 4);
-        sf[0] = s0.x; sf[1] = s0.y; sf[2] = s0.z; sf[3] = s0.w; sf[4] = s1.x; sf[5] = s1.y; sf[6] = s1.z; sf[7] = s1.w;
+        k.sf[0] = s0.x; k.sf[1] = s0.y; k.sf[2] = s0.z; k.sf[3] = s0.w;
+        k.sf[4] = s1.x; k.sf[5] = s1.y; k.sf[6] = s1.z; k.sf[7] = s1.w;
     }
     if (p.post_scale) {
         const float4 s0 = *(const float4 *)(p.post_scale + c), s1 = *(const float4 *)(p.post_scale + c + 4);
-        ps8[0] = s0.x; ps8[1] = s0.y; ps8[2] = s0.z; ps8[3] = s0.w; ps8[4] = s1.x; ps8[5] = s1.y; ps8[6] = s1.z; ps8[7] = s1.w;
+        k.ps8[0] = s0.x; k.ps8[1] = s0.y; k.ps8[2] = s0.z; k.ps8[3] = s0.w;
+        k.ps8[4] = s1.x; k.ps8[5] = s1.y; k.ps8[6] = s1.z; k.ps8[7] = s1.w;
     }
+    if (p.res_parts) k.rinv = 1.0f / (p.res_scale ? *p.res_scale : 1.f);
+}
+
+template <int NCOL8, int NTHREADS, int NQ, int RES, int MASK>
+__device__ __forceinline__ void w8_load(const ConvParams &p, int m_base, int n0, int t, int q0,
+                                        W8Pre<NQ, RES, MASK> &pre) {
+    // rows t/NCOL8 + RG*(q0 + q), q = 0..NQ-1, of the 64-row slab at m_base
+    constexpr int RG = NTHREADS / NCOL8;
+    const int c = n0 + 8 * (t & (NCOL8 - 1));
+    if (c >= p.Cout) return;
+    const int row0 = t / NCOL8 + RG * q0;
     const long o0 = (long)(m_base + row0) * p.Cout + c;      // (Cop == Cout here)
     const long ostep = (long)RG * p.Cout;
-    float4 ra[RES == 1 ? NQ : 1], rb[RES == 1 ? NQ : 1];
-    h16x8_t rp0[RES == 2 ? NQ : 1], rp1[RES == 2 ? NQ : 1];
-    float rinv = 1.f;
-    if (RES == 1) {
-        const float *r = p.residual + o0;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const h16x8_t z8 = {};
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const bool ok = (m_base + row0 + RG * q) < p.M;
-            ra[q] = ok ? *(const float4 *)r : make_float4(0.f, 0.f, 0.f, 0.f);
-            rb[q] = ok ? *(const float4 *)(r + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-            r += ostep;
+    for (int q = 0; q < NQ; ++q) {
+        const bool ok = (m_base + row0 + RG * q) < p.M;
+        const long o = o0 + q * ostep;
+        if (RES == 1) {
+            pre.ra[q] = ok ? *(const float4 *)(p.residual + o) : z4;
+            pre.rb[q] = ok ? *(const float4 *)(p.residual + o + 4) : z4;
         }
-    }
-    if (RES == 2) {
-        rinv = 1.0f / (p.res_scale ? *p.res_scale : 1.f);
-        const __bf16 *r0 = p.res_parts + o0, *r1 = r0 + p.y_part_stride;
-        const h16x8_t z8 = {};
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const bool ok = (m_base + row0 + RG * q) < p.M;
-            rp0[q] = ok ? *(const h16x8_t *)r0 : z8;
-            rp1[q] = ok ? *(const h16x8_t *)r1 : z8;
-            r0 += ostep; r1 += ostep;
+        if (RES == 2) {
+            pre.rp0[q] = ok ? *(const h16x8_t *)(p.res_parts + o) : z8;
+            pre.rp1[q] = ok ? *(const h16x8_t *)(p.res_parts + p.y_part_stride + o) : z8;
         }
+        if (MASK == 1) {
+            pre.ma[q] = ok ? *(const float4 *)(p.mask + o) : z4;
+            pre.mb[q] = ok ? *(const float4 *)(p.mask + o + 4) : z4;
+        }
+        if (MASK == 2) pre.m16[q] = ok ? *(const h16x8_t *)(p.mask_part0 + o) : z8;
     }
-    const float *mk = p.mask ? p.mask + o0 : nullptr;
-    const __bf16 *mk16 = p.mask_part0 ? p.mask_part0 + o0 : nullptr;
-    float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+}
+
+template <int NCOL8, int LD, int NTHREADS, int NQ, int RES, int MASK>
+__device__ __forceinline__ void w8_compute(const ConvParams &p, const float *stage, int m_base, int n0, int t, int q0,
+                                           float yqs, float &amx, W8Cols &k, const W8Pre<NQ, RES, MASK> &pre) {
+    constexpr int RG = NTHREADS / NCOL8;
+    const int cg = t & (NCOL8 - 1);
+    const int c = n0 + 8 * cg;
+    if (c >= p.Cout) return;
+    const int row0 = t / NCOL8 + RG * q0;
+    const long o0 = (long)(m_base + row0) * p.Cout + c;
+    const long ostep = (long)RG * p.Cout;
     float *yp = p.y ? p.y + o0 : nullptr;
     __bf16 *p0 = p.yparts + o0, *p1 = p0 + p.y_part_stride;
     const float *sg = stage + row0 * LD + 8 * cg;
     const bool relu = p.relu != 0;
-    const bool nt = (p.dbg & 64) != 0;       // experiment: non-temporal output stores
+    const bool nt = (p.dbg & 64) != 0;       // experiment: non-temporal output stores (no effect measured)
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         if (m_base + row0 + RG * q < p.M) {
             const float4 a0 = *(const float4 *)(sg + q * RG * LD), a1 = *(const float4 *)(sg + q * RG * LD + 4);
-            float v[8] = {a0.x * sc[0] + sf[0], a0.y * sc[1] + sf[1], a0.z * sc[2] + sf[2], a0.w * sc[3] + sf[3],
-                          a1.x * sc[4] + sf[4], a1.y * sc[5] + sf[5], a1.z * sc[6] + sf[6], a1.w * sc[7] + sf[7]};
+            float v[8] = {a0.x * k.sc[0] + k.sf[0], a0.y * k.sc[1] + k.sf[1], a0.z * k.sc[2] + k.sf[2],
+                          a0.w * k.sc[3] + k.sf[3], a1.x * k.sc[4] + k.sf[4], a1.y * k.sc[5] + k.sf[5],
+                          a1.z * k.sc[6] + k.sf[6], a1.w * k.sc[7] + k.sf[7]};
             if (RES == 1) {
-                v[0] += ra[q].x; v[1] += ra[q].y; v[2] += ra[q].z; v[3] += ra[q].w;
-                v[4] += rb[q].x; v[5] += rb[q].y; v[6] += rb[q].z; v[7] += rb[q].w;
+                v[0] += pre.ra[q].x; v[1] += pre.ra[q].y; v[2] += pre.ra[q].z; v[3] += pre.ra[q].w;
+                v[4] += pre.rb[q].x; v[5] += pre.rb[q].y; v[6] += pre.rb[q].z; v[7] += pre.rb[q].w;
             }
             if (RES == 2) {
-                const h16x8_t b0 = rp0[q], b1 = rp1[q];
-                v[0] += ((float)b0.s0 + (float)b1.s0) * rinv; v[1] += ((float)b0.s1 + (float)b1.s1) * rinv;
-                v[2] += ((float)b0.s2 + (float)b1.s2) * rinv; v[3] += ((float)b0.s3 + (float)b1.s3) * rinv;
-                v[4] += ((float)b0.s4 + (float)b1.s4) * rinv; v[5] += ((float)b0.s5 + (float)b1.s5) * rinv;
-                v[6] += ((float)b0.s6 + (float)b1.s6) * rinv; v[7] += ((float)b0.s7 + (float)b1.s7) * rinv;
+                const h16x8_t b0 = pre.rp0[q], b1 = pre.rp1[q];
+                v[0] += ((float)b0.s0 + (float)b1.s0) * k.rinv; v[1] += ((float)b0.s1 + (float)b1.s1) * k.rinv;
+                v[2] += ((float)b0.s2 + (float)b1.s2) * k.rinv; v[3] += ((float)b0.s3 + (float)b1.s3) * k.rinv;
+                v[4] += ((float)b0.s4 + (float)b1.s4) * k.rinv; v[5] += ((float)b0.s5 + (float)b1.s5) * k.rinv;
+                v[6] += ((float)b0.s6 + (float)b1.s6) * k.rinv; v[7] += ((float)b0.s7 + (float)b1.s7) * k.rinv;
             }
             if (relu) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
             }
-            if (mk) {
-                const float4 k0 = *(const float4 *)mk, k1 = *(const float4 *)(mk + 4);
+            if (MASK == 1) {
+                const float4 k0 = pre.ma[q], k1 = pre.mb[q];
                 if (!(k0.x > 0.f)) v[0] = 0.f;
                 if (!(k0.y > 0.f)) v[1] = 0.f;
                 if (!(k0.z > 0.f)) v[2] = 0.f;
@@ -1047,8 +1081,8 @@ __device__ __forceinline__ void epilogue_slab_w8(const ConvParams &p, const floa
                 if (!(k1.z > 0.f)) v[6] = 0.f;
                 if (!(k1.w > 0.f)) v[7] = 0.f;
             }
-            if (mk16) {
-                const h16x8_t k8 = *(const h16x8_t *)mk16;
+            if (MASK == 2) {
+                const h16x8_t k8 = pre.m16[q];
                 if (!(k8.s0 > (_Float16)0)) v[0] = 0.f;
                 if (!(k8.s1 > (_Float16)0)) v[1] = 0.f;
                 if (!(k8.s2 > (_Float16)0)) v[2] = 0.f;
@@ -1073,12 +1107,12 @@ __device__ __forceinline__ void epilogue_slab_w8(const ConvParams &p, const floa
                 // rounded to fp32 before the split (no contraction into split4's subtraction): the same
                 // value sln_conv_grad_prep_f32 would split
 #pragma clang fp contract(off)
-                v[0] = v[0] * ps8[0]; v[1] = v[1] * ps8[1]; v[2] = v[2] * ps8[2]; v[3] = v[3] * ps8[3];
-                v[4] = v[4] * ps8[4]; v[5] = v[5] * ps8[5]; v[6] = v[6] * ps8[6]; v[7] = v[7] * ps8[7];
+                v[0] = v[0] * k.ps8[0]; v[1] = v[1] * k.ps8[1]; v[2] = v[2] * k.ps8[2]; v[3] = v[3] * k.ps8[3];
+                v[4] = v[4] * k.ps8[4]; v[5] = v[5] * k.ps8[5]; v[6] = v[6] * k.ps8[6]; v[7] = v[7] * k.ps8[7];
             }
             if (p.colsum) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) csum[e] += v[e];
+                for (int e = 0; e < 8; ++e) k.csum[e] += v[e];
             }
             amx = amax4(amax4(amx, v), v + 4);
             bf16x4 lo[2], hi[2];
@@ -1098,15 +1132,69 @@ __device__ __forceinline__ void epilogue_slab_w8(const ConvParams &p, const floa
             }
         }
         if (yp) yp += ostep;
-        if (mk) mk += ostep;
-        if (mk16) mk16 += ostep;
         p0 += ostep; p1 += ostep;
     }
-    if (p.colsum) {   // the row groups share a column: combine in LDS first
+}
+
+// A whole tile through the eight-channel slabs, NSLAB slabs of 64 rows: slab h's accumulators go to LDS
+// (stage_slab(h): the kernel's own C-layout write), and the slab is worked off in two halves of NQ / 2 rows per
+// thread; BEFORE a half's arithmetic and stores the global loads of the NEXT half (of this slab or the next)
+// are issued (w8_load).  Halves, not whole slabs: two sets of a whole slab's residual + mask rows next to the
+// 128 accumulator registers of the wave group whose slabs come last do not fit the 256-register budget.
+template <int NCOL8, int LD, int NTHREADS, int NSLAB, int RES, int MASK, typename StageFn>
+__device__ __forceinline__ void epilogue_tile_w8(const ConvParams &p, const float *stage, int m0, int n0, int t,
+                                                 float *s_colsum, float alpha, float yqs, float &amx,
+                                                 StageFn stage_slab) {
+    constexpr int NQ = 64 / (NTHREADS / NCOL8);
+    constexpr int NH = NQ >= 2 ? 2 : 1, NQH = NQ / NH;
+    // (fp32 residual AND fp32 mask -- a block whose input is an ordinary tensor: rare -- would need 64 more
+    // registers for the look-ahead set: that instance loads each half right before it is used)
+    constexpr bool AHEAD = !(RES == 1 && MASK == 1);
+    W8Cols k;
+    w8_cols<NCOL8>(p, n0, t, alpha, k);
+    W8Pre<NQH, RES, MASK> cur, nxt;
+    if (AHEAD) w8_load<NCOL8, NTHREADS, NQH, RES, MASK>(p, m0, n0, t, 0, cur);
+#pragma unroll
+    for (int h = 0; h < NSLAB; ++h) {
+        stage_slab(h);
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < NH; ++u) {
+            if (!AHEAD) w8_load<NCOL8, NTHREADS, NQH, RES, MASK>(p, m0 + h * 64, n0, t, u * NQH, cur);
+            else if (u + 1 < NH) w8_load<NCOL8, NTHREADS, NQH, RES, MASK>(p, m0 + h * 64, n0, t, (u + 1) * NQH, nxt);
+            else if (h + 1 < NSLAB) w8_load<NCOL8, NTHREADS, NQH, RES, MASK>(p, m0 + (h + 1) * 64, n0, t, 0, nxt);
+            w8_compute<NCOL8, LD, NTHREADS, NQH, RES, MASK>(p, stage, m0 + h * 64, n0, t, u * NQH, yqs, amx, k, cur);
+            if (AHEAD) cur = nxt;
+        }
+        __syncthreads();
+    }
+    if (p.colsum && n0 + 8 * (t & (NCOL8 - 1)) < p.Cout) {   // the row groups share a column: combine in LDS
 #pragma unroll
         for (int e = 0; e < 8; ++e)
-            if (csum[e] != 0.f) atomicAdd(&s_colsum[8 * cg + e], csum[e]);
+            if (k.csum[e] != 0.f) atomicAdd(&s_colsum[8 * (t & (NCOL8 - 1)) + e], k.csum[e]);
+        // (the kernel's own barrier-free read of s_colsum follows a __syncthreads below)
     }
+    __syncthreads();
+}
+
+// Which (RES, MASK) instance a launch needs: the shortcut from its parts (forward block outputs), the ReLU
+// pattern from part 0 (chained data gradients), or neither.
+template <int NCOL8, int LD, int NTHREADS, int NSLAB, typename StageFn>
+__device__ __forceinline__ void epilogue_tile_w8_any(const ConvParams &p, const float *stage, int m0, int n0, int t,
+                                                     float *s_colsum, float alpha, float yqs, float &amx,
+                                                     StageFn stage_slab) {
+#define SLN_W8(R, K) epilogue_tile_w8<NCOL8, LD, NTHREADS, NSLAB, R, K>(p, stage, m0, n0, t, s_colsum, alpha, yqs, amx, stage_slab)
+    if (p.res_parts) SLN_W8(2, 0);                 // (launcher: never together with a mask)
+    else if (p.mask_part0) SLN_W8(0, 2);
+    else SLN_W8(0, 0);
+#undef SLN_W8
+}
+
+__device__ __forceinline__ bool epilogue_is_w8(const ConvParams &p) {
+    // (launches that READ an fp32 residual or mask stay on the four-channel slab: eight channels per thread make
+    // an fp32 row 32-B pieces at a 32-B stride per instruction -- measured 20-35 % slower for the loads, while
+    // an fp32 OUTPUT next to the parts still gains; dbg 32: A/B against the four-channel slab)
+    return p.yparts && (p.Cout & 7) == 0 && !p.residual && !p.mask && !(p.dbg & 32);
 }
 
 // Dispatch of a slab: the fixed-feature version whenever the rows are whole 16-B groups.
@@ -1114,11 +1202,7 @@ template <int P, int NCOLQ, int LD, int NTHREADS>
 __device__ __forceinline__ void epilogue_any(const ConvParams &p, const float *stage, int m_base, int n0, int t,
                                              float *s_colsum, float alpha, float yqs, float &amx, bool &sat,
                                              bool fast) {
-    if (P == 2 && fast && p.yparts && (p.Cout & 7) == 0 && !(p.dbg & 32)) {      // (dbg 32: A/B against the 4-wide slab)
-        if (p.res_parts) epilogue_slab_w8<NCOLQ / 2, LD, NTHREADS, 2>(p, stage, m_base, n0, t, s_colsum, alpha, yqs, amx);
-        else if (p.residual) epilogue_slab_w8<NCOLQ / 2, LD, NTHREADS, 1>(p, stage, m_base, n0, t, s_colsum, alpha, yqs, amx);
-        else epilogue_slab_w8<NCOLQ / 2, LD, NTHREADS, 0>(p, stage, m_base, n0, t, s_colsum, alpha, yqs, amx);
-    } else if (P == 2 && fast) {
+    if (P == 2 && fast) {
 #define SLN_EPI(R, Q) epilogue_slab_f16<NCOLQ, LD, NTHREADS, R, Q>(p, stage, m_base, n0, t, s_colsum, alpha, yqs, amx)
         if (p.res_parts) {
             if (p.yparts) SLN_EPI(2, true); else SLN_EPI(2, false);
@@ -1299,8 +1383,7 @@ __global__ __launch_bounds__(256, BNT == 128 ? SLN_FWD128_BLOCKS : 1) void conv_
     // (t>>5) + 8q.  Per element: v = acc*scale[c] + shift[c] (+ residual) (ReLU).
     float(*stage)[SLD] = (float(*)[SLD])smem;
     const bool plain = P == 2 && epilogue_is_plain(p) && !(p.dbg & 16);
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    auto stage_slab = [&](int h) {
         // rows 64h .. 64h+63 of the tile: waves wr == h (BNT 128, 64 rows each) or wr>>1 == h (BNT 64, 32 each)
         if ((BNT == 128 ? wr : wr >> 1) == h) {
             const int rbase = BNT == 128 ? 0 : (wr & 1) * 32;
@@ -1313,9 +1396,17 @@ __global__ __launch_bounds__(256, BNT == 128 ? SLN_FWD128_BLOCKS : 1) void conv_
                         stage[rbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)][wc * 64 + j * 32 + (lane & 31)] =
                             acc[i][j][r];
         }
-        __syncthreads();
-        epilogue_any<P, BNT / 4, SLD, 256>(p, &stage[0][0], m0 + h * 64, n0, t, s_colsum, alpha, yqs, amx, sat, plain);
-        __syncthreads();
+    };
+    if (plain && epilogue_is_w8(p)) {
+        epilogue_tile_w8_any<BNT / 8, SLD, 256, 2>(p, &stage[0][0], m0, n0, t, s_colsum, alpha, yqs, amx, stage_slab);
+    } else {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            stage_slab(h);
+            __syncthreads();
+            epilogue_any<P, BNT / 4, SLD, 256>(p, &stage[0][0], m0 + h * 64, n0, t, s_colsum, alpha, yqs, amx, sat, plain);
+            __syncthreads();
+        }
     }
     if (p.colsum && t < BNT && n0 + t < p.Cout && s_colsum[t] != 0.f)   // one global atomic per column
         atomicAdd(p.colsum + n0 + t, s_colsum[t]);
@@ -1768,8 +1859,7 @@ __global__ __launch_bounds__(512) void conv_fwd256h_kernel(const ConvParams p) {
     static_assert(64 * 260 * 4 <= 2 * STAGE, "staging slab must fit");
     const bool plain = epilogue_is_plain(p) && !(p.dbg & 16);      // (dbg 16: A/B against epilogue_slab)
     SLN_STAMP(t0);
-#pragma unroll
-    for (int h = 0; h < 4; ++h) {
+    auto stage_slab = [&](int h) {
         if (wr == (h >> 1)) {
 #pragma unroll
             for (int ii = 0; ii < 2; ++ii)
@@ -1780,17 +1870,25 @@ __global__ __launch_bounds__(512) void conv_fwd256h_kernel(const ConvParams p) {
                         stage[(ii * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 260 + wc * 64 + j * 32 +
                               (lane & 31)] = acc[2 * (h & 1) + ii][j][r];
         }
-        SLN_STAMP(t1);
-        __syncthreads();
-        SLN_STAMP(t2);
-        epilogue_any<P, 64, 260, 512>(p, stage, m0 + h * 64, n0, t, s_colsum, alpha, yqs, amx, sat, plain);
-        SLN_STAMP(t3);
-        __syncthreads();
-        SLN_STAMP(t4);
-        if (STAMP && NPH == 2) {
-            sums[11] += t1 - t0; sums[12] += t2 - t1; sums[13] += t3 - t2; sums[14] += t4 - t3;
+    };
+    if (plain && epilogue_is_w8(p)) {
+        epilogue_tile_w8_any<32, 260, 512, 4>(p, stage, m0, n0, t, s_colsum, alpha, yqs, amx, stage_slab);
+    } else {
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            stage_slab(h);
+            SLN_STAMP(t1);
+            __syncthreads();
+            SLN_STAMP(t2);
+            epilogue_any<P, 64, 260, 512>(p, stage, m0 + h * 64, n0, t, s_colsum, alpha, yqs, amx, sat, plain);
+            SLN_STAMP(t3);
+            __syncthreads();
+            SLN_STAMP(t4);
+            if (STAMP && NPH == 2) {
+                sums[11] += t1 - t0; sums[12] += t2 - t1; sums[13] += t3 - t2; sums[14] += t4 - t3;
+            }
+            t0 = t4;
         }
-        t0 = t4;
     }
     if (p.colsum && t < T2 && n0 + t < p.Cout && s_colsum[t] != 0.f) atomicAdd(p.colsum + n0 + t, s_colsum[t]);
     if (plain) sat = amx * yqs > SLN_F16_MAX;      // the fixed-feature slabs clamp without recording it
@@ -2655,6 +2753,7 @@ extern "C" int sln_conv2d_fwd_ms_f32(const uint16_t *x_parts, int nseg, const in
                                      sln_stream_t stream) {
     sln_enter();
     if ((residual_parts && residual) || (mask_part0 && mask)) return SLN_ERR_INVALID_ARG;
+    if (residual_parts && (mask || mask_part0)) return SLN_ERR_UNSUPPORTED;   // (no such reader on the path)
     if (!x_parts || !w_parts || (!y && !y_parts) || !seg_nhw || nseg < 1 || nseg > SLN_MAX_SEG || Cin < 1 || Cout < 1 ||
         KH < 1 || KW < 1 || stride_h < 1 || stride_w < 1 || dil_h < 1 || dil_w < 1)
         return SLN_ERR_INVALID_ARG;

@@ -51,6 +51,10 @@ for (name, N, Cin, H, Cout, k) in LAYERS:
         "parts only":        (lambda: conv_hip._fwd(*A, sc, sf, None, True, out_parts=True, want_y=False, yslot=slot, **common), 4 * Cin + 4 * Cout),
         "res32+y+parts":     (lambda: conv_hip._fwd(*A, sc, sf, res, True, out_parts=True, yslot=slot, **common), 4 * Cin + 12 * Cout),
         "res16+parts only":  (lambda: conv_hip._fwd(*A, sc, sf, None, True, out_parts=True, want_y=False, yslot=slot, res_parts=(rp, rq), **common), 4 * Cin + 8 * Cout),
+        # backward shapes: a chained data gradient (producer's mask from part 0, parts + column sums, no fp32 output)
+        # and the block-input one (fp32 shortcut gradient in, masked fp32 gradient + scaled parts out)
+        "mask16+parts+colsum": (lambda: conv_hip._fwd(*A, sc, None, None, False, out_parts=True, want_y=False, want_colsum=True, yslot=slot, mask_parts=rp, **common), 4 * Cin + 6 * Cout),
+        "res32+mask16+y+parts": (lambda: conv_hip._fwd(*A, None, None, res, False, out_parts=True, want_y=True, want_colsum=True, post_scale=sc, yslot=slot, mask_parts=rp, **common), 4 * Cin + 14 * Cout),
     }
     for v in variants.values():
         v[0](); v[0]()
@@ -58,7 +62,7 @@ for (name, N, Cin, H, Cout, k) in LAYERS:
     print("%s  [%s]  M=%d  %.1f GFLOP" % (name, conv_hip._fwd_kernel_name(layout, 2), M, fl / 1e9))
     for vn, (f, bpp) in variants.items():
         row = []
-        for dbg in ("0", "64", "32", "1", "2"):
+        for dbg in ("0", "32", "1", "2"):
             os.environ["SLN_CONV_DBG"] = dbg
             t = timeit(f)
             row.append("%s %.3f ms" % ({"0": "full", "64": "nt", "32": "4-wide", "1": "noDMA", "2": "noMFMA"}[dbg], t))
