@@ -870,8 +870,28 @@ __device__ __forceinline__ void epilogue_slab_f16(const ConvParams &p, const flo
     // backward extras (uniform per launch): the producer's ReLU mask (its fp32 output, or part 0 of an output
     // that exists as parts only), a scale applied to the parts and column sums only, per-channel sums of what
     // the parts hold (the previous layer's bias gradient)
-    const float *mk = p.mask ? p.mask + o0 : nullptr;
-    const __bf16 *mk16 = p.mask_part0 ? p.mask_part0 + q0 : nullptr;
+    // the ReLU pattern's rows as a block too, before the first store (a load may not be moved above a store
+    // that might alias: inside the row loop every row waited a full memory round trip for its mask)
+    float4 mk4[NQ];
+    h16x4 mk16v[NQ];
+    const bool has_mk = p.mask != nullptr, has_mk16 = p.mask_part0 != nullptr;
+    if (has_mk) {
+        const float *mk = p.mask + o0;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            mk4[q] = (m_base + row0 + RG * q) < p.M ? *(const float4 *)mk : make_float4(0.f, 0.f, 0.f, 0.f);
+            mk += ostep;
+        }
+    }
+    if (has_mk16) {
+        const __bf16 *mk16 = p.mask_part0 + q0;
+        const h16x4 z4 = {};
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            mk16v[q] = (m_base + row0 + RG * q) < p.M ? *(const h16x4 *)mk16 : z4;
+            mk16 += pstep;
+        }
+    }
     float4 ps4 = make_float4(1.f, 1.f, 1.f, 1.f);
     if (p.post_scale) ps4 = *(const float4 *)(p.post_scale + c);
     float csum[4] = {0.f, 0.f, 0.f, 0.f};
@@ -902,15 +922,15 @@ __device__ __forceinline__ void epilogue_slab_f16(const ConvParams &p, const flo
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
             }
-            if (mk) {
-                const float4 k4 = *(const float4 *)mk;
+            if (has_mk) {
+                const float4 k4 = mk4[q];
                 if (!(k4.x > 0.f)) v[0] = 0.f;
                 if (!(k4.y > 0.f)) v[1] = 0.f;
                 if (!(k4.z > 0.f)) v[2] = 0.f;
                 if (!(k4.w > 0.f)) v[3] = 0.f;
             }
-            if (mk16) {
-                const h16x4 k4 = *(const h16x4 *)mk16;
+            if (has_mk16) {
+                const h16x4 k4 = mk16v[q];
                 if (!(k4.x > (_Float16)0)) v[0] = 0.f;
                 if (!(k4.y > (_Float16)0)) v[1] = 0.f;
                 if (!(k4.z > (_Float16)0)) v[2] = 0.f;
@@ -936,8 +956,6 @@ __device__ __forceinline__ void epilogue_slab_f16(const ConvParams &p, const flo
             }
         }
         if (yp) yp += ostep;
-        if (mk) mk += ostep;
-        if (mk16) mk16 += pstep;
         if (PARTS) { p0 += pstep; p1 += pstep; }
     }
     if (p.colsum) {   // the row groups share a column: combine in LDS first
