@@ -429,7 +429,8 @@ class RPN(nn.Module):
         # the shared map has exactly two readers (the two 1x1 heads): whichever data gradient runs second
         # adds the first one, applies the ReLU mask and hands conv_shared its prepared gradient
         ch = {"readers": 2} if CHAIN_TWO_READERS else None
-        x = nn_ops.conv_bn_act(x, self.conv_shared, relu=True, same=True, chain_out=ch)
+        # (its only readers are the two 1x1 heads and their ReLU mask: no fp32 copy of the 512-channel map)
+        x = nn_ops.conv_bn_act(x, self.conv_shared, relu=True, same=True, chain_out=ch, parts_only=True)
         # NHWC output == the reference's permute(0,2,3,1).contiguous()
         logits = nn_ops.conv_bn_act(x, self.conv_class, chain_in=ch).permute(0, 2, 3, 1).reshape(B, -1, 2)
         probs = self.softmax(logits)
@@ -504,9 +505,10 @@ class Mask(nn.Module):
             x = x.contiguous(memory_format=torch.channels_last)
         conv = nn_ops.conv_bn_act
         c12, c23, c34 = {}, {}, {}   # conv1 -> conv2 -> conv3 -> conv4: one reader each (chained gradients)
-        x = conv(x, self.conv1, self.bn1, relu=True, same=True, chain_out=c12)
-        x = conv(x, self.conv2, self.bn2, relu=True, same=True, chain_in=c12, chain_out=c23)
-        x = conv(x, self.conv3, self.bn3, relu=True, same=True, chain_in=c23, chain_out=c34)
+        # conv1..conv3 feed one convolution each (and its ReLU mask): parts only, no fp32 copy
+        x = conv(x, self.conv1, self.bn1, relu=True, same=True, chain_out=c12, parts_only=True)
+        x = conv(x, self.conv2, self.bn2, relu=True, same=True, chain_in=c12, chain_out=c23, parts_only=True)
+        x = conv(x, self.conv3, self.bn3, relu=True, same=True, chain_in=c23, chain_out=c34, parts_only=True)
         feat = conv(x, self.conv4, self.bn4, relu=True, same=True, chain_in=c34)   # feat is also returned
         # deconv + ReLU + 1x1 logits; the sigmoid lives in the losses (modals.py:494-497)
         x = nn_ops.deconv2x2_relu_conv1x1(feat, self.deconv, self.conv5)

@@ -290,13 +290,18 @@ def deconv2x2_relu_conv1x1(x, deconv, conv):
     Ci, Co = deconv.weight.shape[0], deconv.weight.shape[1]
     w2 = deconv.weight.permute(2, 3, 1, 0).reshape(4 * Co, Ci, 1, 1)
     b2 = deconv.bias.repeat(4) if deconv.bias is not None else None
+    # (the 4*Cout-channel map -- the largest activation of the head -- is read by the logits conv and as its own
+    # ReLU mask only: parts only, no fp32 copy)
     y = hip._ConvFn.apply(x, w2, b2, None, None, None, True, (1, 1), (1, 1), (0, 0, 0, 0), None, None, None,
-                          deconv.weight)
+                          deconv.weight, None, PARTS_ONLY)
     N, _, H, W = y.shape
     y4 = y.permute(0, 2, 3, 1).reshape(N, H, W * 4, Co).permute(0, 3, 1, 2)     # pixel (i, 4j + 2a + b)
     hit = getattr(y, "_sln_parts", None)
     if hit is not None and hit[0][0] == y._version:     # the epilogue's parts of y are y4's, re-viewed
         y4._sln_parts = ((y4._version,) + tuple(hit[0][1:]), hit[1].view(hit[1].shape[0], -1, Co), hit[2])
+        po = getattr(y, "_sln_po", None)
+        if po is not None:
+            y4._sln_po = (y4._sln_parts[1], po[1], po[2])
     z = conv_bn_act(y4, conv)
     K = z.shape[1]
     z = z.permute(0, 2, 3, 1).reshape(N, H, W, 2, 2, K).permute(0, 5, 1, 3, 2, 4)

@@ -332,7 +332,9 @@ def test_config3_full_size_train_step_resnet101_16x1024():
     assert float(m.last_grad_norm) > 0 and np.isfinite(float(m.last_grad_norm))
     same = [n for n, p in m.named_parameters() if p.requires_grad and torch.equal(p.detach(), before[n])]
     assert not same, same[:10]
-    assert torch.cuda.max_memory_allocated() > 40 * 2 ** 30      # it really was the full-size step
+    # it really was the full-size step (58 GB with fp32 copies of every activation, 37 GB since the
+    # bottleneck / RPN / mask-head activations are kept as parts only)
+    assert torch.cuda.max_memory_allocated() > 25 * 2 ** 30
     del before, batch, opt
     m.zero_grad(set_to_none=True)
     # ---- the step's largest layer shapes, HIP vs aten fp32 ----
