@@ -2356,6 +2356,9 @@ __device__ __forceinline__ int div_small(int a, int d, float rd) {   // a < 2^24
     return q;
 }
 
+// MS = 16: v_mfma_f32_16x16x32_f16 (see conv_fwd256h_kernel): a stage's 32 pixels are one instruction's K; lane group
+// g (16 lanes) reads pixels 8g..8g+7 of the same 16 channels with two transposing reads.
+template <int MS>
 __global__ __launch_bounds__(512) void conv_wgrad256h_kernel(const WgradParams p) {
     constexpr int P = 2;
     constexpr int KS = 32;                       // pixels per stage
@@ -2440,8 +2443,15 @@ __global__ __launch_bounds__(512) void conv_wgrad256h_kernel(const WgradParams p
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int g4 = lane >> 4;
-    const int k0 = 8 * (g4 >> 1);
-    const int cb = 64 * wc + 16 * (g4 & 1), ca = 128 * wr + 16 * (g4 & 1);
+    const int k0 = MS == 16 ? 8 * g4 : 8 * (g4 >> 1);
+    const int cb = 64 * wc + (MS == 16 ? 0 : 16 * (g4 & 1)), ca = 128 * wr + (MS == 16 ? 0 : 16 * (g4 & 1));
+    f32x4v acc16[8][4];
+    if (MS == 16) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc16[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    }
     if (nk > 0) {
         stage_offsets();
 #pragma unroll
@@ -2455,13 +2465,28 @@ __global__ __launch_bounds__(512) void conv_wgrad256h_kernel(const WgradParams p
     asm volatile("" ::: "memory");
 
     typedef __attribute__((address_space(3))) unsigned char lds_u8;
+    bf16x8 b16[4][P];
     for (int s = 0; s < nk; ++s) {
         const unsigned st = (unsigned)(size_t)(lds_u8 *)(smem + (s & 1) * STAGE);
         const bool more = s + 1 < nk;
 #pragma unroll
         for (int ph = 0; ph < 2; ++ph) {
-            TrFrag fa[4][P], fb[2][P];
-            const int kk = 16 * ph + k0;
+            TrFrag fa[4][P], fb[MS == 16 ? 4 : 2][P];
+            const int kk = (MS == 16 ? 0 : 16 * ph) + k0;
+            if (MS == 16) {
+                // phase 0: the four channel tiles of x (kept for phase 1) and gz tiles 0..3; phase 1: gz tiles 4..7
+                if (ph == 0) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int pp = 0; pp < P; ++pp) tr_issue(fb[j][pp], st + (P + pp) * REGION, kk, cb + 16 * j, lane);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int pp = 0; pp < P; ++pp)
+                        tr_issue(fa[i][pp], st + pp * REGION, kk, ca + 16 * (4 * ph + i), lane);
+            } else {
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -2470,6 +2495,7 @@ __global__ __launch_bounds__(512) void conv_wgrad256h_kernel(const WgradParams p
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int pp = 0; pp < P; ++pp) tr_issue(fa[i][pp], st + pp * REGION, kk, ca + 32 * i, lane);
+            }
             __builtin_amdgcn_sched_barrier(0);
             if (more && ph == 0) {
 #pragma unroll
@@ -2486,19 +2512,35 @@ __global__ __launch_bounds__(512) void conv_wgrad256h_kernel(const WgradParams p
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             bf16x8 a[4][P], b[2][P];
+            if (MS == 16) {
+                if (ph == 0) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int pp = 0; pp < P; ++pp) b16[j][pp] = tr_value(fb[j][pp]);
+                }
+            } else {
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int pp = 0; pp < P; ++pp) b[j][pp] = tr_value(fb[j][pp]);
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int pp = 0; pp < P; ++pp) a[i][pp] = tr_value(fa[i][pp]);
             __builtin_amdgcn_s_setprio(1);
+            if (MS == 16) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) mfma16_products(a[i], b16[j], acc16[4 * ph + i][j]);
+            } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) mfma_products<P>(a[i], b[j], acc[i][j]);
+            }
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
@@ -2509,6 +2551,25 @@ __global__ __launch_bounds__(512) void conv_wgrad256h_kernel(const WgradParams p
 
     // epilogue: row = co, col = ci; partial slab (two-phase split-K) or atomics
     const float alpha = operand_unscale(p.gz_scale, p.x_scale);
+    if (MS == 16) {     // C layout of 16x16: column lane % 16, rows 4 * (lane / 16) + r
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ci = n0 + wc * 64 + j * 16 + (lane & 15);
+            if (ci >= p.Cin) continue;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int co = m0 + wr * 128 + i * 16 + 4 * (lane >> 4) + r;
+                    if (co >= p.Cout) continue;
+                    const float v = acc16[i][j][r] * alpha;
+                    const long e = ((long)co * p.KH * p.KW + tap) * p.Cin + ci;
+                    if (p.partial) p.partial[(long)split * ((long)p.Cout * p.KH * p.KW * p.Cin) + e] = v;
+                    else if (v != 0.f) atomicAdd(p.gw + e, v);
+                }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int ci = n0 + wc * 64 + j * 32 + (lane & 31);
@@ -3026,7 +3087,10 @@ extern "C" int sln_conv2d_wgrad_f32(const uint16_t *gz_parts, int Cout, int Cout
         const bool h = parts == 2 && sln_knob("SLN_WGRAD_F16_KERNEL", 1) && M < (1L << 24) &&
                        p.gz_part_stride * 2 < 4294967295L && p.x_part_stride * 2 < 4294967295L;
         if (h)
-            hipLaunchKernelGGL(conv_wgrad256h_kernel, dim3((unsigned)nblk), dim3(512), 0, st, p);
+            if (sln_knob("SLN_WGRAD_MFMA16", 0))      // (same-box A/B on the train step: no difference, 85.6 / 85.7 img/s)
+                hipLaunchKernelGGL(conv_wgrad256h_kernel<16>, dim3((unsigned)nblk), dim3(512), 0, st, p);
+            else
+                hipLaunchKernelGGL(conv_wgrad256h_kernel<32>, dim3((unsigned)nblk), dim3(512), 0, st, p);
         else if (parts == 2)
             hipLaunchKernelGGL(conv_wgrad256_kernel<2>, dim3((unsigned)nblk), dim3(512), 0, st, p);
         else
