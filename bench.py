@@ -38,7 +38,7 @@ def split_peak(parts):
 PEAK_HBM_GBS = 8000.0
 # HBM bytes per launch cannot be collected live (PMC needs rocprofv3 around the process): the bench line
 # REPLAYS the committed counter passes of the same command and marks them as such
-PMC_TRAFFIC = os.path.join("profiles", "r2_v4_pmc_traffic.json")
+PMC_TRAFFIC = os.path.join("profiles", "r3_v3_pmc_traffic.json")
 
 
 def step_gflop_per_image(stage, dim, arch):
@@ -249,6 +249,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     prof, conv_hip.PROFILE = conv_hip.PROFILE, None
+    max_mem_gb = round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)      # (of the fp16 x 2 steps: before the strict leg)
     # the same step in the strict operand format (3 x bf16, 6 MFMA products per multiply-add: >= fp32 per
     # element), 2 untimed + 5 timed steps, so that the fp16 x 2 line always sits next to it
     strict = None
@@ -297,7 +298,7 @@ def main():
                        if conv_hip.PARTS == 2 else "3 x bf16 (6 MFMA products per fp32 multiply-add)",
                        "final_loss": round(final_loss, 5),
                        "loss_trace": [round(float(l), 4) for l in losses[:: max(1, len(losses) // 8)]],
-                       "max_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
+                       "max_mem_gb": max_mem_gb,
                        # fp16 x 2 operands: blocks that had to clamp a value to +-65504 since start-up
                        # (set-up, warm-up steps, timed steps)
                        "conv_saturated_blocks": [sat_setup, sat_warmup - sat_setup,

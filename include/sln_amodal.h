@@ -352,6 +352,10 @@ int64_t sln_rle_from_string(const char *s, int64_t len, uint32_t *counts, int64_
  * read whole consecutive 128-B lines (sln_conv_tiled_weight_elems() elements per part, zero padded).
  * (TILED256H: the same for the fp16 x 2 kernel's 32-channel stages.)  A forward call must pass the
  * layout its kernel uses: sln_conv_fwd_weights_layout(). */
+/* Column sums (colsum of sln_conv2d_fwd_ms_f32, gbias of sln_conv_grad_prep_f32) are accumulated with atomics into a
+ * buffer the callee zeroes first -- one fill launch per layer and step.  A caller that hands over memory it has
+ * already cleared (slices of an arena zeroed once per step) ORs this flag into `relu` / `parts` to skip the fill. */
+#define SLN_SUMS_PREZEROED 0x100
 #define SLN_WEIGHTS_ROWS 0
 #define SLN_WEIGHTS_TILED256 1
 #define SLN_WEIGHTS_TILED256H 2 /* parts = 2 only: 32-channel stages, 16-KB blocks */

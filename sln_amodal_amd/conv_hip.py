@@ -164,6 +164,7 @@ def update_scales(sync=True):
     for b in _books.values():
         b.update(sync)
     SCALE_EPOCH[0] += 1
+    _arena_reset()
 
 
 def check_ranks():
@@ -369,6 +370,39 @@ def _act_split(xc2d, M, C, parts, slot):
     return out
 
 
+# ------------------------------------------------------------------ zeroed arena for per-channel sums
+# Bias gradients (the column sums of a prepared gradient) are accumulated with atomics into zeroed memory: ~130
+# fill launches per train step when every layer clears its own [Cout] vector.  Instead one arena per device is
+# cleared once per step (update_scales) and the layers take slices of it (SLN_SUMS_PREZEROED).  A slice lives as
+# long as its tensor: the arena is REPLACED, not overwritten, when a step begins.
+SUMS_ARENA = os.environ.get("SLN_SUMS_ARENA", "1") != "0"      # A/B switch
+_ARENA = {}           # device index -> [tensor, cursor]
+ARENA_FLOATS = 1 << 20
+SLN_SUMS_PREZEROED = 0x100
+
+
+def _arena_reset():
+    for st in _ARENA.values():
+        st[0] = torch.zeros(ARENA_FLOATS, dtype=torch.float32, device=st[0].device)
+        st[1] = 0
+
+
+def _zeroed(n, device):
+    """-> (float32 [n] tensor, already_zero flag): a slice of the step's arena, or fresh memory the callee clears."""
+    if not SUMS_ARENA:
+        return torch.empty((n,), dtype=torch.float32, device=device), 0
+    st = _ARENA.get(device.index)
+    if st is None:
+        st = _ARENA[device.index] = [torch.zeros(ARENA_FLOATS, dtype=torch.float32, device=device), 0]
+    a = (n + 63) // 64 * 64
+    if st[1] + a > ARENA_FLOATS:          # (no update_scales() between many backward passes: start a new arena)
+        st[0] = torch.zeros(ARENA_FLOATS, dtype=torch.float32, device=device)
+        st[1] = 0
+    out = st[0][st[1]:st[1] + n]
+    st[1] += a
+    return out, SLN_SUMS_PREZEROED
+
+
 _NAN = {}
 
 
@@ -506,7 +540,7 @@ def _fwd(xparts, N, H, W, w, Cout, KH, KW, stride, dil, pt, pl, OH, OW, scale, s
     if out_parts and not fresh:   # the epilogue also emits the output's parts (next layer's operand)
         alloc = torch.empty if Cout % 8 == 0 else torch.zeros   # pad channels must be zero
         yp = alloc((P, N * OH * OW, _pad8(Cout)), dtype=torch.bfloat16, device=dev)
-    cs = torch.empty((Cout,), dtype=torch.float32, device=dev) if want_colsum else None
+    cs, cs_flag = _zeroed(Cout, dev) if want_colsum else (None, 0)
     pb = (OH - 1) * stride[0] + dil[0] * (KH - 1) + 1 - H - pt
     pr = (OW - 1) * stride[1] + dil[1] * (KW - 1) + 1 - W - pl
     seg = (C.c_int32 * 3)(N, H, W)
@@ -514,7 +548,7 @@ def _fwd(xparts, N, H, W, w, Cout, KH, KW, stride, dil, pt, pl, OH, OW, scale, s
     _lib.check(_lib.lib().sln_conv2d_fwd_ms_f32(
         ops._ptr(xparts), 1, seg, xparts.shape[2], ops._ptr(wparts), layout, P, Cout, KH, KW,
         stride[0], stride[1], dil[0], dil[1], pt, pl, pb, pr, ops._ptr(scale), ops._ptr(shift),
-        ops._ptr(residual), 1 if relu else 0, ops._ptr(mask), ops._ptr(post_scale), ops._ptr(y),
+        ops._ptr(residual), (1 if relu else 0) | cs_flag, ops._ptr(mask), ops._ptr(post_scale), ops._ptr(y),
         ops._ptr(yp), ops._ptr(cs), ops._ptr(xq), ops._ptr(wq), *_q3(yslot if yp is not None and P == 2 else None),
         ops._ptr(res_parts[0]) if res_parts is not None else None,
         ops._ptr(res_parts[1]) if res_parts is not None else None,
@@ -663,13 +697,13 @@ def _grad_prep(gy, y, scale, want_gu, want_bias, parts, slot=None):
     write_gu = want_gu and (y is not None or y16 is not None)
     if write_gu:
         gu = torch.empty((N, H, W, C), dtype=torch.float32, device=gy.device).permute(0, 3, 1, 2)
-    gb = torch.empty((C,), dtype=torch.float32, device=gy.device) if want_bias else None
+    gb, gb_flag = _zeroed(C, gy.device) if want_bias else (None, 0)
     if parts == 2 and slot is None:
         raise RuntimeError("two-part gradient preparation needs a scale slot")
 
     def launch(dst):
         _lib.check(_lib.lib().sln_conv_grad_prep_f32(
-            ops._ptr(gy), ops._ptr(y), ops._ptr(y16), ops._ptr(scale), M, C, Cp, parts,
+            ops._ptr(gy), ops._ptr(y), ops._ptr(y16), ops._ptr(scale), M, C, Cp, parts | (gb_flag if dst is not None else 0),
             ops._ptr(gu) if write_gu else None, ops._ptr(dst), ops._ptr(gb), *_q3(slot if parts == 2 else None),
             ops._stream()), "sln_conv_grad_prep_f32")
     if parts == 2 and slot.fresh:

@@ -2839,11 +2839,16 @@ extern "C" int sln_conv_grad_prep_f32(const float *gy, const float *y, const uin
                                       float *gbias, const float *q_scale, float *q_amax,
                                       int32_t *q_saturated, sln_stream_t stream) {
     sln_enter();
+    // (parts | SLN_SUMS_PREZEROED: the caller hands gbias over already zero -- slices of one arena it clears once
+    // per step -- and the fill launch per layer is saved)
+    const bool sums_zero = (parts & SLN_SUMS_PREZEROED) != 0;
+    parts &= ~SLN_SUMS_PREZEROED;
     if (M < 0 || C < 1 || C_pad < C || (C_pad & 7) || parts < 2 || parts > 3) return SLN_ERR_INVALID_ARG;
     if (!gy || (!gz_parts && !(parts == 2 && q_amax))) return SLN_ERR_INVALID_ARG;
     if (y_part0 && (y || parts != 2)) return SLN_ERR_INVALID_ARG;   // one ReLU pattern; fp16 parts only
     hipStream_t st = (hipStream_t)stream;
-    if (gz_parts && gbias && hipMemsetAsync(gbias, 0, sizeof(float) * C, st) != hipSuccess) return SLN_ERR_LAUNCH;
+    if (!sums_zero && gz_parts && gbias && hipMemsetAsync(gbias, 0, sizeof(float) * C, st) != hipSuccess)
+        return SLN_ERR_LAUNCH;
     if (M == 0) return SLN_OK;
     int tw = 1;
     while (tw < C_pad / 4 && tw < 256) tw <<= 1;
@@ -2926,7 +2931,9 @@ extern "C" int sln_conv2d_fwd_ms_f32(const uint16_t *x_parts, int nseg, const in
         p.segH[q] = p.segW[q] = p.segOH[q] = p.segOW[q] = 1;
         p.seg_m0[q] = 2147483647; p.seg_x0[q] = 0;
     }
-    if (colsum && hipMemsetAsync(colsum, 0, sizeof(float) * Cout, (hipStream_t)stream) != hipSuccess)
+    const bool sums_zero = (relu & SLN_SUMS_PREZEROED) != 0;      // colsum arrives zeroed (see sln_amodal.h)
+    relu &= 1;
+    if (colsum && !sums_zero && hipMemsetAsync(colsum, 0, sizeof(float) * Cout, (hipStream_t)stream) != hipSuccess)
         return SLN_ERR_LAUNCH;
     if (M == 0) return SLN_OK;
     if (M > 2147483647L - BM || Min > 2147483647L) return SLN_ERR_UNSUPPORTED;
