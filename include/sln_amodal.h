@@ -207,6 +207,27 @@ int sln_upsample2x_add_f32(const float *lateral, const float *top, int N, int h,
 int sln_sumpool2x2_f32(const float *g, int N, int h, int w, int C, float *gtop, sln_stream_t stream);
 
 /* ---------------------------------------------------------------------------
+ * Pyramid RoIAlign backward as a write-once gather (no zero fill, no atomics, bit-reproducible).
+ * Replaces: crop_and_resize_gpu_backward's memset + atomicAdd scatter
+ *           (roialign/roi_align/src/cuda/crop_and_resize_kernel.cu:118-215) for the crops of
+ *           pyramid_roi_align (modal/modals.py:66-108), for up to 4 crop sets of the SAME four maps at once
+ *           (classifier 7x7 + mask 16x16: modals.py:438, 479).
+ * Host arrays of length nsrc describe the sources: grads[i] [K_i][ch_i][cw_i][g_cstride_i] with the C channels
+ * at g_coffset_i, boxes / box_ind / level as in sln_pyramid_crop_fwd_f32 (box_ind < 0: padded slot), ch, cw <= 32.
+ * Every element of the four grad_maps [B][H_l][W_l][C] is WRITTEN (zeros where no roi reaches): per 8x8 map tile
+ * a block finds the rois of its image and level that meet the tile, inverts their bin taps per map row /
+ * column and sums w_x * (w_y * g) -- the reference's products, a fixed order of additions.
+ * workspace: sln_pyramid_crop_bwd_gather_workspace_bytes(sum K_i, B) bytes (per-image roi lists).
+ * ------------------------------------------------------------------------- */
+size_t sln_pyramid_crop_bwd_gather_workspace_bytes(int total_rois, int B);
+int sln_pyramid_crop_bwd_gather_f32(int nsrc, const float *const *grads, const int32_t *g_cstride,
+                                    const int32_t *g_coffset, const float *const *boxes,
+                                    const int32_t *const *box_ind, const int32_t *const *level, const int32_t *K,
+                                    const int32_t *ch, const int32_t *cw, int B, int C, float *const *grad_maps,
+                                    const int32_t *map_hw, void *workspace, size_t workspace_bytes,
+                                    sln_stream_t stream);
+
+/* ---------------------------------------------------------------------------
  * Optimiser step: global-norm clip + momentum SGD over the whole parameter set.
  * Replaces: torch.nn.utils.clip_grad_norm(params, 5.0) followed by torch.optim.SGD.step()
  *           (model.py:441-444, optimizer built at model.py:352-358): one norm kernel per tensor,

@@ -43,6 +43,10 @@ SIGNATURES = {
                                       _f, _p, _i, _i, _p]),
     "sln_pyramid_crop_bwd_f32": (_i, [_p, _i, _i, _p, _p, _p, _i, _i, _i, _i, _i, C.POINTER(_p),
                                       C.POINTER(_i), _i, _p]),
+    "sln_pyramid_crop_bwd_gather_workspace_bytes": (C.c_size_t, [_i, _i]),
+    "sln_pyramid_crop_bwd_gather_f32": (_i, [_i, C.POINTER(_p), C.POINTER(_i), C.POINTER(_i), C.POINTER(_p),
+                                             C.POINTER(_p), C.POINTER(_p), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i),
+                                             _i, _i, C.POINTER(_p), C.POINTER(_i), _p, C.c_size_t, _p]),
     "sln_conv_tiled_weight_elems": (C.c_int64, [_i, _i, _i, _i, _i]),
     "sln_conv_fwd_weights_layout": (_i, [C.c_int64, _i, _i, _i, _i, C.c_int64]),
     "sln_debug_read_stamps": (_i, [_p]),

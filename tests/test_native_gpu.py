@@ -496,3 +496,39 @@ def test_max_pool_matches_torch_forward_and_argmax(shape, kind):
         assert same.float().mean() > 0.999 or (x > 0).float().mean() < 0.5
         pos = x > 0
         assert torch.equal(a.grad[pos], b.grad[pos])
+
+
+def test_pyramid_gather_backward_is_bit_reproducible_and_equals_the_scatter():
+    """The write-once gather (no zero fill, no atomics) gives the same bits on every run and the atomic
+    scatter's sums up to the order of the additions -- for one crop set and for two sets of the same maps
+    in one launch."""
+    from sln_amodal_amd.modal import modals
+    gen = torch.Generator().manual_seed(11)
+    B, C, R = 3, 96, 50
+    sizes = [(64, 64), (32, 32), (16, 16), (8, 8)]
+    ctr = torch.rand(B, R, 2, generator=gen) * 0.7 + 0.15
+    half = torch.exp(torch.rand(B, R, 2, generator=gen) * 3.0 - 4.0)
+    rois = torch.cat([ctr - half, ctr + half], dim=2).clamp(0, 1).cuda()
+    base = [torch.randn(B, C, h, w, generator=gen).cuda().contiguous(memory_format=torch.channels_last)
+            for h, w in sizes]
+    up7 = torch.randn(B * R, C, 7, 7, generator=gen).cuda()
+    up16 = torch.randn(B * R, C, 16, 16, generator=gen).cuda()
+
+    def run(gather, pooled):
+        saved = modals.GATHER_BACKWARD
+        modals.GATHER_BACKWARD = gather
+        try:
+            maps = [m.clone().requires_grad_(True) for m in base]
+            pool = modals.CropGradPool() if pooled else None
+            a = modals.pyramid_roi_align([rois] + maps, 7, (256, 256), grad_pool=pool)
+            b = modals.pyramid_roi_align([rois] + maps, 16, (256, 256), grad_pool=pool)
+            ((a * up7).sum() + (b * up16).sum()).backward()
+            return [m.grad.clone() for m in maps]
+        finally:
+            modals.GATHER_BACKWARD = saved
+
+    for pooled in (False, True):
+        g1, g2, s1 = run(True, pooled), run(True, pooled), run(False, pooled)
+        for a, b, c in zip(g1, g2, s1):
+            assert torch.equal(a, b)
+            assert (a - c).abs().max().item() <= 1e-5 * max(c.abs().max().item(), 1e-6)

@@ -43,35 +43,46 @@ def measure(dev, B=16):
     ms = [m.clone().requires_grad_(True) for m in maps]
     o = _PyramidCrop.apply(boxes, ind, lvl, pool, None, *ms)
     up = torch.randn_like(o)
+    # the op as the train step runs it: one-launch zero fill of the four maps + atomic scatter
     t = _time(lambda: torch.autograd.grad(o, ms, up, retain_graph=True))
-    # the same backward without the zero fill of the four gradient maps (accumulate mode: how the second crop
-    # of a train step runs), and the zero fill alone: the stand-alone op is their sum
+    from sln_amodal_amd.modal import modals as _modals
+    was = _modals.GATHER_BACKWARD
+    _modals.GATHER_BACKWARD = True
+    try:          # the deterministic option (SLN_CROP_GATHER=1): write-once gather, no fill, no atomics
+        t_gather = _time(lambda: torch.autograd.grad(o, ms, up, retain_graph=True))
+    finally:
+        _modals.GATHER_BACKWARD = was
+    # its two launches timed alone: the scatter in accumulate mode (how the second crop of a train step runs)
+    # and the zero fill (the same entry point with no rois)
     import ctypes as C
     from sln_amodal_amd import _lib
     grads = [torch.empty_like(m) for m in maps]
     ptrs = (C.c_void_p * 4)(*[t_.data_ptr() for t_ in grads])
     hw = (C.c_int * 8)(*[d for m in maps for d in (m.shape[2], m.shape[3])])
     upc = up.contiguous(memory_format=torch.channels_last)
-
-    def kernel_only():
-        _lib.check(_lib.lib().sln_pyramid_crop_bwd_f32(ops._ptr(upc), C_, 0, ops._ptr(boxes), ops._ptr(ind),
-                                                       ops._ptr(lvl), K, pool, pool, B, C_, ptrs, hw, 1,
-                                                       ops._stream()), "sln_pyramid_crop_bwd_f32")
     C_ = maps[0].shape[1]
-    tk = _time(kernel_only)
-    tz = _time(lambda: [g_.zero_() for g_ in grads])
+
+    def launch(k, accumulate):
+        _lib.check(_lib.lib().sln_pyramid_crop_bwd_f32(ops._ptr(upc), C_, 0, ops._ptr(boxes), ops._ptr(ind),
+                                                       ops._ptr(lvl), k, pool, pool, B, C_, ptrs, hw, accumulate,
+                                                       ops._stream()), "sln_pyramid_crop_bwd_f32")
+    tk = _time(lambda: launch(K, 1))
+    tz = _time(lambda: launch(0, 0))
     map_bytes = sum(g_.numel() * 4 for g_ in grads)
-    out["roialign_bwd"] = {"kernel": "pyr_bwd_patch_kernel (+memset of 4 grad maps)", "bound": "hbm",
+    out["roialign_bwd"] = {"kernel": "pyr_zero_kernel + pyr_bwd_patch_kernel", "bound": "hbm",
                            "bytes_per_elem": 36, "elems": elems, "ms": round(t * 1e3, 4),
                            "achieved": round(elems * 36 / t / 1e9, 1), "peak": PEAK_HBM_GBS,
                            "unit": "GB/s", "frac": round(elems * 36 / t / 1e9 / PEAK_HBM_GBS, 4),
-                           "kernel_only_ms": round(tk * 1e3, 4),
-                           "kernel_only_frac": round(elems * 36 / tk / 1e9 / PEAK_HBM_GBS, 4),
+                           "scatter_kernel_only_ms": round(tk * 1e3, 4),
+                           "scatter_kernel_only_frac": round(elems * 36 / tk / 1e9 / PEAK_HBM_GBS, 4),
                            "zero_fill_ms": round(tz * 1e3, 4), "zero_fill_bytes": map_bytes,
                            "zero_fill_gbs": round(map_bytes / tz / 1e9, 1),
-                           "note": "36 B / element is the algorithmic model (4 B load + 4 x 8 B atomic RMW); the four "
-                                   "maps total %d MB, so most of it is served by L2 / Infinity Cache -- measured "
-                                   "FETCH_SIZE / WRITE_SIZE: profiles/ (pmc_roialign)" % (map_bytes >> 20)}
+                           "gather_form_ms": round(t_gather * 1e3, 4),
+                           "note": "ms = the whole op (zero fill + scatter, two launches). 36 B / element is the "
+                                   "algorithmic model (4 B load + 4 x 8 B atomic RMW); the four maps total %d MB, so "
+                                   "most of it is served by L2 / Infinity Cache -- measured FETCH_SIZE / WRITE_SIZE: "
+                                   "profiles/ (pmc_roialign).  gather_form_ms: the deterministic write-once option "
+                                   "(SLN_CROP_GATHER=1)" % (map_bytes >> 20)}
     # ---- NMS: 16 images x 6000 boxes ----
     N = 6000
     tl = torch.rand(B, N, 2, device=dev, generator=g) * 900
