@@ -269,6 +269,7 @@ def main():
     if os.environ.get("SLN_DEBUG_BN_CACHE") and rank == 0:
         print("shortcut-gradient links handed over/consumed:", conv_hip.LINK_STATS, file=sys.stderr)
         print("chained gradient preparations handed over/used:", conv_hip.CHAIN_STATS, file=sys.stderr)
+        print("weight gradients on the side / main stream:", conv_hip.SIDE_STATS, file=sys.stderr)
         print("bn_affine cache hits/misses:", nn_ops.BN_CACHE_STATS, file=sys.stderr)
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:

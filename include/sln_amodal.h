@@ -449,6 +449,22 @@ int sln_conv_wgrad_tile(int64_t M, int Cout, int Cin, int taps, int parts);
  * gw_layout 0: gw [Cout][KH][KW][Cin]; 1: gw [Cout][Cin][KH][KW], the parameter's own order (written by the
  * reduce pass: needs the workspace), so that no layout copy stands between the kernel and the optimiser. */
 size_t sln_conv_wgrad_workspace_bytes(int64_t M, int Cout, int Cin, int taps, int parts);
+/* gw_layout | SLN_WGRAD_DEFER_REDUCE: only the partial sums are written (workspace required, gw may be NULL);
+ * the caller adds them later with sln_wgrad_reduce_batch_f32 -- the reduce passes of up to
+ * SLN_WGRAD_REDUCE_BATCH layers in one launch.  An entry: partial = the layer's workspace, gw = its gradient,
+ * n = Cout*KH*KW*Cin, ksplit = sln_conv_wgrad_ksplit() of the same problem, taps = KH*KW if the gradient is wanted
+ * in the parameter's own order (gw_layout 1) and KH*KW > 1, else 0.  `descs` is HOST memory (copied into the
+ * launch).  Same summation tree as the per-layer reduce: the same bits. */
+#define SLN_WGRAD_DEFER_REDUCE 2
+#define SLN_WGRAD_REDUCE_BATCH 16
+typedef struct {
+    const float *partial;
+    float *gw;
+    int64_t n;
+    int32_t ksplit, taps, Cin, reserved;
+} sln_wgrad_reduce_desc_t;
+int sln_conv_wgrad_ksplit(int64_t M, int Cout, int Cin, int taps, int parts);
+int sln_wgrad_reduce_batch_f32(const sln_wgrad_reduce_desc_t *descs, int n, sln_stream_t stream);
 int sln_conv2d_wgrad_f32(const uint16_t *gz_parts, int Cout, int Cout_pad, const uint16_t *x_parts,
                          int N, int H, int W, int Cin, int Cin_pad, int parts, int KH, int KW,
                          int stride_h, int stride_w, int dil_h, int dil_w, int pad_top, int pad_left,

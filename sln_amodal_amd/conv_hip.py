@@ -14,6 +14,7 @@ The scales live on the device (ScaleBook): every tensor role of every layer owns
 the last time it was produced, and records the new amax -- no host round trip.  The first time a
 slot is used it is bootstrapped exactly (an amax pass, then the split).
 """
+import ctypes
 import heapq
 import os
 
@@ -47,7 +48,97 @@ PO_STATS = [0, 0, 0]   # outputs produced as parts only / shortcuts read from pa
 # weight gradients: split-K partial sums through a workspace + ordered reduce (bit-reproducible) instead of
 # fp32 atomics; "0" restores the atomics for A/B runs
 DETERMINISTIC_WGRAD = os.environ.get("SLN_DETERMINISTIC_WGRAD", "1") != "0"
+# weight gradients on a second stream, next to the data gradients of the same and the following layers: both are
+# whole-CU kernels, so the gain is the other kernel's tail rounds and epilogue bursts filled.  A C4 block's backward
+# alone: 21.2 -> 19.9 ms (tools/two_stream_probe.py); the train step: +0.5 % (86.5 -> 86.9 img/s, same box), with
+# every kernel's own duration stretched by the sharing (dominant kernel 0.43 -> 0.37 of its roofline over its own
+# launches) -- OFF by default, "1" enables it.  See _side_wgrad_ok for when it applies.
+WGRAD_STREAM = os.environ.get("SLN_WGRAD_STREAM", "0") == "1"
+_SIDE = {}            # device index -> [stream, weights with a side-stream gradient in flight (ids), join queued]
+SIDE_STATS = [0, 0]   # weight gradients launched on the side stream / on the main stream
 _cache = _NoCache()   # kept for tools that call _cache.clear(); caches live on the tensors
+
+
+def _side_state(device):
+    st = _SIDE.get(device.index)
+    if st is None:
+        st = _SIDE[device.index] = [torch.cuda.Stream(device=device), set(), False]
+    return st
+
+
+def join_side_streams(end_of_pass=False):
+    """The current stream waits for every weight gradient in flight on a side stream.  Runs by itself at the end
+    of each backward pass (engine callback); anything that reads a weight gradient INSIDE the pass (bucket
+    all-reduce hooks) calls it first -- the weights stay marked until the pass ends, so that a second gradient of
+    the same weight (which autograd ADDS on the main stream) is still produced on the main stream."""
+    for st in _SIDE.values():
+        if st[1]:
+            torch.cuda.current_stream(st[0].device).wait_stream(st[0])
+        if end_of_pass:
+            st[1].clear()
+            st[2] = False
+
+
+def _end_of_backward():
+    flush_wgrad_reduces(True)
+    join_side_streams(True)
+
+
+def _adopted_untouched(own, weight):
+    """True if nothing touches this weight gradient on the main stream before the pass ends: AccumulateGrad
+    ADOPTS it (no kernel) -- leaf parameter without a gradient yet, contiguous, the reduce pass writes the
+    parameter's own layout, no graph of the backward is recorded -- and it is the weight's first gradient of this
+    pass (a second one is ADDED by autograd on the main stream, at once)."""
+    if not DETERMINISTIC_WGRAD or torch.is_grad_enabled():
+        return False
+    if not (own.is_leaf and own.grad is None and own.is_contiguous() and own.data_ptr() == weight.data_ptr()):
+        return False
+    return id(own) not in _side_state(weight.device)[1] and id(own) not in _reduce_state(weight.device)[1]
+
+
+def _side_wgrad_ok(own, weight):
+    return WGRAD_STREAM and _adopted_untouched(own, weight)
+
+
+# Deferred reduce of the two-phase weight gradients: a layer writes its split-K partial sums only; the reduce passes
+# of up to 16 layers run as ONE launch (sln_wgrad_reduce_batch_f32: the same summation tree, the same bits) -- when
+# 16 are waiting, when something is about to read a gradient inside the pass (flush_wgrad_reduces) and when the
+# pass ends.  ~137 reduce launches per train step become ~9.  "0": A/B switch.
+BATCH_WGRAD_REDUCE = os.environ.get("SLN_BATCH_WGRAD_REDUCE", "1") != "0"
+_REDUCE = {}          # device index -> [pending (workspace, gradient storage, pointer, n, ksplit, taps, Cin), weight ids, callback queued]
+REDUCE_STATS = [0, 0]   # batched launches, layers reduced in them
+
+
+class _ReduceDesc(ctypes.Structure):
+    _fields_ = [("partial", ctypes.c_void_p), ("gw", ctypes.c_void_p), ("n", ctypes.c_int64),
+                ("ksplit", ctypes.c_int32), ("taps", ctypes.c_int32), ("Cin", ctypes.c_int32),
+                ("reserved", ctypes.c_int32)]     # == sln_wgrad_reduce_desc_t
+
+
+def _reduce_state(device):
+    st = _REDUCE.get(device.index)
+    if st is None:
+        st = _REDUCE[device.index] = [[], set(), False]
+    return st
+
+
+def flush_wgrad_reduces(end_of_pass=False):
+    """Launch the reduce of every weight gradient that is waiting (current stream).  The weights stay marked until
+    the pass ends: a second gradient of the same weight is reduced at once (autograd adds it to the first)."""
+    for idx, st in _REDUCE.items():
+        if st[0]:
+            pend, st[0] = st[0], []
+            arr = (_ReduceDesc * len(pend))()
+            for i, (ws, _keep, gw_ptr, n, ksplit, taps, cin) in enumerate(pend):
+                arr[i] = _ReduceDesc(ws.data_ptr(), gw_ptr, n, ksplit, taps, cin, 0)
+            with torch.cuda.device(idx):
+                _lib.check(_lib.lib().sln_wgrad_reduce_batch_f32(arr, len(pend), ops._stream()),
+                           "sln_wgrad_reduce_batch_f32")
+            REDUCE_STATS[0] += 1
+            REDUCE_STATS[1] += len(pend)
+        if end_of_pass:
+            st[1].clear()
+            st[2] = False
 
 
 # ------------------------------------------------------------------ per-tensor scales (PARTS = 2)
@@ -159,6 +250,8 @@ def update_scales(sync=True):
     lockstep); inference / validation forwards pass False and stay rank-local.
     A backward pass of a graph built BEFORE this call would de-scale its weight gradient with the new
     scale of operands that were quantised with the old one: _ConvFn.backward raises in that case."""
+    flush_wgrad_reduces(True)    # (a backward pass that raised never ran its end-of-pass callback)
+    join_side_streams(True)
     if hold_scales.depth:
         return
     for b in _books.values():
@@ -988,6 +1081,33 @@ class _ConvFn(torch.autograd.Function):
             if m is None:
                 return {}
             return dict(mask_parts=m) if m.dtype == torch.bfloat16 else dict(mask=_nhwc(m))
+        side = gw_t = ws = None
+        ws_bytes = 0
+        if need_w:
+            # the gradient tensor is allocated BEFORE the event below: whatever used its memory before has been
+            # queued on this stream by now and is complete when the side stream passes the event
+            if DETERMINISTIC_WGRAD and GRAD_SINK is not None and own.is_leaf and \
+                    own.data_ptr() == weight.data_ptr() and tuple(own.shape) == (Co, Ci, KH, KW):
+                # the parameter's slot of its all-reduce bucket: autograd adopts the view as .grad (no pack /
+                # unpack copies around the collective)
+                gw_t = GRAD_SINK(own, (Co, Ci, KH, KW))
+            if gw_t is None:
+                gw_t = torch.empty((Co, Ci, KH, KW) if DETERMINISTIC_WGRAD else (Co, KH, KW, Ci), dtype=torch.float32,
+                                   device=weight.device)
+            untouched = _adopted_untouched(own, weight)
+            defer = BATCH_WGRAD_REDUCE and untouched and N > 0
+            if WGRAD_STREAM and untouched:
+                side = _side_state(weight.device)
+                side[1].add(id(own))
+                ready = torch.cuda.Event()
+                ready.record()                      # gz (and x) are complete here; the data gradient starts below
+                defer = False                       # (the side stream reduces its own gradients at once)
+            rst = _reduce_state(weight.device)
+            if defer:
+                rst[1].add(id(own))
+            if (side is not None or defer) and not (rst[2] or _side_state(weight.device)[2]):
+                rst[2] = True
+                torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward)
         if ctx.link_tail is not None and g_res is not None:
             ctx.link_tail["idgrad"] = g_res     # consumed by the head's data gradient below
             g_res = None
@@ -1086,34 +1206,47 @@ class _ConvFn(torch.autograd.Function):
             else:
                 raise NotImplementedError("data gradient of a strided %dx%d conv" % (KH, KW))
         if need_w:
-            ws, ws_bytes = None, 0
-            if DETERMINISTIC_WGRAD:     # two-phase split-K through a lent workspace: no atomics
-                ws_bytes = _lib.lib().sln_conv_wgrad_workspace_bytes(N * OH * OW, Co, Ci, KH * KW, parts)
-                ws = ops._workspace(max(ws_bytes, 16), weight.device)
             # with the workspace the reduce pass writes the parameter's own [Co,Ci,KH,KW] order (no layout
             # copy in AccumulateGrad); the atomic path produces [Co,KH,KW,Ci]
-            own_layout = ws is not None
-            gw_t = None
-            if own_layout and GRAD_SINK is not None and own.is_leaf and own.data_ptr() == weight.data_ptr() and \
-                    tuple(own.shape) == (Co, Ci, KH, KW):
-                # the parameter's slot of its all-reduce bucket: autograd adopts the view as .grad (no pack /
-                # unpack copies around the collective)
-                gw_t = GRAD_SINK(own, (Co, Ci, KH, KW))
-            if gw_t is None:
-                gw_t = torch.empty((Co, Ci, KH, KW) if own_layout else (Co, KH, KW, Ci), dtype=torch.float32,
-                                   device=weight.device)
-            e0 = _prof_begin()
-            _lib.check(_lib.lib().sln_conv2d_wgrad_f32(
-                ops._ptr(gz), Co, gz.shape[2], ops._ptr(xp), N, H, W, Ci, xp.shape[2], parts, KH, KW,
-                stride[0], stride[1], dil[0], dil[1], pt, pl, OH, OW, ops._ptr(gw_t), ops._ptr(gzq),
-                ops._ptr(xq), ops._ptr(ws), ws_bytes, 1 if own_layout else 0, ops._stream()),
-                "sln_conv2d_wgrad_f32")
-            wt_ = _lib.lib().sln_conv_wgrad_tile(N * OH * OW, Co, Ci, KH * KW, parts) if e0 is not None else 128
-            _prof_end(e0, 2.0 * N * OH * OW * Co * KH * KW * Ci,
-                      ("conv_wgrad256h_kernel" if (wt_ == 256 and parts == 2) else
-                       ("conv_wgrad256_kernel<%d>" if wt_ == 256 else "conv_wgrad_kernel<%d>") % parts),
-                      "wgrad N%d %dx%d C%d->%d k%d s%d d%d" % (N, H, W, Ci, Co, KH, stride[0], dil[0]),
-                      _nbytes(gz, xp), _nbytes(gw_t))
+            own_layout = DETERMINISTIC_WGRAD
+            main = torch.cuda.current_stream(weight.device)
+            if side is not None:
+                side[0].wait_event(ready)
+                for tns in (gz, xp):
+                    tns.record_stream(side[0])      # freed by this stream's allocator only after the side stream is done
+                SIDE_STATS[0] += 1
+            else:
+                if id(own) in _side_state(weight.device)[1]:
+                    main.wait_stream(_side_state(weight.device)[0])    # autograd adds this one to the first on this stream
+                if not defer and id(own) in rst[1]:
+                    flush_wgrad_reduces()                              # ... and the first must be complete by then
+                SIDE_STATS[1] += 1
+            with torch.cuda.stream(side[0] if side is not None else main):
+                if DETERMINISTIC_WGRAD:     # two-phase split-K through a lent workspace: no atomics
+                    ws_bytes = _lib.lib().sln_conv_wgrad_workspace_bytes(N * OH * OW, Co, Ci, KH * KW, parts)
+                    # deferred reduce: the partial sums live until the batched launch -- memory of their own
+                    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=weight.device) if defer else \
+                        ops._workspace(max(ws_bytes, 16), weight.device)
+                e0 = _prof_begin()
+                _lib.check(_lib.lib().sln_conv2d_wgrad_f32(
+                    ops._ptr(gz), Co, gz.shape[2], ops._ptr(xp), N, H, W, Ci, xp.shape[2], parts, KH, KW,
+                    stride[0], stride[1], dil[0], dil[1], pt, pl, OH, OW, ops._ptr(gw_t), ops._ptr(gzq),
+                    ops._ptr(xq), ops._ptr(ws), ws_bytes, (1 if own_layout else 0) | (2 if defer else 0),
+                    ops._stream()), "sln_conv2d_wgrad_f32")
+                if defer:
+                    # (the gradient's STORAGE is kept alive, not the tensor: a second reference to the tensor would
+                    # make AccumulateGrad copy it -- before the reduce has run -- instead of adopting it)
+                    rst[0].append((ws, gw_t.untyped_storage(), gw_t.data_ptr(), Co * KH * KW * Ci,
+                                   _lib.lib().sln_conv_wgrad_ksplit(N * OH * OW, Co, Ci, KH * KW, parts),
+                                   KH * KW if (own_layout and KH * KW > 1) else 0, Ci))
+                    if len(rst[0]) >= 16:
+                        flush_wgrad_reduces()
+                wt_ = _lib.lib().sln_conv_wgrad_tile(N * OH * OW, Co, Ci, KH * KW, parts) if e0 is not None else 128
+                _prof_end(e0, 2.0 * N * OH * OW * Co * KH * KW * Ci,          # (both events on the launch stream)
+                          ("conv_wgrad256h_kernel" if (wt_ == 256 and parts == 2) else
+                           ("conv_wgrad256_kernel<%d>" if wt_ == 256 else "conv_wgrad_kernel<%d>") % parts),
+                          "wgrad N%d %dx%d C%d->%d k%d s%d d%d" % (N, H, W, Ci, Co, KH, stride[0], dil[0]),
+                          _nbytes(gz, xp), _nbytes(gw_t))
             gw = gw_t if own_layout else gw_t.permute(0, 3, 1, 2)  # logical [Co,Ci,KH,KW]
         return gx, gw, g_bias, None, None, g_res, None, None, None, None, None, None, None, None, None, None
 

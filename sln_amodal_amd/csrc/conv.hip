@@ -2045,7 +2045,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     const int lane = t & 63, wave = t >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int ntile = p.gm * p.gn_per_tap * p.KH * p.KW;
-    int bid = blockIdx.x;
+    // all (Cout tile, Cin tile, tap) blocks of one pixel range on the SAME XCD, next to each other in dispatch
+    // order: the range's gz and x rows come from HBM once and from that L2 for the other ntile - 1 readers
+    int bid = (p.xcd_wgrad & 2) ? xcd_remap(blockIdx.x, ntile * p.ksplit) : (int)blockIdx.x;
     const int split = bid / ntile;
     bid -= split * ntile;
     const int mt = bid % p.gm;
@@ -2213,7 +2215,7 @@ __global__ __launch_bounds__(512) void conv_wgrad256_kernel(const WgradParams p)
     const int ntile = p.gm * p.gn_per_tap * p.KH * p.KW;
     // the tap tiles of one pixel range are consecutive block ids: keep them on one XCD (one L2), so
     // that the range's gz rows are fetched from HBM once and not once per tap (xcd_wgrad)
-    int bid = p.xcd_wgrad ? xcd_remap(blockIdx.x, ntile * p.ksplit) : (int)blockIdx.x;
+    int bid = (p.xcd_wgrad & 1) ? xcd_remap(blockIdx.x, ntile * p.ksplit) : (int)blockIdx.x;
     const int split = bid / ntile;
     bid -= split * ntile;
     const int mt = bid % p.gm;
@@ -2371,7 +2373,7 @@ __global__ __launch_bounds__(512) void conv_wgrad256h_kernel(const WgradParams p
     const int lane = t & 63, wave = t >> 6;
     const int wr = wave >> 2, wc = wave & 3;
     const int ntile = p.gm * p.gn_per_tap * p.KH * p.KW;
-    int bid = p.xcd_wgrad ? xcd_remap(blockIdx.x, ntile * p.ksplit) : (int)blockIdx.x;
+    int bid = (p.xcd_wgrad & 1) ? xcd_remap(blockIdx.x, ntile * p.ksplit) : (int)blockIdx.x;
     const int split = bid / ntile;
     bid -= split * ntile;
     const int mt = bid % p.gm;
@@ -2594,13 +2596,13 @@ __global__ __launch_bounds__(512) void conv_wgrad256h_kernel(const WgradParams p
 // taps > 0: gw is written in the parameter's own [Cout][Cin][KH][KW] order (element (co, tap, ci) of the
 // slabs' [Cout][taps][Cin] order goes to (co*Cin + ci)*taps + tap): autograd then accumulates it as it is,
 // without the layout copy a permuted view costs per weight and step.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ partial, int ksplit,
-                                                           long n, float *__restrict__ gw, int taps, int Cin) {
+__device__ __forceinline__ void wgrad_reduce_block(const float *__restrict__ partial, int ksplit, long n,
+                                                   float *__restrict__ gw, int taps, int Cin, long block) {
     // 32 element quads x 8 range lanes per block: lane kl adds the ranges kl, kl+8, ... in order, the
     // eight sums are then added in lane order -- a fixed summation tree, whatever the launch timing
     __shared__ float4 s_part[8][32];
     const int q = threadIdx.x & 31, kl = threadIdx.x >> 5;
-    const long i4 = ((long)blockIdx.x * 32 + q) * 4;
+    const long i4 = (block * 32 + q) * 4;
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
     if (i4 < n) {
         if (i4 + 3 < n && (n & 3) == 0) {
@@ -2652,6 +2654,26 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
             for (int e = 0; e < 4 && i4 + e < n; ++e) gw[i4 + e] = t4[e];
         }
     }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ partial, int ksplit,
+                                                           long n, float *__restrict__ gw, int taps, int Cin) {
+    wgrad_reduce_block(partial, ksplit, n, gw, taps, Cin, blockIdx.x);
+}
+
+// The reduce passes of up to SLN_WGRAD_REDUCE_BATCH layers in one launch (sln_wgrad_reduce_batch_f32): a train
+// step has ~137 weight gradients, each followed by a 13-us reduce launch; deferred and batched they are ~9.
+struct WgradReduceBatch {
+    sln_wgrad_reduce_desc_t d[SLN_WGRAD_REDUCE_BATCH];
+    long first[SLN_WGRAD_REDUCE_BATCH + 1];      // first block of entry i; first[n] = grid size
+    int n;
+};
+
+__global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const WgradReduceBatch b) {
+    int e = 0;
+    while (e + 1 < b.n && (long)blockIdx.x >= b.first[e + 1]) ++e;      // (block-uniform)
+    const sln_wgrad_reduce_desc_t &d = b.d[e];
+    wgrad_reduce_block(d.partial, d.ksplit, d.n, d.gw, d.taps, d.Cin, (long)blockIdx.x - b.first[e]);
 }
 
 static inline int sln_knob(const char *name, int dflt);
@@ -2891,7 +2913,7 @@ extern "C" int sln_conv_fwd_tile(int64_t M, int Cout, int64_t K, int parts) {
     // at least 176 of the last 256 columns in use (ASPP's Cout = 182: +6...11 % per launch over
     // the 128x128 kernel, which wastes the same share of its second 128-column tile)
     const bool cols = Cout >= 176 && (Cout % T2 == 0 || Cout % T2 >= 160);
-    return (cols && fill >= 0.85 && K >= 256) ? T2 : BM;   // K >= 256: 16 stages (1x1 256 -> 1024: +3 %)
+    return (cols && fill >= 0.85 && K >= sln_knob("SLN_CONV_TILE256_MINK", 256)) ? T2 : BM;   // K >= 256: 16 stages (1x1 256 -> 1024: +3 %)
 }
 
 extern "C" int sln_conv2d_fwd_ms_f32(const uint16_t *x_parts, int nseg, const int32_t *seg_nhw, int Cin,
@@ -3052,8 +3074,11 @@ extern "C" int sln_conv2d_wgrad_f32(const uint16_t *gz_parts, int Cout, int Cout
                                     const float *gz_scale, const float *x_scale, void *workspace,
                                     size_t workspace_bytes, int gw_layout, sln_stream_t stream) {
     sln_enter();
+    const bool defer = (gw_layout & SLN_WGRAD_DEFER_REDUCE) != 0;     // partial sums only: the caller batches the reduce
+    gw_layout &= ~SLN_WGRAD_DEFER_REDUCE;
     if (gw_layout != 0 && gw_layout != 1) return SLN_ERR_INVALID_ARG;
-    if (!gz_parts || !x_parts || !gw || N < 0 || H < 1 || W < 1 || Cin < 1 || Cout < 1 || KH < 1 || KW < 1 ||
+    if (defer && (!workspace || N == 0)) return SLN_ERR_INVALID_ARG;
+    if (!gz_parts || !x_parts || (!gw && !defer) || N < 0 || H < 1 || W < 1 || Cin < 1 || Cout < 1 || KH < 1 || KW < 1 ||
         OH < 1 || OW < 1 || Cin_pad < Cin || Cout_pad < Cout || (Cin_pad & 7) || (Cout_pad & 7))
         return SLN_ERR_INVALID_ARG;
     if (parts != 2 && parts != 3) return SLN_ERR_INVALID_ARG;
@@ -3068,8 +3093,8 @@ extern "C" int sln_conv2d_wgrad_f32(const uint16_t *gz_parts, int Cout, int Cout
     // workspace even for a single pixel range (1x1 kernels: the two orders coincide)
     const bool transpose = gw_layout == 1 && KH * KW > 1;
     if (transpose && !workspace) return SLN_ERR_WORKSPACE;
-    const size_t need = (w.ksplit > 1 || transpose) ? sizeof(float) * (size_t)w.ksplit * gw_elems : 0;
-    const bool two_phase = workspace != nullptr && (w.ksplit > 1 || transpose);
+    const size_t need = (w.ksplit > 1 || transpose || defer) ? sizeof(float) * (size_t)w.ksplit * gw_elems : 0;
+    const bool two_phase = workspace != nullptr && (w.ksplit > 1 || transpose || defer);
     if (two_phase && workspace_bytes < need) return SLN_ERR_WORKSPACE;
     const bool direct = w.ksplit == 1 && workspace != nullptr && !transpose;   // a single pixel range: plain stores into gw
     if (!two_phase && !direct &&
@@ -3086,7 +3111,7 @@ extern "C" int sln_conv2d_wgrad_f32(const uint16_t *gz_parts, int Cout, int Cout
     p.gz_part_stride = M * Cout_pad;
     p.x_part_stride = (long)N * H * W * Cin_pad;
     p.gm = w.gm; p.gn_per_tap = w.gn; p.ksplit = w.ksplit; p.pix_per_split = w.pps;
-    p.xcd_wgrad = sln_knob("SLN_WGRAD_XCD", 1);
+    p.xcd_wgrad = sln_knob("SLN_WGRAD_XCD", 3);      // bit 0: the 256^2 kernels, bit 1: the 128^2 kernel
     const long nblk = (long)w.gm * w.gn * KH * KW * w.ksplit;
     if (nblk > 2147483647L) return SLN_ERR_UNSUPPORTED;
     if (w.tile == T2) {
@@ -3115,8 +3140,33 @@ extern "C" int sln_conv2d_wgrad_f32(const uint16_t *gz_parts, int Cout, int Cout
         }
 #undef SLN_WG
     }
-    if (two_phase)
+    if (two_phase && !defer)
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((gw_elems + 127) / 128)), dim3(256), 0, st,
                            (const float *)workspace, w.ksplit, (long)gw_elems, gw, transpose ? KH * KW : 0, Cin);
+    return sln_launch_status();
+}
+
+extern "C" int sln_conv_wgrad_ksplit(int64_t M, int Cout, int Cin, int taps, int parts) {
+    if (M < 1 || Cout < 1 || Cin < 1 || taps < 1) return 0;
+    return wgrad_plan(M, Cout, Cin, taps, parts).ksplit;
+}
+
+extern "C" int sln_wgrad_reduce_batch_f32(const sln_wgrad_reduce_desc_t *descs, int n, sln_stream_t stream) {
+    sln_enter();
+    if (n < 0 || n > SLN_WGRAD_REDUCE_BATCH || (n > 0 && !descs)) return SLN_ERR_INVALID_ARG;
+    if (n == 0) return SLN_OK;
+    WgradReduceBatch b;
+    b.n = n;
+    long blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        const sln_wgrad_reduce_desc_t &d = descs[i];
+        if (!d.partial || !d.gw || d.n < 1 || d.ksplit < 1 || d.taps < 0 || d.Cin < 1) return SLN_ERR_INVALID_ARG;
+        b.d[i] = d;
+        b.first[i] = blocks;
+        blocks += (d.n + 127) / 128;
+    }
+    b.first[n] = blocks;
+    if (blocks > 2147483647L) return SLN_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, b);
     return sln_launch_status();
 }

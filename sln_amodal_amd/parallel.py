@@ -156,6 +156,9 @@ class GradientAllReducer(object):
             self._next += 1
 
     def _launch(self, bi):
+        from . import conv_hip
+        conv_hip.flush_wgrad_reduces()   # weight gradients whose (batched) reduce pass has not been launched yet
+        conv_hip.join_side_streams()     # ... or that are in flight on the side stream (conv_hip.WGRAD_STREAM)
         flat = self._storage(bi)
         src, dst, missing = [], [], []
         for p in self.buckets[bi]:

@@ -661,6 +661,64 @@ def test_weight_gradient_is_bit_reproducible(parts, shape, monkeypatch):
     assert torch.allclose(atomic, first, rtol=1e-4, atol=1e-5 * float(first.abs().max()))
 
 
+def test_deferred_reduce_and_side_stream_weight_gradients_equal_the_plain_ones(monkeypatch):
+    """conv_hip.BATCH_WGRAD_REDUCE (the reduce passes of up to 16 layers in one launch) and conv_hip.WGRAD_STREAM: weight gradients launched on a second stream next to the data gradients.  A stack of
+    three bottlenecks plus ONE convolution applied twice (the RPN's shared weights: its second gradient is added by
+    autograd on the main stream, so it must not run on the side stream).  Ten passes under allocator churn: every
+    weight gradient equals, bit for bit, the one of a pass with the switch off, and the main stream is joined when
+    backward() returns (the gradients are read right away)."""
+    from sln_amodal_amd import conv_hip, nn_ops
+    from sln_amodal_amd.modal.modals import Bottleneck
+    from tests._util import key_init_
+    monkeypatch.setattr(conv_hip, "PARTS", 2)
+    down = nn.Sequential(nn.Conv2d(64, 128, kernel_size=1, stride=1), nn.BatchNorm2d(128, eps=0.001))
+    net = nn.Sequential(Bottleneck(64, 32, 1, down), Bottleneck(128, 32), Bottleneck(128, 32)).cuda()
+    shared = nn.Conv2d(128, 128, kernel_size=3, padding=1).cuda()
+    key_init_(net)
+    for m in net.modules():
+        if isinstance(m, nn.BatchNorm2d):
+            m.eval()
+            m.weight.requires_grad = m.bias.requires_grad = False
+    g = torch.Generator().manual_seed(5)
+    x0 = torch.randn(4, 64, 40, 40, generator=g).cuda().contiguous(memory_format=torch.channels_last)
+    up = torch.randn(4, 128, 40, 40, generator=g).cuda().contiguous(memory_format=torch.channels_last)
+    every = [p for p in list(net.parameters()) + list(shared.parameters()) if p.requires_grad]
+    params = [p for p in every if p.dim() == 4]       # (bias gradients are atomic column sums: not bit-stable)
+
+    def run():
+        conv_hip.update_scales()
+        for p in every:
+            p.grad = None
+        y = net(x0.clone().requires_grad_(True))
+        z = nn_ops.conv_bn_act(y, shared, None, same=True) + nn_ops.conv_bn_act(y * 0.5, shared, None, same=True)   # one weight twice
+        junk = [torch.empty(1 << 20, device="cuda").normal_() for _ in range(4)]     # allocator churn
+        (z * up).sum().backward()
+        del junk
+        return [p.grad.clone() for p in params]          # read on the main stream, no synchronize in between
+
+    monkeypatch.setattr(conv_hip, "WGRAD_STREAM", False)
+    monkeypatch.setattr(conv_hip, "BATCH_WGRAD_REDUCE", False)
+    run()
+    want = run()
+    # the reduce passes deferred and batched (the default): same bits, far fewer launches
+    monkeypatch.setattr(conv_hip, "BATCH_WGRAD_REDUCE", True)
+    conv_hip.REDUCE_STATS[:] = [0, 0]
+    for _ in range(3):
+        for a, b in zip(run(), want):
+            assert torch.equal(a, b)
+    # 10 + the shared weight's first; two launches a pass: the shared weight's second gradient flushes what waits
+    assert conv_hip.REDUCE_STATS[1] == 3 * 11 and conv_hip.REDUCE_STATS[0] == 3 * 2
+    assert not any(st[0] or st[1] for st in conv_hip._REDUCE.values())
+    monkeypatch.setattr(conv_hip, "WGRAD_STREAM", True)
+    conv_hip.SIDE_STATS[:] = [0, 0]
+    for _ in range(10):
+        got = run()
+        for a, b in zip(got, want):
+            assert torch.equal(a, b)
+    assert conv_hip.SIDE_STATS[0] >= 10 * 10 and conv_hip.SIDE_STATS[1] >= 10     # the shared weight's 2nd: main stream
+    assert not any(st[1] for st in conv_hip._SIDE.values())                         # nothing left marked in flight
+
+
 # ------------------------------------------------------------------ 3-channel stems (im2col + 1x1)
 STEMS = [
     # N, H, W, pads: backbone C1 (modals.py:311, padding 3) and the GLM stem at its three scales

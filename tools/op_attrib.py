@@ -33,14 +33,37 @@ def main(batch=16, dim=1024):
     for _ in range(2):
         model.train_step(b, opt, None)
     torch.cuda.synchronize()
-    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=False, record_shapes=True) as prof:
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
         model.train_step(b, opt, None)
         torch.cuda.synchronize()
-    rows = sorted(prof.key_averages(group_by_input_shape=True), key=lambda e: -e.self_device_time_total)
-    want = ("aten::add", "aten::copy_", "aten::add_", "aten::mul", "aten::fill_", "aten::sum", "aten::cat",
-            "aten::clone", "aten::contiguous")
-    for e in [r for r in rows if r.key in want and r.self_device_time_total >= 100][:40]:
-        print("%9.2f ms  n=%5d  %-14s %s" % (e.self_device_time_total / 1e3, e.count, e.key, str(e.input_shapes)[:150]))
+    # every op that launched a kernel that is not one of ours, by (op, first frame inside the package): time, launches
+    import collections
+    agg = collections.defaultdict(lambda: [0.0, 0, set()])
+    for ev in prof.events():
+        if ev.self_device_time_total <= 0 or not ev.key.startswith(("aten::", "Memset", "Memcpy")):
+            continue
+        site = "?"
+        for fr in (ev.stack or []):
+            if "sln_amodal_amd" in fr and "torch/" not in fr:
+                site = fr.split("sln_amodal_amd/")[-1]
+                break
+        k = (ev.key, site)
+        agg[k][0] += ev.self_device_time_total
+        agg[k][1] += 1
+        agg[k][2].add(str(ev.input_shapes)[:80])
+    big = collections.defaultdict(lambda: [0.0, 0])
+    for ev in prof.events():
+        if ev.self_device_time_total > 0 and ev.key in ("aten::add_", "aten::copy_", "aten::add", "aten::sum", "aten::fill_",
+                                                        "aten::mul", "aten::div", "aten::cat", "aten::_softmax"):
+            k = (ev.key, str(ev.input_shapes)[:110])
+            big[k][0] += ev.self_device_time_total
+            big[k][1] += 1
+    for (key, shp), (t, n) in sorted(big.items(), key=lambda kv: -kv[1][0])[:45]:
+        print("%8.3f ms n=%4d %-14s %s" % (t / 1e3, n, key, shp))
+    tot = sum(v[0] for v in agg.values())
+    print("aten / runtime ops with device time: %.2f ms in %d calls" % (tot / 1e3, sum(v[1] for v in agg.values())))
+    for (key, site), (t, n, shp) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:70]:
+        print("%8.3f ms n=%4d %-22s %-60s %s" % (t / 1e3, n, key, site[:60], sorted(shp)[0] if shp else ""))
 
 
 if __name__ == "__main__":
