@@ -202,6 +202,13 @@ int sln_maxpool_bwd_f32(const float *g, const uint8_t *argmax, int N, int H, int
  * sln_upsample2x_add_f32  lateral, out [N,2h,2w,C]; top [N,h,w,C]
  * sln_sumpool2x2_f32      g [N,2h,2w,C] -> gtop [N,h,w,C] = (g00 + g01) + (g10 + g11)
  * ------------------------------------------------------------------------- */
+/* Tail of the global layer module (reference model.py:537-541, modal/msc_deeplab.py:42-48), one pass: the logits
+ * of the coarser scales resized bilinearly (align_corners = False) to the scale-1 grid, element-wise maximum over
+ * the scales, softmax over the C classes, argmax.  All maps NHWC fp32 with the given pixel strides (floats).
+ * probs [B,H,W,C+1]: the C probabilities and argmax / 255; label [B,H,W] int64: the argmax. */
+int sln_msc_softmax_tail_f32(const float *logits, int64_t logits_pixel_stride, const float *const *pyramid,
+                             const int32_t *pyramid_hw, const int64_t *pyramid_pixel_stride, int n_pyramid,
+                             int B, int C, int H, int W, float *probs, int64_t *label, sln_stream_t stream);
 int sln_upsample2x_add_f32(const float *lateral, const float *top, int N, int h, int w, int C, float *out,
                            sln_stream_t stream);
 int sln_sumpool2x2_f32(const float *g, int N, int h, int w, int C, float *gtop, sln_stream_t stream);

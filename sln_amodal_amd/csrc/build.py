@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, "libsln_amodal_hip.so")
 
 EXACT = ["abi.hip", "nms.hip", "crop_and_resize.hip", "label_decode.hip", "proposal.hip",
-         "pyramid_crop.hip", "topk.hip", "tail.hip", "optim.hip", "fpn_merge.hip", "maxpool.hip"]
+         "pyramid_crop.hip", "topk.hip", "tail.hip", "optim.hip", "fpn_merge.hip", "maxpool.hip", "glm_tail.hip"]
 FAST = [f for f in sorted(os.listdir(HERE)) if f.endswith(".hip") and f not in EXACT]
 
 COMMON = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall",

@@ -36,6 +36,14 @@ class MSC(nn.Module):
         return (x.is_cuda and not torch.is_grad_enabled() and nn_ops.BACKEND in ("auto", "hip") and
                 nn_ops._hip_conv() is not None and PACK_SCALES)
 
+    def softmax_tail(self, x):
+        """Inference tail of the reference's glue (model.py:537-541) fused with the scale maximum below:
+        -> ([B, C+1, H, W] = softmax probabilities of the maximum logits | argmax / 255, argmax [B, H, W]) -- one
+        HIP pass over the three scales' logits instead of resizes, maxima, softmax, argmax and a concatenation."""
+        from .. import ops
+        logits, pyramid = self._forward_packed(x)
+        return ops.msc_softmax_tail(logits, pyramid)
+
     def forward(self, x):
         if self._packable(x):
             logits, pyramid = self._forward_packed(x)

@@ -30,6 +30,9 @@ from .modal.Functions import (build_rpn_targets, compose_image_meta, detection_l
 from .modal.deeplabv2 import DeepLabV2_ResNet101_MSC
 from .modal.modals import (FPN, RPN, Classifier, Mask, ResNet, pyramid_roi_align_image)
 
+# the GLM's resize / max / softmax / argmax / concat tail as one HIP pass (ops.msc_softmax_tail); "0": A/B switch
+FUSED_GLM_TAIL = os.environ.get("SLN_FUSED_GLM_TAIL", "1") != "0"
+
 LAYER_REGEX = {
     "new": r"(fpn.C1.*)|(classifier.*)|(mask.*)|(layer_decoder.*)|(rpn.*)",
     "rpn": r"(fpn.C3.*)|(fpn.C4.*)|(fpn.C5.*)|(fpn.P5\_.*)|(fpn.P4\_.*)|(fpn.P3\_.*)|(fpn.P2\_.*)|(rpn.*)",
@@ -219,10 +222,15 @@ class MaskRCNN(nn.Module):
         with torch.no_grad():
             s = self.config.GLM_SIZE
             x = F.interpolate(molded_images, size=(s, s), mode="bilinear", align_corners=False)
-            logits = self.GLM_modual(x.contiguous(memory_format=torch.channels_last))
-            probs = F.softmax(logits, dim=1)
-            lab_small = torch.argmax(probs, dim=1)
-            probs = torch.cat((probs, lab_small.unsqueeze(1).float() / 255), dim=1)
+            x = x.contiguous(memory_format=torch.channels_last)
+            glm = self.GLM_modual
+            if FUSED_GLM_TAIL and hasattr(glm, "softmax_tail") and not glm.training and glm._packable(x):
+                probs, lab_small = glm.softmax_tail(x)
+            else:
+                logits = glm(x)
+                probs = F.softmax(logits, dim=1)
+                lab_small = torch.argmax(probs, dim=1)
+                probs = torch.cat((probs, lab_small.unsqueeze(1).float() / 255), dim=1)
             gloable_lab = F.interpolate(lab_small.unsqueeze(1).float(), size=(H, W), mode="bilinear",
                                         align_corners=False)
         return probs.contiguous(memory_format=torch.channels_last), gloable_lab

@@ -161,6 +161,39 @@ def mask_targets(label, L, rois, roi_img, roi_obj, mh, mw):
     return masks
 
 
+# --------------------------------------------------------------------- global layer module tail
+def _nhwc_stride(t):
+    """Pixel stride (floats) of a logical [B,C,H,W] tensor that is NHWC in memory with rows of equal stride, else None."""
+    B, C, H, W = t.shape
+    sb, sc, sh, sw = t.stride()
+    if sc == 1 and sw >= C and sh == W * sw and (B == 1 or sb == H * sh):
+        return sw
+    return None
+
+
+def msc_softmax_tail(logits, pyramid):
+    """logits [B,C,H,W] (scale 1) and the coarser scales' logits -> probs [B,C+1,H,W] (channels-last: the C softmax
+    probabilities of the element-wise maximum over the resized scales, then argmax/255) and label [B,H,W] int64.
+    Reference model.py:537-541 + modal/msc_deeplab.py:42-48 in one pass (csrc/glm_tail.hip)."""
+    import ctypes as C
+    ts = []
+    for t in [logits] + list(pyramid):
+        _need(t, torch.float32, "logits")
+        if _nhwc_stride(t) is None:
+            t = t.contiguous(memory_format=torch.channels_last)
+        ts.append(t)
+    B, Cc, H, W = ts[0].shape
+    n = len(ts) - 1
+    probs = torch.empty((B, H, W, Cc + 1), dtype=torch.float32, device=logits.device)
+    label = torch.empty((B, H, W), dtype=torch.int64, device=logits.device)
+    ptrs = (C.c_void_p * max(n, 1))(*[t.data_ptr() for t in ts[1:]])
+    hw = (C.c_int32 * max(2 * n, 1))(*[d for t in ts[1:] for d in (t.shape[2], t.shape[3])])
+    ps = (C.c_int64 * max(n, 1))(*[_nhwc_stride(t) for t in ts[1:]])
+    _lib.check(_lib.lib().sln_msc_softmax_tail_f32(_ptr(ts[0]), _nhwc_stride(ts[0]), ptrs, hw, ps, n, B, Cc, H, W,
+                                                   _ptr(probs), _ptr(label), _stream()), "sln_msc_softmax_tail_f32")
+    return probs.permute(0, 3, 1, 2), label
+
+
 # --------------------------------------------------------------------- proposals
 def topk_order(scores, k):
     """scores [B,A] f32 (any strides) -> order [B,k] int64: the k best per row, score descending, ties

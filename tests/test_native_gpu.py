@@ -532,3 +532,38 @@ def test_pyramid_gather_backward_is_bit_reproducible_and_equals_the_scatter():
         for a, b, c in zip(g1, g2, s1):
             assert torch.equal(a, b)
             assert (a - c).abs().max().item() <= 1e-5 * max(c.abs().max().item(), 1e-6)
+
+
+@pytest.mark.parametrize("shape", [(2, 182, 65, 65, ((33, 33), (49, 49))), (3, 21, 17, 23, ((9, 12), (13, 17))),
+                                   (1, 200, 8, 8, ())])
+def test_msc_softmax_tail_equals_the_unfused_ops(shape):
+    """ops.msc_softmax_tail (csrc/glm_tail.hip) against the reference's sequence (msc_deeplab.py:42-48,
+    model.py:537-541): bilinear resizes (align_corners False) -> maxima -> softmax -> argmax -> cat, run with
+    torch ops on the same device.  Probabilities within 5e-6 absolute (a last-bit difference in a resized logit of
+    magnitude ~10 moves exp() by 1e-6 relative; the path's bound is 1e-4); the label exact wherever the best two
+    probabilities are not within rounding of each other; inputs are strided NHWC views like MultiScale's."""
+    import torch.nn.functional as F
+    from sln_amodal_amd import ops
+    B, C, H, W, pyr = shape
+    g = torch.Generator(device="cuda").manual_seed(C + H)
+
+    def nhwc(b, c, h, w, pad):          # [b, c, h, w] view of an NHWC buffer whose pixel stride is c + pad
+        buf = torch.randn(b, h, w, c + pad, device="cuda", generator=g) * 3.0
+        return buf[..., :c].permute(0, 3, 1, 2)
+
+    logits = nhwc(B, C, H, W, 2)
+    pyramid = [nhwc(B, C, h, w, 0) for (h, w) in pyr]
+    want = logits
+    for l in pyramid:
+        want = torch.max(want, F.interpolate(l, size=(H, W), mode="bilinear", align_corners=False))
+    wp = F.softmax(want, dim=1)
+    wl = torch.argmax(wp, dim=1)
+    probs, label = ops.msc_softmax_tail(logits, pyramid)
+    assert probs.shape == (B, C + 1, H, W) and probs.is_contiguous(memory_format=torch.channels_last)
+    assert (probs[:, :C] - wp).abs().max().item() < 5e-6
+    top2 = wp.topk(2, dim=1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 1e-5
+    assert clear.float().mean().item() > 0.99
+    assert torch.equal(label[clear], wl[clear])
+    # (true division like the reference's CPU path; ATen's CUDA division by a scalar multiplies by 1/255)
+    assert torch.equal(probs[:, C].cpu(), label.cpu().float() / 255)
