@@ -909,7 +909,12 @@ class hold_scales(object):
 class _ConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, bn_scale, bn_shift, residual, relu, stride, dil, pads, link=None,
-                chain_in=None, chain_out=None, owner=None, pair=None, parts_only=False):
+                chain_in=None, chain_out=None, owner=None, pair=None, parts_only=False, inbox=None):
+        ctx.inbox = None
+        if inbox is not None and stride == (1, 1) and ctx.needs_input_grad[0] and chain_in is None:
+            ctx.inbox = inbox              # (the plain stride-1 data gradient below is the one that adds it)
+            inbox.clear()
+            inbox["armed"] = True
         parts = PARTS
         if PARTS_NOGRAD and not any(ctx.needs_input_grad):
             parts = PARTS_NOGRAD
@@ -1165,6 +1170,11 @@ class _ConvFn(torch.autograd.Function):
                 gx = _dummy_grad(weight.device).expand(N, Ci, H, W)   # never read: see chain_out above
                 CHAIN_STATS[0] += 1
             elif stride == (1, 1):
+                extra = ctx.inbox.take() if ctx.inbox is not None else None      # another reader's gradient w.r.t. x
+                if extra is not None and id_grad is not None:
+                    id_grad = id_grad + extra
+                elif extra is not None:
+                    id_grad = extra
                 gx = _fwd(gz, N, OH, OW, wt, Ci, KH, KW, (1, 1), dil, dil[0] * (KH - 1) - pt,
                           dil[1] * (KW - 1) - pl, H, W, None, None,
                           _nhwc(id_grad) if id_grad is not None else None, False, cin=Co, **qs)
@@ -1248,7 +1258,7 @@ class _ConvFn(torch.autograd.Function):
                           "wgrad N%d %dx%d C%d->%d k%d s%d d%d" % (N, H, W, Ci, Co, KH, stride[0], dil[0]),
                           _nbytes(gz, xp), _nbytes(gw_t))
             gw = gw_t if own_layout else gw_t.permute(0, 3, 1, 2)  # logical [Co,Ci,KH,KW]
-        return gx, gw, g_bias, None, None, g_res, None, None, None, None, None, None, None, None, None, None
+        return gx, gw, g_bias, None, None, g_res, None, None, None, None, None, None, None, None, None, None, None
 
 
 class _StemFn(torch.autograd.Function):
@@ -1373,8 +1383,47 @@ def _dummy_grad(device):
     return d
 
 
+class GradInbox(dict):
+    """Where another reader of a conv's input leaves ITS gradient w.r.t. that input during the backward pass, for
+    the conv's data gradient to add in its epilogue (one fused pass instead of autograd's accumulation add: the
+    FPN maps are read by the RPN's shared conv and by the RoIAlign crops; at P2 the add moves 3 GB).
+    Protocol: the conv's forward arms the box; the other reader's backward calls offer(g): True = taken (it then
+    returns no gradient for that input), False = the conv's backward has already run or will not run (not armed):
+    return the gradient to autograd as usual.  A gradient that was taken and never consumed (the conv's backward did
+    not run in this pass) is an error, raised when the pass ends."""
+    pending = []          # boxes holding a gradient, checked at the end of the pass
+    STATS = [0, 0]        # offered and taken / consumed
+
+    def offer(self, g):
+        if not self.get("armed") or self.get("closed") or "g" in self:
+            return False
+        self["g"] = g
+        GradInbox.STATS[0] += 1
+        if not GradInbox.pending:
+            torch.autograd.Variable._execution_engine.queue_callback(GradInbox._check)
+        GradInbox.pending.append(self)
+        return True
+
+    def take(self):
+        self["closed"] = True
+        g = self.pop("g", None)
+        if g is not None:
+            GradInbox.STATS[1] += 1
+        return g
+
+    @staticmethod
+    def _check():
+        left = [b for b in GradInbox.pending if "g" in b]
+        del GradInbox.pending[:]
+        for b in left:
+            b.pop("g", None)
+        if left:
+            raise RuntimeError("GradInbox: %d deposited gradient(s) were never consumed -- the convolution that "
+                               "should have added them took no part in this backward pass" % len(left))
+
+
 def conv_bn_act(x, conv, bn, relu, residual, pads, weight=None, link=None, chain_in=None, chain_out=None,
-                stride=None, pair=None, parts_only=False):
+                stride=None, pair=None, parts_only=False, grad_inbox=None):
     from .nn_ops import bn_affine
     scale = shift = None
     if bn is not None:
@@ -1382,4 +1431,4 @@ def conv_bn_act(x, conv, bn, relu, residual, pads, weight=None, link=None, chain
     return _ConvFn.apply(x, conv.weight if weight is None else weight, conv.bias, scale, shift,
                          residual, bool(relu), tuple(stride or conv.stride), tuple(conv.dilation), tuple(pads),
                          link if LINK_SHORTCUT_GRAD else None, chain_in, chain_out, conv.weight, pair,
-                         bool(parts_only))
+                         bool(parts_only), grad_inbox)

@@ -60,6 +60,15 @@ class CropGradPool(object):
         self.registered = self.pending = 0
         self.bufs = None
         self.sources = []       # gather backward: the crops' gradients wait here for ONE launch over all of them
+        # conv_hip.GradInbox per map (or None): the maps' other reader (the RPN's shared conv) adds the crops'
+        # gradient in its data-gradient epilogue instead of autograd's accumulation pass
+        self.inboxes = None
+
+    def hand_over(self, grads):
+        """The finished gradient maps: left in the inboxes that take them, returned to autograd otherwise."""
+        if not self.inboxes:
+            return tuple(grads)
+        return tuple(None if (box is not None and box.offer(g)) else g for g, box in zip(grads, self.inboxes))
 
     def register(self):
         self.registered += 1
@@ -113,7 +122,7 @@ def _pyramid_backward(ctx, g, cstride, coff):
         srcs, pool.sources = pool.sources, []
         if pool.pending <= 0:
             pool.pending = pool.registered
-        return _gather_backward(srcs, ctx.shapes, g.device)
+        return pool.hand_over(_gather_backward(srcs, ctx.shapes, g.device))
     first = pool is None or pool.bufs is None
     if first:
         grads = [torch.empty(s, dtype=torch.float32, device=g.device,
@@ -133,6 +142,7 @@ def _pyramid_backward(ctx, g, cstride, coff):
         if pool.pending > 0:
             return (None,) * len(grads)          # a later crop's backward returns the shared maps
         pool.bufs, pool.pending = None, pool.registered
+        return pool.hand_over(grads)
     return tuple(grads)
 
 
@@ -466,13 +476,14 @@ class RPN(nn.Module):
         self.softmax = nn.Softmax(dim=2)
         self.conv_bbox = nn.Conv2d(512, 4 * anchors_per_location, kernel_size=1, stride=1)
 
-    def forward(self, x):
+    def forward(self, x, grad_inbox=None):
         B = x.shape[0]
         # the shared map has exactly two readers (the two 1x1 heads): whichever data gradient runs second
         # adds the first one, applies the ReLU mask and hands conv_shared its prepared gradient
         ch = {"readers": 2} if CHAIN_TWO_READERS else None
         # (its only readers are the two 1x1 heads and their ReLU mask: no fp32 copy of the 512-channel map)
-        x = nn_ops.conv_bn_act(x, self.conv_shared, relu=True, same=True, chain_out=ch, parts_only=True)
+        x = nn_ops.conv_bn_act(x, self.conv_shared, relu=True, same=True, chain_out=ch, parts_only=True,
+                               grad_inbox=grad_inbox)
         # NHWC output == the reference's permute(0,2,3,1).contiguous()
         logits = nn_ops.conv_bn_act(x, self.conv_class, chain_in=ch).permute(0, 2, 3, 1).reshape(B, -1, 2)
         probs = self.softmax(logits)

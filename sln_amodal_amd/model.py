@@ -32,6 +32,8 @@ from .modal.modals import (FPN, RPN, Classifier, Mask, ResNet, pyramid_roi_align
 
 # the GLM's resize / max / softmax / argmax / concat tail as one HIP pass (ops.msc_softmax_tail); "0": A/B switch
 FUSED_GLM_TAIL = os.environ.get("SLN_FUSED_GLM_TAIL", "1") != "0"
+# the crops' gradient w.r.t. P2..P5 added inside the RPN conv's data gradient (rpn_forward); "0": A/B switch
+FUSE_CROP_GRADS = os.environ.get("SLN_FUSE_CROP_GRADS", "1") != "0"
 
 LAYER_REGEX = {
     "new": r"(fpn.C1.*)|(classifier.*)|(mask.*)|(layer_decoder.*)|(rpn.*)",
@@ -237,7 +239,17 @@ class MaskRCNN(nn.Module):
 
     def rpn_forward(self, molded_images):
         maps = self.fpn(molded_images)
-        outs = [self.rpn(p) for p in maps]
+        # training on the HIP path: P2..P5 are read by the RPN and by the heads' crops; the crops' gradient is
+        # added in the epilogue of the RPN conv's data gradient (conv_hip.GradInbox) -- valid when the RPN losses
+        # take part in the backward pass, as in train_step; a pass without them fails loudly
+        self._crop_inboxes = None
+        if FUSE_CROP_GRADS and molded_images.is_cuda and torch.is_grad_enabled() and self.training and \
+                all(m.requires_grad for m in maps[:4]):
+            from . import conv_hip, nn_ops
+            if nn_ops.BACKEND in ("auto", "hip"):
+                self._crop_inboxes = [conv_hip.GradInbox() for _ in range(4)]
+        boxes = (self._crop_inboxes or []) + [None] * len(maps)
+        outs = [self.rpn(p, boxes[i]) for i, p in enumerate(maps)]
         rpn_class_logits, rpn_class, rpn_bbox = [torch.cat(list(o), dim=1) for o in zip(*outs)]
         return maps, rpn_class_logits, rpn_class, rpn_bbox
 
@@ -299,6 +311,7 @@ class MaskRCNN(nn.Module):
                 for m in mrcnn_feature_maps):
             from .modal.modals import CropGradPool
             pool = CropGradPool()
+            pool.inboxes = getattr(self, "_crop_inboxes", None)
         mrcnn_class_logits, mrcnn_class, mrcnn_bbox = self.classifier(mrcnn_feature_maps, rois, box_ind,
                                                                       grad_pool=pool)
         mrcnn_mask, _feat = self.mask(mrcnn_feature_maps, rois, GLM_feature, box_ind, grad_pool=pool)

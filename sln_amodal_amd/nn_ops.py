@@ -69,7 +69,7 @@ def bn_affine(bn):
 
 
 def conv_bn_act(x, conv, bn=None, relu=False, residual=None, same=False, link=None, chain_in=None,
-                chain_out=None, parts_only=False, pair=None):
+                chain_out=None, parts_only=False, pair=None, grad_inbox=None):
     """x [B,C,H,W] (any memory format; channels-last preferred).
     conv: nn.Conv2d parameter holder (weight, bias, stride, padding, dilation).
     bn:   frozen nn.BatchNorm2d or None.  same: apply SamePad2d first.
@@ -80,7 +80,10 @@ def conv_bn_act(x, conv, bn=None, relu=False, residual=None, same=False, link=No
     parts_only: the output is read by convolutions, as the next shortcut and as a ReLU mask only (a bottleneck's
           convolutions): no fp32 copy is written, the result is a placeholder that carries the parts
           (conv_hip.parts_only_of / materialize).  HIP backend, fp16 x 2 operands; ignored elsewhere.
-    pair: dict shared by the two strided 1x1 convs that read the same x (a stage's first block)."""
+    pair: dict shared by the two strided 1x1 convs that read the same x (a stage's first block).
+    grad_inbox: dict in which ANOTHER reader of x leaves its gradient w.r.t. x during the backward pass
+          (conv_hip.GradInbox): this conv's data gradient adds it in its epilogue and returns the sum, the other
+          reader returns nothing -- no accumulation pass by autograd.  HIP backend only; ignored elsewhere."""
     if CALIBRATING is not None and bn is not None:
         # statistics pass (synthetic.calibrate_*): the raw convolution on the same backend, its output's
         # statistics into the frozen BN, then the un-fused normalisation / shortcut / ReLU
@@ -123,7 +126,7 @@ def conv_bn_act(x, conv, bn=None, relu=False, residual=None, same=False, link=No
             return hip.conv_bn_act(xr, conv, bn, relu, None, (0, 0, 0, 0), weight=w2, stride=(1, 1))
         return hip.conv_bn_act(x, conv, bn, relu, residual, (pt, pb, pl, pr), link=link,
                                chain_in=chain_in, chain_out=chain_out, pair=pair,
-                               parts_only=parts_only and PARTS_ONLY)
+                               parts_only=parts_only and PARTS_ONLY, grad_inbox=grad_inbox)
     if hip is not None and not isinstance(x, hip.MultiScale) and hip.is_stem(conv, x) and residual is None:
         return hip.stem_conv_bn_act(x, conv, bn, relu, (pt, pb, pl, pr))   # 3-channel 7x7/2 stems
     if BACKEND != "torch" and x.is_cuda:

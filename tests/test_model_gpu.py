@@ -398,3 +398,51 @@ def test_stage_transition_gradients_merge_into_the_lateral_map():
     for n in grads[0]:
         a, b = grads[0][n], grads[1][n]
         assert (a - b).norm().item() <= 2e-5 * max(b.norm().item(), 1e-12), n
+
+
+def test_crop_gradients_are_added_inside_the_rpn_data_gradient(monkeypatch):
+    """P2..P5 are read by the RPN's shared conv and by the heads' crops: the crops' gradient maps are left in a
+    conv_hip.GradInbox and added in the epilogue of the RPN conv's data gradient (model.FUSE_CROP_GRADS) instead of
+    autograd's accumulation pass.  Same proposals and sampling priorities with the switch on and off: every
+    parameter gradient agrees up to the order of the additions (the crops' own atomics already vary in the last
+    bit); all four maps are handed over and consumed; a backward pass without the RPN losses fails loudly."""
+    from sln_amodal_amd import conv_hip, model as model_mod, synthetic
+    m, cfg = _small_model()
+    batch = synthetic.make_batch(cfg, 2, 256, 256, seed=11, anchors_f64=m.anchors_f64)
+    synthetic.calibrate_batchnorm(m, batch["images"])
+    synthetic.calibrate_glm(m, batch["images"])
+    synthetic.warm_start_rpn(m, [batch], iters=30)
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    pr = {"pos": torch.rand(2, 1000, device="cuda", generator=gen),
+          "neg": torch.rand(2, 1000, device="cuda", generator=gen)}
+    inp = [batch["images"], None, batch["gt_class_ids"], batch["gt_boxes"], batch["gt_layer"]]
+    with torch.no_grad():
+        out = m.predict(inp, mode="training", priorities=pr)
+    pr = dict(pr, rpn_rois=out["rpn_rois"], num_rois=out["num_rois"])
+    grads = []
+    for fused in (False, True, True):
+        monkeypatch.setattr(model_mod, "FUSE_CROP_GRADS", fused)
+        for p in m.parameters():
+            p.grad = None
+        before = list(conv_hip.GradInbox.STATS)
+        out = m.predict(inp, mode="training", priorities=pr)
+        loss, _ = m.compute_losses(out, batch["rpn_match"], batch["rpn_bbox"])
+        loss.backward()
+        got = [a - b for a, b in zip(conv_hip.GradInbox.STATS, before)]
+        assert got == ([4, 4] if fused else [0, 0]), got
+        grads.append({n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None})
+    assert int(out["roi_valid"].sum()) > 20
+    assert grads[0].keys() == grads[1].keys() and len(grads[0]) > 100
+    for n in grads[0]:
+        a, b = grads[1][n], grads[0][n]
+        assert (a - b).norm().item() <= 2e-5 * max(b.norm().item(), 1e-12), n
+    # without the RPN losses the conv that should add the deposit never runs: an error, not a silent loss
+    out = m.predict(inp, mode="training", priorities=pr)
+    _, parts = m.compute_losses(out, batch["rpn_match"], batch["rpn_bbox"])
+    with pytest.raises(RuntimeError, match="never consumed"):
+        (parts["layer"] + parts["mrcnn_class"]).backward()
+    # (and nothing is left behind for the next pass)
+    assert not conv_hip.GradInbox.pending
+    out = m.predict(inp, mode="training", priorities=pr)
+    loss, _ = m.compute_losses(out, batch["rpn_match"], batch["rpn_bbox"])
+    loss.backward()
