@@ -310,6 +310,13 @@ def main():
                               "vs_fp32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
                               "algorithmic_gflop_per_image": round(gflop, 1)},
         }
+        if world > 1:       # gradient exchange: bytes the reduce passes wrote straight into their bucket slots / packed
+            st_ = reducer.stats
+            out["gradient_exchange"] = {"buckets": len(reducer.buckets), "in_place_bytes": st_["in_place_bytes"],
+                                        "copied_bytes": st_["copied_bytes"], "copied_tensors": st_["copied_tensors"],
+                                        "backend": os.environ.get("SLN_DIST_BACKEND", "nccl")}
+        out["launches"] = {"wgrad_reduce_batches": conv_hip.REDUCE_STATS[0], "wgrad_layers_reduced": conv_hip.REDUCE_STATS[1],
+                           "crop_gradients_fused": conv_hip.GradInbox.STATS[1]}
         if strict is not None:
             st = torch.tensor([strict], dtype=torch.float64, device=dev)
             out["strict_bf16x3_images_per_sec"] = round(float(st.item()), 4)
