@@ -202,6 +202,12 @@ int sln_maxpool_bwd_f32(const float *g, const uint8_t *argmax, int N, int H, int
  * sln_upsample2x_add_f32  lateral, out [N,2h,2w,C]; top [N,h,w,C]
  * sln_sumpool2x2_f32      g [N,2h,2w,C] -> gtop [N,h,w,C] = (g00 + g01) + (g10 + g11)
  * ------------------------------------------------------------------------- */
+/* Grouped 3x3 convolution, forward only (BASELINE.json configs[4]; reference modal/resnext.py:31-41,
+ * GroupBottleneck.conv2: padding 1, stride 1 or 2, no bias): x [N,H,W,C] fp32 NHWC, w [C][C/groups][3][3] (torch
+ * layout), C/groups in {4, 8, 16, 32} (SLN_ERR_UNSUPPORTED otherwise), y [N,OH,OW,C] = relu?(conv * scale[c] +
+ * shift[c]) with OH = (H - 1) / stride + 1; scale / shift may be NULL. */
+int sln_grouped_conv3x3_f32(const float *x, int N, int H, int W, int C, int groups, const float *w, int stride,
+                            const float *scale, const float *shift, int relu, float *y, sln_stream_t stream);
 /* Tail of the global layer module (reference model.py:537-541, modal/msc_deeplab.py:42-48), one pass: the logits
  * of the coarser scales resized bilinearly (align_corners = False) to the scale-1 grid, element-wise maximum over
  * the scales, softmax over the C classes, argmax.  All maps NHWC fp32 with the given pixel strides (floats).

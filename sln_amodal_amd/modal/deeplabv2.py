@@ -33,6 +33,8 @@ class _ASPP(nn.Module):
 
 
 class DeepLabV2(nn.Sequential):
+    supports_packed_scales = True      # every layer takes a conv_hip.MultiScale (msc_deeplab.MSC._forward_packed)
+
     def __init__(self, n_classes, n_blocks, atrous_rates):
         super(DeepLabV2, self).__init__()
         ch = [64 * 2 ** p for p in range(6)]

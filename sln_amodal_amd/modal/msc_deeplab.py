@@ -33,8 +33,11 @@ class MSC(nn.Module):
 
     def _packable(self, x):
         from .. import nn_ops
+        # (a base declares that its layers -- children in order, the first one the per-scale stem -- take a
+        # conv_hip.MultiScale: DeepLabV2 does, the ResNeXt encoder + ASPP base does not)
         return (x.is_cuda and not torch.is_grad_enabled() and nn_ops.BACKEND in ("auto", "hip") and
-                nn_ops._hip_conv() is not None and PACK_SCALES)
+                nn_ops._hip_conv() is not None and PACK_SCALES and
+                getattr(self.base, "supports_packed_scales", False))
 
     def softmax_tail(self, x):
         """Inference tail of the reference's glue (model.py:537-541) fused with the scale maximum below:

@@ -127,6 +127,19 @@ def conv_bn_act(x, conv, bn=None, relu=False, residual=None, same=False, link=No
         return hip.conv_bn_act(x, conv, bn, relu, residual, (pt, pb, pl, pr), link=link,
                                chain_in=chain_in, chain_out=chain_out, pair=pair,
                                parts_only=parts_only and PARTS_ONLY, grad_inbox=grad_inbox)
+    if hip is not None and not isinstance(x, hip.MultiScale) and x.is_cuda and conv.groups > 1 and \
+            (kh, kw) == (3, 3) and (pt, pb, pl, pr) == (1, 1, 1, 1) and tuple(dilation) == (1, 1) and \
+            conv.bias is None and residual is None and stride[0] == stride[1] and \
+            conv.in_channels == conv.out_channels and (conv.in_channels // conv.groups) in (4, 8, 16, 32):
+        # ResNeXt's grouped 3x3 (BASELINE.json configs[4]; reference modal/resnext.py:36): forward-only HIP path
+        if torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad):
+            raise RuntimeError("grouped 3x3 convolution: the HIP path is forward only (run under torch.no_grad(), "
+                               "or set nn_ops.BACKEND = 'torch' to differentiate it on aten)")
+        from . import ops
+        scale = shift = None
+        if bn is not None:
+            scale, shift = bn_affine(bn)
+        return ops.grouped_conv3x3(x, conv.weight, conv.groups, stride[0], scale, shift, relu)
     if hip is not None and not isinstance(x, hip.MultiScale) and hip.is_stem(conv, x) and residual is None:
         return hip.stem_conv_bn_act(x, conv, bn, relu, (pt, pb, pl, pr))   # 3-channel 7x7/2 stems
     if BACKEND != "torch" and x.is_cuda:
@@ -136,9 +149,9 @@ def conv_bn_act(x, conv, bn=None, relu=False, residual=None, same=False, link=No
                            (conv.in_channels, conv.out_channels, tuple(conv.kernel_size), conv.groups,
                             x.dtype, BACKEND))
     if pt == pb and pl == pr:
-        y = F.conv2d(x, conv.weight, conv.bias, stride, (pt, pl), dilation)
+        y = F.conv2d(x, conv.weight, conv.bias, stride, (pt, pl), dilation, conv.groups)
     else:
-        y = F.conv2d(F.pad(x, (pl, pr, pt, pb)), conv.weight, conv.bias, stride, 0, dilation)
+        y = F.conv2d(F.pad(x, (pl, pr, pt, pb)), conv.weight, conv.bias, stride, 0, dilation, conv.groups)
     if bn is not None:
         y = F.batch_norm(y, bn.running_mean, bn.running_var, bn.weight, bn.bias, False, 0.0, bn.eps)
     if residual is not None:
@@ -217,6 +230,16 @@ def max_pool_ceil(x, kernel, stride, padding):
             return o - 1 if (o - 1) * stride >= n + padding else o
         return _MaxPoolFn.apply(x, kernel, stride, padding, padding, out(x.shape[2]), out(x.shape[3]))
     return F.max_pool2d(x, kernel, stride, padding, ceil_mode=True)
+
+
+def max_pool_pad(x, kernel, stride, padding):
+    """nn.MaxPool2d(kernel, stride, padding) (floor mode) on a non-negative map (ResNeXt's stem pool,
+    modal/resnext.py:83): the window clipped at the border equals the -inf padded one."""
+    if _hip_pool_ok(x) and padding < kernel:
+        OH = (x.shape[2] + 2 * padding - kernel) // stride + 1
+        OW = (x.shape[3] + 2 * padding - kernel) // stride + 1
+        return _MaxPoolFn.apply(x, kernel, stride, padding, padding, OH, OW)
+    return F.max_pool2d(x, kernel, stride, padding)
 
 
 class _FpnMerge(torch.autograd.Function):

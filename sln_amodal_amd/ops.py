@@ -161,6 +161,26 @@ def mask_targets(label, L, rois, roi_img, roi_obj, mh, mw):
     return masks
 
 
+# --------------------------------------------------------------------- grouped convolution (forward only)
+def grouped_conv3x3(x, weight, groups, stride=1, scale=None, shift=None, relu=False):
+    """x [N,C,H,W] fp32 (channels-last in memory, else copied), weight [C, C/groups, 3, 3], padding 1 -> y
+    [N,C,OH,OW] channels-last = relu?(conv * scale[c] + shift[c]).  Forward only (csrc/grouped_conv.hip; reference
+    modal/resnext.py:31-41 GroupBottleneck.conv2)."""
+    _need(x, torch.float32, "x")
+    N, C, H, W = x.shape
+    if tuple(weight.shape) != (C, C // groups, 3, 3):
+        raise ValueError("grouped_conv3x3: weight %s for C=%d groups=%d" % (tuple(weight.shape), C, groups))
+    xc = x if x.permute(0, 2, 3, 1).is_contiguous() else x.contiguous(memory_format=torch.channels_last)
+    OH, OW = (H - 1) // stride + 1, (W - 1) // stride + 1
+    y = torch.empty((N, OH, OW, C), dtype=torch.float32, device=x.device)
+    w = weight.detach().contiguous()
+    _lib.check(_lib.lib().sln_grouped_conv3x3_f32(_ptr(xc), N, H, W, C, int(groups), _ptr(w), int(stride),
+                                                  _ptr(scale.detach().contiguous()) if scale is not None else None,
+                                                  _ptr(shift.detach().contiguous()) if shift is not None else None,
+                                                  1 if relu else 0, _ptr(y), _stream()), "sln_grouped_conv3x3_f32")
+    return y.permute(0, 3, 1, 2)
+
+
 # --------------------------------------------------------------------- global layer module tail
 def _nhwc_stride(t):
     """Pixel stride (floats) of a logical [B,C,H,W] tensor that is NHWC in memory with rows of equal stride, else None."""

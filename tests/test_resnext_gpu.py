@@ -1,0 +1,83 @@
+"""BASELINE.json configs[4] on the GPU: the grouped 3x3 HIP kernel against aten, the ResNeXt encoder + multi-scale
+ASPP heads against the fixtures of the reference's own classes, and a full-depth forward at a config-sized shape."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.test_resnext_cpu import check
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _hip_backend():
+    from sln_amodal_amd import nn_ops
+    old = nn_ops.BACKEND
+    nn_ops.BACKEND = "hip"       # raise instead of silently falling back
+    yield
+    nn_ops.BACKEND = old
+
+
+@pytest.mark.parametrize("cg", [4, 8, 16, 32])
+@pytest.mark.parametrize("stride", [1, 2])
+def test_grouped_conv3x3_matches_aten(cg, stride):
+    """csrc/grouped_conv.hip (reference modal/resnext.py:36: groups 32, padding 1, no bias) with the fused BN affine
+    and ReLU, odd sizes, against F.conv2d in fp64: relative error of an fp32 accumulation over K = 9 * cg."""
+    from sln_amodal_amd import ops
+    G = 32
+    C = G * cg
+    g = torch.Generator(device="cuda").manual_seed(cg + stride)
+    x = torch.randn(2, C, 37, 29, device="cuda", generator=g).contiguous(memory_format=torch.channels_last)
+    w = torch.randn(C, cg, 3, 3, device="cuda", generator=g) / (9 * cg) ** 0.5
+    scale = torch.rand(C, device="cuda", generator=g) + 0.5
+    shift = torch.randn(C, device="cuda", generator=g) * 0.1
+    want = F.relu(F.conv2d(x.double(), w.double(), None, stride, 1, 1, G) * scale.double().view(1, -1, 1, 1) +
+                  shift.double().view(1, -1, 1, 1))
+    got = ops.grouped_conv3x3(x, w, G, stride, scale, shift, True)
+    assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
+    assert (got.double() - want).abs().max().item() < 2e-6 * want.abs().max().item()
+    plain = ops.grouped_conv3x3(x, w, G, stride)                       # no affine, no ReLU
+    want2 = F.conv2d(x.double(), w.double(), None, stride, 1, 1, G)
+    assert (plain.double() - want2).abs().max().item() < 2e-6 * want2.abs().max().item()
+
+
+def test_resnext_encoder_and_msc_heads_match_the_reference_modules_gpu():
+    """The HIP path (split-operand MFMA kernels for the dense convolutions, the grouped kernel, HIP max-pool) on
+    the fixtures of tools/gen_golden_resnext.py: 1e-4, the path's bound."""
+    check("cuda", 1e-4)
+
+
+def test_grouped_conv_is_forward_only_and_says_so():
+    from sln_amodal_amd import nn_ops
+    from sln_amodal_amd.modal.resnext import GroupBottleneck
+    blk = GroupBottleneck(256, 128, groups=32).cuda().eval()
+    x = torch.randn(1, 256, 16, 16, device="cuda").contiguous(memory_format=torch.channels_last)
+    with pytest.raises(RuntimeError, match="forward only"):
+        blk(x.requires_grad_(True))
+    nn_ops.BACKEND = "torch"          # the explicit way to differentiate it
+    blk(x).sum().backward()
+    assert blk.conv2.weight.grad is not None
+
+
+def test_config5_resnext101_msc_forward_full_depth():
+    """ResNeXt-101 (3, 4, 23, 3; 32 groups) + ASPP under the multi-scale maximum, 4 x 513^2 images, eval: finite
+    logits of the right shape; prints the forward rate."""
+    import time
+    from sln_amodal_amd.modal.resnext import DeepLabV2_ResNeXt101_MSC
+    from tests._util import key_init_
+    from tests.test_resnext_cpu import damp_
+    net = DeepLabV2_ResNeXt101_MSC(182).eval()
+    key_init_(net)
+    damp_(net)
+    net = net.cuda()
+    x = torch.randn(4, 3, 513, 513, device="cuda").contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        y = net(x)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            y = net(x)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 3
+    assert tuple(y.shape) == (4, 182, 17, 17) and bool(torch.isfinite(y).all())
+    print("ResNeXt-101 MSC forward, 4 x 513^2: %.1f ms (%.1f img/s)" % (dt * 1e3, 4 / dt))
