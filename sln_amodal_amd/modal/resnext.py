@@ -19,84 +19,80 @@ def _bn(c):
     return nn.BatchNorm2d(c, eps=1e-5, momentum=0.001)
 
 
-def conv3x3(in_planes, out_planes, stride=1):
-    return nn.Conv2d(in_planes, out_planes, kernel_size=3, stride=stride, padding=1, bias=False)
+def _cba(x, conv, bn, residual=None):
+    """conv -> frozen BN -> (+ shortcut) -> ReLU, one fused launch on the HIP path."""
+    return nn_ops.conv_bn_act(x, conv, bn, relu=True, residual=residual)
 
 
 class GroupBottleneck(nn.Module):
+    """1x1 reduce -> grouped 3x3 (carries the stride) -> 1x1 expand to 2 x planes, shortcut added before the last
+    ReLU (modal/resnext.py:31-66).  Attribute names are the reference's state-dict keys."""
     expansion = 2
 
     def __init__(self, inplanes, planes, stride=1, groups=1, downsample=None):
         super(GroupBottleneck, self).__init__()
-        self.conv1 = nn.Conv2d(inplanes, planes, kernel_size=1, bias=False)
-        self.bn1 = _bn(planes)
-        self.conv2 = nn.Conv2d(planes, planes, kernel_size=3, stride=stride, padding=1, groups=groups, bias=False)
-        self.bn2 = _bn(planes)
-        self.conv3 = nn.Conv2d(planes, planes * 2, kernel_size=1, bias=False)
-        self.bn3 = _bn(planes * 2)
-        self.relu = nn.ReLU(inplace=True)
+        wide = planes * self.expansion
+        shapes = ((inplanes, planes, 1, 1, 0, 1), (planes, planes, 3, stride, 1, groups), (planes, wide, 1, 1, 0, 1))
+        for i, (cin, cout, k, s, pad, g) in enumerate(shapes, 1):
+            setattr(self, "conv%d" % i, nn.Conv2d(cin, cout, kernel_size=k, stride=s, padding=pad, groups=g, bias=False))
+            setattr(self, "bn%d" % i, _bn(cout))
+        self.relu = nn.ReLU(inplace=True)       # (kept for module-tree parity; the ReLUs run inside the fused convs)
         self.downsample = downsample
         self.stride = stride
 
     def forward(self, x):
-        residual = x
-        if self.downsample is not None:
-            residual = nn_ops.conv_bn_act(x, self.downsample[0], self.downsample[1])
-        out = nn_ops.conv_bn_act(x, self.conv1, self.bn1, relu=True)
-        out = nn_ops.conv_bn_act(out, self.conv2, self.bn2, relu=True)
-        return nn_ops.conv_bn_act(out, self.conv3, self.bn3, relu=True, residual=residual)
+        shortcut = x if self.downsample is None else nn_ops.conv_bn_act(x, self.downsample[0], self.downsample[1])
+        h = _cba(_cba(x, self.conv1, self.bn1), self.conv2, self.bn2)
+        return _cba(h, self.conv3, self.bn3, residual=shortcut)
+
+
+_STEM = ((3, 64, 2), (64, 64, 1), (64, 128, 1))                  # three 3x3 convolutions (modal/resnext.py:73-81)
+_STAGES = ((128, 1), (256, 2), (512, 2), (1024, 2))              # planes, stride of layer1..4 (:85-88)
+
+
+def _stem_forward(m, x):
+    for i in (1, 2, 3):
+        x = _cba(x, getattr(m, "conv%d" % i), getattr(m, "bn%d" % i))
+    return nn_ops.max_pool_pad(x, 3, 2, 1)                        # MaxPool2d(3, 2, 1) on a post-ReLU map
 
 
 class ResNeXt(nn.Module):
     def __init__(self, block, layers, groups=32, num_classes=1000):
-        self.inplanes = 128
         super(ResNeXt, self).__init__()
-        self.conv1 = conv3x3(3, 64, stride=2)
-        self.bn1 = _bn(64)
-        self.relu1 = nn.ReLU(inplace=True)
-        self.conv2 = conv3x3(64, 64)
-        self.bn2 = _bn(64)
-        self.relu2 = nn.ReLU(inplace=True)
-        self.conv3 = conv3x3(64, 128)
-        self.bn3 = _bn(128)
-        self.relu3 = nn.ReLU(inplace=True)
+        for i, (cin, cout, s) in enumerate(_STEM, 1):
+            setattr(self, "conv%d" % i, nn.Conv2d(cin, cout, kernel_size=3, stride=s, padding=1, bias=False))
+            setattr(self, "bn%d" % i, _bn(cout))
+            setattr(self, "relu%d" % i, nn.ReLU(inplace=True))
         self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
-        self.layer1 = self._make_layer(block, 128, layers[0], groups=groups)
-        self.layer2 = self._make_layer(block, 256, layers[1], stride=2, groups=groups)
-        self.layer3 = self._make_layer(block, 512, layers[2], stride=2, groups=groups)
-        self.layer4 = self._make_layer(block, 1024, layers[3], stride=2, groups=groups)
+        width = _STEM[-1][1]
+        for i, ((planes, stride), n) in enumerate(zip(_STAGES, layers), 1):
+            setattr(self, "layer%d" % i, self._stage(block, width, planes, n, stride, groups))
+            width = planes * block.expansion
         self.avgpool = nn.AvgPool2d(7, stride=1)
-        self.fc = nn.Linear(1024 * block.expansion, num_classes)
-        for m in self.modules():
+        self.fc = nn.Linear(width, num_classes)
+        for m in self.modules():                                   # He initialisation over the fan-out (:92-98)
             if isinstance(m, nn.Conv2d):
-                n = m.kernel_size[0] * m.kernel_size[1] * m.out_channels // m.groups
-                m.weight.data.normal_(0, math.sqrt(2. / n))
+                fan_out = m.kernel_size[0] * m.kernel_size[1] * m.out_channels // m.groups
+                nn.init.normal_(m.weight, 0.0, math.sqrt(2.0 / fan_out))
             elif isinstance(m, nn.BatchNorm2d):
-                m.weight.data.fill_(1)
-                m.bias.data.zero_()
+                nn.init.ones_(m.weight)
+                nn.init.zeros_(m.bias)
 
-    def _make_layer(self, block, planes, blocks, stride=1, groups=1):
-        downsample = None
-        if stride != 1 or self.inplanes != planes * block.expansion:
-            downsample = nn.Sequential(
-                nn.Conv2d(self.inplanes, planes * block.expansion, kernel_size=1, stride=stride, bias=False),
-                _bn(planes * block.expansion))
-        layers = [block(self.inplanes, planes, stride, groups, downsample)]
-        self.inplanes = planes * block.expansion
-        for _ in range(1, blocks):
-            layers.append(block(self.inplanes, planes, groups=groups))
-        return nn.Sequential(*layers)
-
-    def stem(self, x):
-        x = nn_ops.conv_bn_act(x, self.conv1, self.bn1, relu=True)
-        x = nn_ops.conv_bn_act(x, self.conv2, self.bn2, relu=True)
-        x = nn_ops.conv_bn_act(x, self.conv3, self.bn3, relu=True)
-        return nn_ops.max_pool_pad(x, 3, 2, 1)            # (post-ReLU input)
+    @staticmethod
+    def _stage(block, width, planes, n, stride, groups):
+        """n blocks; the first one carries the stride and, when the width changes, a 1x1 + BN shortcut."""
+        out = planes * block.expansion
+        down = None
+        if stride != 1 or width != out:
+            down = nn.Sequential(nn.Conv2d(width, out, kernel_size=1, stride=stride, bias=False), _bn(out))
+        return nn.Sequential(block(width, planes, stride, groups, down),
+                             *[block(out, planes, groups=groups) for _ in range(n - 1)])
 
     def forward(self, x):
-        x = self.layer4(self.layer3(self.layer2(self.layer1(self.stem(x)))))
-        x = self.avgpool(x)
-        return self.fc(x.reshape(x.size(0), -1))
+        x = _stem_forward(self, x)
+        for i in (1, 2, 3, 4):
+            x = getattr(self, "layer%d" % i)(x)
+        return self.fc(self.avgpool(x).flatten(1))
 
 
 def resnext101(**kwargs):
@@ -115,12 +111,12 @@ class ResNeXtEncoder(nn.Module):
             setattr(self, name, getattr(orig, name))
 
     def forward(self, x, return_feature_maps=False):
-        x = ResNeXt.stem(self, x)
-        out = []
-        for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
-            x = layer(x)
-            out.append(x)
-        return out if return_feature_maps else [x]
+        x = _stem_forward(self, x)
+        maps = []
+        for i in (1, 2, 3, 4):
+            x = getattr(self, "layer%d" % i)(x)
+            maps.append(x)
+        return maps if return_feature_maps else maps[-1:]
 
 
 class _EncoderASPP(nn.Module):
