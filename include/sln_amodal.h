@@ -205,9 +205,21 @@ int sln_maxpool_bwd_f32(const float *g, const uint8_t *argmax, int N, int H, int
 /* Grouped 3x3 convolution, forward only (BASELINE.json configs[4]; reference modal/resnext.py:31-41,
  * GroupBottleneck.conv2: padding 1, stride 1 or 2, no bias): x [N,H,W,C] fp32 NHWC, w [C][C/groups][3][3] (torch
  * layout), C/groups in {4, 8, 16, 32} (SLN_ERR_UNSUPPORTED otherwise), y [N,OH,OW,C] = relu?(conv * scale[c] +
- * shift[c]) with OH = (H - 1) / stride + 1; scale / shift may be NULL. */
+ * shift[c]) with OH = (H - 1) / stride + 1; scale / shift may be NULL.  (The reference differentiates it through
+ * autograd's grouped convolution; the two entry points below are that backward.) */
 int sln_grouped_conv3x3_f32(const float *x, int N, int H, int W, int C, int groups, const float *w, int stride,
                             const float *scale, const float *shift, int relu, float *y, sln_stream_t stream);
+/* Its data gradient: gy [N,OH,OW,C] (w.r.t. the layer's output) -> gx [N,H,W,C].  With y_out (the forward output
+ * of conv -> BN -> ReLU) the gradient is first taken through the ReLU and the BN scale: g = gy * scale[c] where
+ * y_out > 0, else 0 (scale NULL = 1); y_out NULL: g = gy. */
+int sln_grouped_conv3x3_dgrad_f32(const float *gy, const float *y_out, const float *scale, int N, int H, int W,
+                                  int C, int groups, const float *w, int stride, float *gx, sln_stream_t stream);
+/* Its weight gradient gw [C][C/groups][3][3] (the parameter's order) from x [N,H,W,C] and the same g; `workspace`
+ * of sln_grouped_conv3x3_wgrad_workspace_bytes() bytes: per-range partial sums + an ordered reduce, no atomics. */
+size_t sln_grouped_conv3x3_wgrad_workspace_bytes(int N, int H, int W, int C, int groups, int stride);
+int sln_grouped_conv3x3_wgrad_f32(const float *x, const float *gy, const float *y_out, const float *scale, int N,
+                                  int H, int W, int C, int groups, int stride, float *gw, void *workspace,
+                                  size_t workspace_bytes, sln_stream_t stream);
 /* Tail of the global layer module (reference model.py:537-541, modal/msc_deeplab.py:42-48), one pass: the logits
  * of the coarser scales resized bilinearly (align_corners = False) to the scale-1 grid, element-wise maximum over
  * the scales, softmax over the C classes, argmax.  All maps NHWC fp32 with the given pixel strides (floats).

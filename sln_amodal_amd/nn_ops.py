@@ -131,14 +131,16 @@ def conv_bn_act(x, conv, bn=None, relu=False, residual=None, same=False, link=No
             (kh, kw) == (3, 3) and (pt, pb, pl, pr) == (1, 1, 1, 1) and tuple(dilation) == (1, 1) and \
             conv.bias is None and residual is None and stride[0] == stride[1] and \
             conv.in_channels == conv.out_channels and (conv.in_channels // conv.groups) in (4, 8, 16, 32):
-        # ResNeXt's grouped 3x3 (BASELINE.json configs[4]; reference modal/resnext.py:36): forward-only HIP path
-        if torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad):
-            raise RuntimeError("grouped 3x3 convolution: the HIP path is forward only (run under torch.no_grad(), "
-                               "or set nn_ops.BACKEND = 'torch' to differentiate it on aten)")
+        # ResNeXt's grouped 3x3 (BASELINE.json configs[4]; reference modal/resnext.py:36)
         from . import ops
         scale = shift = None
         if bn is not None:
             scale, shift = bn_affine(bn)
+            if torch.is_grad_enabled() and (scale.requires_grad or shift.requires_grad):
+                raise RuntimeError("grouped 3x3 convolution: the HIP path takes a FROZEN BatchNorm (as the whole hot "
+                                   "path does); set nn_ops.BACKEND = 'torch' to train the normalisation on aten")
+        if torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad):
+            return ops.GroupedConv3x3.apply(x, conv.weight, scale, shift, bool(relu), conv.groups, stride[0])
         return ops.grouped_conv3x3(x, conv.weight, conv.groups, stride[0], scale, shift, relu)
     if hip is not None and not isinstance(x, hip.MultiScale) and hip.is_stem(conv, x) and residual is None:
         return hip.stem_conv_bn_act(x, conv, bn, relu, (pt, pb, pl, pr))   # 3-channel 7x7/2 stems

@@ -164,8 +164,8 @@ def mask_targets(label, L, rois, roi_img, roi_obj, mh, mw):
 # --------------------------------------------------------------------- grouped convolution (forward only)
 def grouped_conv3x3(x, weight, groups, stride=1, scale=None, shift=None, relu=False):
     """x [N,C,H,W] fp32 (channels-last in memory, else copied), weight [C, C/groups, 3, 3], padding 1 -> y
-    [N,C,OH,OW] channels-last = relu?(conv * scale[c] + shift[c]).  Forward only (csrc/grouped_conv.hip; reference
-    modal/resnext.py:31-41 GroupBottleneck.conv2)."""
+    [N,C,OH,OW] channels-last = relu?(conv * scale[c] + shift[c]).  No autograd here: GroupedConv3x3 below
+    (csrc/grouped_conv.hip; reference modal/resnext.py:31-41 GroupBottleneck.conv2)."""
     _need(x, torch.float32, "x")
     N, C, H, W = x.shape
     if tuple(weight.shape) != (C, C // groups, 3, 3):
@@ -179,6 +179,48 @@ def grouped_conv3x3(x, weight, groups, stride=1, scale=None, shift=None, relu=Fa
                                                   _ptr(shift.detach().contiguous()) if shift is not None else None,
                                                   1 if relu else 0, _ptr(y), _stream()), "sln_grouped_conv3x3_f32")
     return y.permute(0, 3, 1, 2)
+
+
+class GroupedConv3x3(torch.autograd.Function):
+    """conv (groups, 3x3, padding 1) -> frozen BN affine -> ReLU as one node: forward csrc/grouped_conv.hip, backward
+    its data- and weight-gradient kernels with the ReLU mask and the BN scale applied while the gradient is read
+    (what autograd does for the reference's nn.Conv2d(groups=32) + BN + ReLU, modal/resnext.py:50-52)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, scale, shift, relu, groups, stride):
+        y = grouped_conv3x3(x, weight, groups, stride, scale, shift, relu)
+        ctx.save_for_backward(x, weight, scale, y if relu else None)
+        ctx.cfg = (bool(relu), int(groups), int(stride))
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, scale, y = ctx.saved_tensors
+        relu, groups, stride = ctx.cfg
+        N, C, H, W = x.shape
+        nhwc = lambda t: t if t.permute(0, 2, 3, 1).is_contiguous() else t.contiguous(memory_format=torch.channels_last)
+        gy, xc = nhwc(gy), nhwc(x)
+        if not relu and scale is not None:          # no mask to carry the scale: fold it into the gradient
+            gy, sc = gy * scale.view(1, -1, 1, 1), None
+        else:
+            sc = scale
+        w = weight.detach().contiguous()
+        gx = gw = None
+        L = _lib.lib()
+        if ctx.needs_input_grad[0]:
+            gxb = torch.empty((N, H, W, C), dtype=torch.float32, device=x.device)
+            _lib.check(L.sln_grouped_conv3x3_dgrad_f32(_ptr(gy), _ptr(y) if relu else None, _ptr(sc), N, H, W, C, groups,
+                                                       _ptr(w), stride, _ptr(gxb), _stream()),
+                       "sln_grouped_conv3x3_dgrad_f32")
+            gx = gxb.permute(0, 3, 1, 2)
+        if ctx.needs_input_grad[1]:
+            gw = torch.empty_like(w)
+            nbytes = L.sln_grouped_conv3x3_wgrad_workspace_bytes(N, H, W, C, groups, stride)
+            ws = _workspace(nbytes, x.device)
+            _lib.check(L.sln_grouped_conv3x3_wgrad_f32(_ptr(xc), _ptr(gy), _ptr(y) if relu else None, _ptr(sc), N, H, W,
+                                                       C, groups, stride, _ptr(gw), _ptr(ws), nbytes, _stream()),
+                       "sln_grouped_conv3x3_wgrad_f32")
+        return gx, gw, None, None, None, None, None
 
 
 # --------------------------------------------------------------------- global layer module tail
