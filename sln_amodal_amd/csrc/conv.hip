@@ -108,6 +108,34 @@ __device__ __forceinline__ bool split4(const float4 v, bf16x4 *parts, float s = 
     return sat;
 }
 
+// Two fp16 parts of four values that are KNOWN to be inside the fp16 range after scaling (|v| * s <= 65504: the
+// caller has compared the row's maximum, wave-uniformly): the split without the three clamp instructions per
+// element.  The epilogues are bound by their VALU work (~11 instructions per output element, 64 K elements per
+// 256 x 256 tile = 18 k cycles of the four SIMDs), not by memory; bit-identical to split4<2> on such values.
+__device__ __forceinline__ void split4_inrange(const float4 v, bf16x4 *parts, float s) {
+    const float r[4] = {v.x, v.y, v.z, v.w};
+    h16x4 h0, h1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float q = r[j] * s;                // exact: s is a power of two
+        h0[j] = (_Float16)q;
+        h1[j] = (_Float16)(q - (float)h0[j]);
+    }
+    parts[0] = __builtin_bit_cast(bf16x4, h0);
+    parts[1] = __builtin_bit_cast(bf16x4, h1);
+}
+
+// max(|a|, |b|, |c|) in ONE instruction (source modifiers).  Written out because fmaxf(fabsf(a), ...) costs a
+// canonicalising v_max_f32 |a|, |a| per operand in IEEE mode: 14 instructions for a row of eight instead of 4.
+__device__ __forceinline__ float max3abs(float a, float b, float c) {
+    float d;
+    asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ float amax8(const float v[8]) {
+    return max3abs(max3abs(max3abs(v[0], v[1], v[2]), v[3], v[4]), max3abs(v[5], v[6], v[7]), 0.f);
+}
+
 __device__ __forceinline__ float amax4(float m, const float v[4]) {
     return fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
 }
@@ -948,9 +976,13 @@ __device__ __forceinline__ void epilogue_slab_f16(const ConvParams &p, const flo
                 for (int e = 0; e < 4; ++e) csum[e] += v[e];
             }
             if (PARTS) {
-                amx = amax4(amx, v);
+                const float rmax = amax4(0.f, v);
+                amx = fmaxf(amx, rmax);
                 bf16x4 ps[2];
-                (void)split4<2>(make_float4(v[0], v[1], v[2], v[3]), ps, yqs);
+                if (!(p.dbg & 128) && __builtin_amdgcn_ballot_w64(rmax * yqs > SLN_F16_MAX) == 0)
+                    split4_inrange(make_float4(v[0], v[1], v[2], v[3]), ps, yqs);
+                else
+                    (void)split4<2>(make_float4(v[0], v[1], v[2], v[3]), ps, yqs);
                 *(bf16x4 *)p0 = ps[0];
                 *(bf16x4 *)p1 = ps[1];
             }
@@ -1019,13 +1051,17 @@ __device__ __forceinline__ void w8_cols(const ConvParams &p, int n0, int t, floa
     if (p.res_parts) k.rinv = 1.0f / (p.res_scale ? *p.res_scale : 1.f);
 }
 
-template <int NCOL8, int NTHREADS, int NQ, int RES, int MASK>
+// FULL: the tile lies completely inside the output (all but the last row / column tiles of a launch): no per-row or
+// per-column predicate, so every load and store is issued unconditionally and the compiler can count them -- with
+// the predicates it cannot, and waits for the look-ahead loads with vmcnt(0), i.e. also for every store and for
+// the loads of the half AFTER the one it is about to use.
+template <int NCOL8, int NTHREADS, int NQ, int RES, int MASK, bool FULL>
 __device__ __forceinline__ void w8_load(const ConvParams &p, int m_base, int n0, int t, int q0,
                                         W8Pre<NQ, RES, MASK> &pre) {
     // rows t/NCOL8 + RG*(q0 + q), q = 0..NQ-1, of the 64-row slab at m_base
     constexpr int RG = NTHREADS / NCOL8;
     const int c = n0 + 8 * (t & (NCOL8 - 1));
-    if (c >= p.Cout) return;
+    if (!FULL && c >= p.Cout) return;
     const int row0 = t / NCOL8 + RG * q0;
     const long o0 = (long)(m_base + row0) * p.Cout + c;      // (Cop == Cout here)
     const long ostep = (long)RG * p.Cout;
@@ -1033,7 +1069,7 @@ __device__ __forceinline__ void w8_load(const ConvParams &p, int m_base, int n0,
     const h16x8_t z8 = {};
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-        const bool ok = (m_base + row0 + RG * q) < p.M;
+        const bool ok = FULL || (m_base + row0 + RG * q) < p.M;
         const long o = o0 + q * ostep;
         if (RES == 1) {
             pre.ra[q] = ok ? *(const float4 *)(p.residual + o) : z4;
@@ -1051,13 +1087,13 @@ __device__ __forceinline__ void w8_load(const ConvParams &p, int m_base, int n0,
     }
 }
 
-template <int NCOL8, int LD, int NTHREADS, int NQ, int RES, int MASK>
+template <int NCOL8, int LD, int NTHREADS, int NQ, int RES, int MASK, bool FULL>
 __device__ __forceinline__ void w8_compute(const ConvParams &p, const float *stage, int m_base, int n0, int t, int q0,
                                            float yqs, float &amx, W8Cols &k, const W8Pre<NQ, RES, MASK> &pre) {
     constexpr int RG = NTHREADS / NCOL8;
     const int cg = t & (NCOL8 - 1);
     const int c = n0 + 8 * cg;
-    if (c >= p.Cout) return;
+    if (!FULL && c >= p.Cout) return;
     const int row0 = t / NCOL8 + RG * q0;
     const long o0 = (long)(m_base + row0) * p.Cout + c;
     const long ostep = (long)RG * p.Cout;
@@ -1068,7 +1104,7 @@ __device__ __forceinline__ void w8_compute(const ConvParams &p, const float *sta
     const bool nt = (p.dbg & 64) != 0;       // experiment: non-temporal output stores (no effect measured)
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-        if (m_base + row0 + RG * q < p.M) {
+        if (FULL || m_base + row0 + RG * q < p.M) {
             const float4 a0 = *(const float4 *)(sg + q * RG * LD), a1 = *(const float4 *)(sg + q * RG * LD + 4);
             float v[8] = {a0.x * k.sc[0] + k.sf[0], a0.y * k.sc[1] + k.sf[1], a0.z * k.sc[2] + k.sf[2],
                           a0.w * k.sc[3] + k.sf[3], a1.x * k.sc[4] + k.sf[4], a1.y * k.sc[5] + k.sf[5],
@@ -1132,10 +1168,16 @@ __device__ __forceinline__ void w8_compute(const ConvParams &p, const float *sta
 #pragma unroll
                 for (int e = 0; e < 8; ++e) k.csum[e] += v[e];
             }
-            amx = amax4(amax4(amx, v), v + 4);
+            const float rmax = (p.dbg & 512) ? amax4(amax4(0.f, v), v + 4) : amax8(v);      // (dbg 512: A/B)
+            amx = fmaxf(amx, rmax);
             bf16x4 lo[2], hi[2];
-            (void)split4<2>(make_float4(v[0], v[1], v[2], v[3]), lo, yqs);
-            (void)split4<2>(make_float4(v[4], v[5], v[6], v[7]), hi, yqs);
+            if (!(p.dbg & 128) && __builtin_amdgcn_ballot_w64(rmax * yqs > SLN_F16_MAX) == 0) {   // the wave's rows in range (dbg 128: A/B)
+                split4_inrange(make_float4(v[0], v[1], v[2], v[3]), lo, yqs);
+                split4_inrange(make_float4(v[4], v[5], v[6], v[7]), hi, yqs);
+            } else {
+                (void)split4<2>(make_float4(v[0], v[1], v[2], v[3]), lo, yqs);
+                (void)split4<2>(make_float4(v[4], v[5], v[6], v[7]), hi, yqs);
+            }
             bf16x8 w0, w1;
             w0.s0 = lo[0].x; w0.s1 = lo[0].y; w0.s2 = lo[0].z; w0.s3 = lo[0].w;
             w0.s4 = hi[0].x; w0.s5 = hi[0].y; w0.s6 = hi[0].z; w0.s7 = hi[0].w;
@@ -1159,7 +1201,7 @@ __device__ __forceinline__ void w8_compute(const ConvParams &p, const float *sta
 // thread; BEFORE a half's arithmetic and stores the global loads of the NEXT half (of this slab or the next)
 // are issued (w8_load).  Halves, not whole slabs: two sets of a whole slab's residual + mask rows next to the
 // 128 accumulator registers of the wave group whose slabs come last do not fit the 256-register budget.
-template <int NCOL8, int LD, int NTHREADS, int NSLAB, int RES, int MASK, typename StageFn>
+template <int NCOL8, int LD, int NTHREADS, int NSLAB, int RES, int MASK, bool FULL, typename StageFn>
 __device__ __forceinline__ void epilogue_tile_w8(const ConvParams &p, const float *stage, int m0, int n0, int t,
                                                  float *s_colsum, float alpha, float yqs, float &amx,
                                                  StageFn stage_slab) {
@@ -1171,17 +1213,17 @@ __device__ __forceinline__ void epilogue_tile_w8(const ConvParams &p, const floa
     W8Cols k;
     w8_cols<NCOL8>(p, n0, t, alpha, k);
     W8Pre<NQH, RES, MASK> cur, nxt;
-    if (AHEAD) w8_load<NCOL8, NTHREADS, NQH, RES, MASK>(p, m0, n0, t, 0, cur);
+    if (AHEAD) w8_load<NCOL8, NTHREADS, NQH, RES, MASK, FULL>(p, m0, n0, t, 0, cur);
 #pragma unroll
     for (int h = 0; h < NSLAB; ++h) {
         stage_slab(h);
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < NH; ++u) {
-            if (!AHEAD) w8_load<NCOL8, NTHREADS, NQH, RES, MASK>(p, m0 + h * 64, n0, t, u * NQH, cur);
-            else if (u + 1 < NH) w8_load<NCOL8, NTHREADS, NQH, RES, MASK>(p, m0 + h * 64, n0, t, (u + 1) * NQH, nxt);
-            else if (h + 1 < NSLAB) w8_load<NCOL8, NTHREADS, NQH, RES, MASK>(p, m0 + (h + 1) * 64, n0, t, 0, nxt);
-            w8_compute<NCOL8, LD, NTHREADS, NQH, RES, MASK>(p, stage, m0 + h * 64, n0, t, u * NQH, yqs, amx, k, cur);
+            if (!AHEAD) w8_load<NCOL8, NTHREADS, NQH, RES, MASK, FULL>(p, m0 + h * 64, n0, t, u * NQH, cur);
+            else if (u + 1 < NH) w8_load<NCOL8, NTHREADS, NQH, RES, MASK, FULL>(p, m0 + h * 64, n0, t, (u + 1) * NQH, nxt);
+            else if (h + 1 < NSLAB) w8_load<NCOL8, NTHREADS, NQH, RES, MASK, FULL>(p, m0 + (h + 1) * 64, n0, t, 0, nxt);
+            w8_compute<NCOL8, LD, NTHREADS, NQH, RES, MASK, FULL>(p, stage, m0 + h * 64, n0, t, u * NQH, yqs, amx, k, cur);
             if (AHEAD) cur = nxt;
         }
         __syncthreads();
@@ -1201,10 +1243,17 @@ template <int NCOL8, int LD, int NTHREADS, int NSLAB, typename StageFn>
 __device__ __forceinline__ void epilogue_tile_w8_any(const ConvParams &p, const float *stage, int m0, int n0, int t,
                                                      float *s_colsum, float alpha, float yqs, float &amx,
                                                      StageFn stage_slab) {
-#define SLN_W8(R, K) epilogue_tile_w8<NCOL8, LD, NTHREADS, NSLAB, R, K>(p, stage, m0, n0, t, s_colsum, alpha, yqs, amx, stage_slab)
-    if (p.res_parts) SLN_W8(2, 0);                 // (launcher: never together with a mask)
-    else if (p.mask_part0) SLN_W8(0, 2);
-    else SLN_W8(0, 0);
+#define SLN_W8(R, K, F) epilogue_tile_w8<NCOL8, LD, NTHREADS, NSLAB, R, K, F>(p, stage, m0, n0, t, s_colsum, alpha, yqs, amx, stage_slab)
+    const bool full = m0 + 64 * NSLAB <= p.M && n0 + 8 * NCOL8 <= p.Cout && !(p.dbg & 256);      // block-uniform (dbg 256: A/B)
+    if (full) {
+        if (p.res_parts) SLN_W8(2, 0, true);           // (launcher: never together with a mask)
+        else if (p.mask_part0) SLN_W8(0, 2, true);
+        else SLN_W8(0, 0, true);
+    } else {
+        if (p.res_parts) SLN_W8(2, 0, false);
+        else if (p.mask_part0) SLN_W8(0, 2, false);
+        else SLN_W8(0, 0, false);
+    }
 #undef SLN_W8
 }
 
