@@ -66,6 +66,9 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 //        Scales are powers of two, so v*s and acc/(sa*sb) are exact: the only rounding is in the
 //        parts themselves.  Parts are stored in the same 16-bit containers as bf16 parts.
 #define SLN_F16_MAX 65504.0f
+#ifndef SLN_W8_DEPTH
+#define SLN_W8_DEPTH 2      // half slabs of residual / mask rows in flight ahead, single-epilogue instances of the 256^2 kernel
+#endif
 
 struct SplitScale {
     const float *scale;   // device scalar s (NULL = 1)
@@ -1201,32 +1204,36 @@ __device__ __forceinline__ void w8_compute(const ConvParams &p, const float *sta
 // thread; BEFORE a half's arithmetic and stores the global loads of the NEXT half (of this slab or the next)
 // are issued (w8_load).  Halves, not whole slabs: two sets of a whole slab's residual + mask rows next to the
 // 128 accumulator registers of the wave group whose slabs come last do not fit the 256-register budget.
-template <int NCOL8, int LD, int NTHREADS, int NSLAB, int RES, int MASK, bool FULL, typename StageFn>
+template <int NCOL8, int LD, int NTHREADS, int NSLAB, int RES, int MASK, bool FULL, typename StageFn, int DEPTH = 1>
 __device__ __forceinline__ void epilogue_tile_w8(const ConvParams &p, const float *stage, int m0, int n0, int t,
                                                  float *s_colsum, float alpha, float yqs, float &amx,
                                                  StageFn stage_slab) {
     constexpr int NQ = 64 / (NTHREADS / NCOL8);
     constexpr int NH = NQ >= 2 ? 2 : 1, NQH = NQ / NH;
+    constexpr int NSTEP = NSLAB * NH;               // half slabs of the tile, in order
     // (fp32 residual AND fp32 mask -- a block whose input is an ordinary tensor: rare -- would need 64 more
     // registers for the look-ahead set: that instance loads each half right before it is used)
-    constexpr bool AHEAD = !(RES == 1 && MASK == 1);
+    // D half slabs of residual / mask rows are in flight ahead of the one being worked on
+    constexpr int D = (RES == 1 && MASK == 1) ? 0 : ((RES == 0 && MASK == 0) ? 0 : DEPTH);
     W8Cols k;
     w8_cols<NCOL8>(p, n0, t, alpha, k);
-    W8Pre<NQH, RES, MASK> cur, nxt;
-    if (AHEAD) w8_load<NCOL8, NTHREADS, NQH, RES, MASK, FULL>(p, m0, n0, t, 0, cur);
+    W8Pre<NQH, RES, MASK> pre[D + 1];
 #pragma unroll
-    for (int h = 0; h < NSLAB; ++h) {
-        stage_slab(h);
-        __syncthreads();
+    for (int i = 0; i < D && i < NSTEP; ++i)
+        w8_load<NCOL8, NTHREADS, NQH, RES, MASK, FULL>(p, m0 + (i / NH) * 64, n0, t, (i % NH) * NQH, pre[i % (D + 1)]);
 #pragma unroll
-        for (int u = 0; u < NH; ++u) {
-            if (!AHEAD) w8_load<NCOL8, NTHREADS, NQH, RES, MASK, FULL>(p, m0 + h * 64, n0, t, u * NQH, cur);
-            else if (u + 1 < NH) w8_load<NCOL8, NTHREADS, NQH, RES, MASK, FULL>(p, m0 + h * 64, n0, t, (u + 1) * NQH, nxt);
-            else if (h + 1 < NSLAB) w8_load<NCOL8, NTHREADS, NQH, RES, MASK, FULL>(p, m0 + (h + 1) * 64, n0, t, 0, nxt);
-            w8_compute<NCOL8, LD, NTHREADS, NQH, RES, MASK, FULL>(p, stage, m0 + h * 64, n0, t, u * NQH, yqs, amx, k, cur);
-            if (AHEAD) cur = nxt;
+    for (int i = 0; i < NSTEP; ++i) {
+        const int h = i / NH, u = i % NH;
+        if (u == 0) {
+            stage_slab(h);
+            __syncthreads();
         }
-        __syncthreads();
+        if (i + D < NSTEP || D == 0)
+            w8_load<NCOL8, NTHREADS, NQH, RES, MASK, FULL>(p, m0 + ((i + D) / NH) * 64, n0, t, ((i + D) % NH) * NQH,
+                                                           pre[(i + D) % (D + 1)]);
+        w8_compute<NCOL8, LD, NTHREADS, NQH, RES, MASK, FULL>(p, stage, m0 + h * 64, n0, t, u * NQH, yqs, amx, k,
+                                                              pre[i % (D + 1)]);
+        if (u == NH - 1) __syncthreads();
     }
     if (p.colsum && n0 + 8 * (t & (NCOL8 - 1)) < p.Cout) {   // the row groups share a column: combine in LDS
 #pragma unroll
@@ -1247,21 +1254,27 @@ __device__ __forceinline__ void epilogue_tile_w8_any(const ConvParams &p, const 
     const bool full = m0 + 64 * NSLAB <= p.M && n0 + 8 * NCOL8 <= p.Cout && !(p.dbg & 256);      // block-uniform (dbg 256: A/B)
     if (full) {
         if (p.res_parts) SLN_W8(2, 0, true);           // (launcher: never together with a mask)
+        else if (p.residual && p.mask_part0) SLN_W8(1, 2, true);
+        else if (p.residual) SLN_W8(1, 0, true);
         else if (p.mask_part0) SLN_W8(0, 2, true);
         else SLN_W8(0, 0, true);
     } else {
         if (p.res_parts) SLN_W8(2, 0, false);
+        else if (p.residual && p.mask_part0) SLN_W8(1, 2, false);
+        else if (p.residual) SLN_W8(1, 0, false);
         else if (p.mask_part0) SLN_W8(0, 2, false);
         else SLN_W8(0, 0, false);
     }
 #undef SLN_W8
 }
 
-__device__ __forceinline__ bool epilogue_is_w8(const ConvParams &p) {
+__host__ __device__ __forceinline__ bool epilogue_is_w8(const ConvParams &p) {
     // (launches that READ an fp32 residual or mask stay on the four-channel slab: eight channels per thread make
     // an fp32 row 32-B pieces at a 32-B stride per instruction -- measured 20-35 % slower for the loads, while
     // an fp32 OUTPUT next to the parts still gains; dbg 32: A/B against the four-channel slab)
-    return p.yparts && (p.Cout & 7) == 0 && !p.residual && !p.mask && !(p.dbg & 32);
+    // (round 3, later: with predicate-free full tiles the fp32 residual rows gain too -- dbg 1024 keeps them on
+    // the four-channel slab for A/B; an fp32 MASK stays there)
+    return p.yparts && (p.Cout & 7) == 0 && (!p.residual || !(p.dbg & 1024)) && !p.mask && !(p.dbg & 32);
 }
 
 // Dispatch of a slab: the fixed-feature version whenever the rows are whole 16-B groups.
@@ -1284,7 +1297,7 @@ __device__ __forceinline__ void epilogue_any(const ConvParams &p, const float *s
     }
 }
 
-__device__ __forceinline__ bool epilogue_is_plain(const ConvParams &p) {
+__host__ __device__ __forceinline__ bool epilogue_is_plain(const ConvParams &p) {
     return (p.Cout & 3) == 0 && (!p.yparts || (p.Cop & 3) == 0);
 }
 
@@ -1706,7 +1719,11 @@ __device__ __forceinline__ void mfma16_products(const bf16x8 (&a)[2], const bf16
     c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b0, c, 0, 0, 0);
 }
 
-template <bool STAMP, int NPH, int MS = 32>
+// EPI: which epilogue the instance carries.  0 = all of them, chosen at run time (diagnostic builds, odd shapes);
+// 1 / 2 / 3 / 4 / 5 = ONLY the eight-channel tile epilogue without operands / with the shortcut from its parts / with
+// the ReLU pattern from part 0 / fp32 residual + that pattern / fp32 residual -- the launcher knows which a launch needs.  One variant per instance instead of
+// seven: the all-in-one instance spills 1600 scalar registers into vector lanes (26 VGPRs, a v_readlane per use).
+template <bool STAMP, int NPH, int MS = 32, int EPI = 0>
 __global__ __launch_bounds__(512) void conv_fwd256h_kernel(const ConvParams p) {
     constexpr int P = 2;
     static_assert(MS == 32 || (MS == 16 && NPH == 2), "the 16x16x32 body is written for two phases per stage");
@@ -2008,7 +2025,18 @@ __global__ __launch_bounds__(512) void conv_fwd256h_kernel(const ConvParams p) {
             }
         }
     };
-    if (plain && epilogue_is_w8(p)) {
+    if (EPI > 0) {
+        const bool full = m0 + T2 <= p.M && n0 + T2 <= p.Cout;          // block-uniform
+#define SLN_W8E(R, K, F) epilogue_tile_w8<32, 260, 512, 4, R, K, F, decltype(stage_slab), SLN_W8_DEPTH>(p, stage, m0, n0, t, s_colsum, alpha, yqs, amx, stage_slab)
+        if (full) {
+            if (EPI == 2) SLN_W8E(2, 0, true); else if (EPI == 3) SLN_W8E(0, 2, true);
+            else if (EPI == 4) SLN_W8E(1, 2, true); else if (EPI == 5) SLN_W8E(1, 0, true); else SLN_W8E(0, 0, true);
+        } else {
+            if (EPI == 2) SLN_W8E(2, 0, false); else if (EPI == 3) SLN_W8E(0, 2, false);
+            else if (EPI == 4) SLN_W8E(1, 2, false); else if (EPI == 5) SLN_W8E(1, 0, false); else SLN_W8E(0, 0, false);
+        }
+#undef SLN_W8E
+    } else if (plain && epilogue_is_w8(p)) {
         epilogue_tile_w8_any<32, 260, 512, 4>(p, stage, m0, n0, t, s_colsum, alpha, yqs, amx, stage_slab);
     } else {
 #pragma unroll
@@ -3047,7 +3075,17 @@ extern "C" int sln_conv2d_fwd_ms_f32(const uint16_t *x_parts, int nseg, const in
             const bool m16 = sln_knob("SLN_CONV_MFMA16", 1) != 0;
             if (stamp && four) hipLaunchKernelGGL((conv_fwd256h_kernel<true, 4>), g2, b2, 0, (hipStream_t)stream, p);
             else if (stamp && m16) hipLaunchKernelGGL((conv_fwd256h_kernel<true, 2, 16>), g2, b2, 0, (hipStream_t)stream, p);
-            else if (m16 && !four) hipLaunchKernelGGL((conv_fwd256h_kernel<false, 2, 16>), g2, b2, 0, (hipStream_t)stream, p);
+            else if (m16 && !four) {
+                // the instance that carries only the epilogue this launch needs (SLN_CONV_EPI=0: the all-in-one instance)
+                const bool w8 = epilogue_is_plain(p) && !(p.dbg & 16) && epilogue_is_w8(p) && !(p.dbg & 256) &&
+                                sln_knob("SLN_CONV_EPI", 1) != 0;
+                if (!w8) hipLaunchKernelGGL((conv_fwd256h_kernel<false, 2, 16>), g2, b2, 0, (hipStream_t)stream, p);
+                else if (p.res_parts) hipLaunchKernelGGL((conv_fwd256h_kernel<false, 2, 16, 2>), g2, b2, 0, (hipStream_t)stream, p);
+                else if (p.residual && p.mask_part0) hipLaunchKernelGGL((conv_fwd256h_kernel<false, 2, 16, 4>), g2, b2, 0, (hipStream_t)stream, p);
+                else if (p.residual) hipLaunchKernelGGL((conv_fwd256h_kernel<false, 2, 16, 5>), g2, b2, 0, (hipStream_t)stream, p);
+                else if (p.mask_part0) hipLaunchKernelGGL((conv_fwd256h_kernel<false, 2, 16, 3>), g2, b2, 0, (hipStream_t)stream, p);
+                else hipLaunchKernelGGL((conv_fwd256h_kernel<false, 2, 16, 1>), g2, b2, 0, (hipStream_t)stream, p);
+            }
             else if (stamp) hipLaunchKernelGGL((conv_fwd256h_kernel<true, 2>), g2, b2, 0, (hipStream_t)stream, p);
             else if (four) hipLaunchKernelGGL((conv_fwd256h_kernel<false, 4>), g2, b2, 0, (hipStream_t)stream, p);
             else hipLaunchKernelGGL((conv_fwd256h_kernel<false, 2>), g2, b2, 0, (hipStream_t)stream, p);
