@@ -1303,7 +1303,9 @@ __host__ __device__ __forceinline__ bool epilogue_is_plain(const ConvParams &p) 
 
 // BNT = 128: waves 2x2, each 64x64 (2x2 MFMA tiles).  BNT = 64 (Cout <= 64: the C2 stage): waves 4x1,
 // each 32x64 (1x2 tiles) -- half the B tile and half the MFMAs of a 128-wide tile that would be half empty.
-template <int P, int BNT>
+// EPI as in conv_fwd256h_kernel: 0 = every epilogue, chosen at run time; 1..5 = only that eight-channel tile
+// epilogue (the all-in-one 128-wide instance: 168 VGPRs at three blocks per CU with 144 B of scratch per lane).
+template <int P, int BNT, int EPI = 0>
 __global__ __launch_bounds__(256, BNT == 128 ? SLN_FWD128_BLOCKS : 1) void conv_fwd_kernel(const ConvParams p) {
     constexpr int NI = BNT == 128 ? 2 : 1;        // 32-row MFMA tiles per wave along M
     constexpr int NBI = BNT / 64;                 // 64-row staging passes of the B tile
@@ -1477,7 +1479,18 @@ __global__ __launch_bounds__(256, BNT == 128 ? SLN_FWD128_BLOCKS : 1) void conv_
                             acc[i][j][r];
         }
     };
-    if (plain && epilogue_is_w8(p)) {
+    if (EPI > 0) {
+        const bool full = m0 + BM <= p.M && n0 + BNT <= p.Cout;          // block-uniform
+#define SLN_W8E(R, K, F) epilogue_tile_w8<BNT / 8, SLD, 256, 2, R, K, F>(p, &stage[0][0], m0, n0, t, s_colsum, alpha, yqs, amx, stage_slab)
+        if (full) {
+            if (EPI == 2) SLN_W8E(2, 0, true); else if (EPI == 3) SLN_W8E(0, 2, true);
+            else if (EPI == 4) SLN_W8E(1, 2, true); else if (EPI == 5) SLN_W8E(1, 0, true); else SLN_W8E(0, 0, true);
+        } else {
+            if (EPI == 2) SLN_W8E(2, 0, false); else if (EPI == 3) SLN_W8E(0, 2, false);
+            else if (EPI == 4) SLN_W8E(1, 2, false); else if (EPI == 5) SLN_W8E(1, 0, false); else SLN_W8E(0, 0, false);
+        }
+#undef SLN_W8E
+    } else if (plain && epilogue_is_w8(p)) {
         epilogue_tile_w8_any<BNT / 8, SLD, 256, 2>(p, &stage[0][0], m0, n0, t, s_colsum, alpha, yqs, amx, stage_slab);
     } else {
 #pragma unroll
@@ -3070,12 +3083,12 @@ extern "C" int sln_conv2d_fwd_ms_f32(const uint16_t *x_parts, int nseg, const in
     if (use256) {
         p.gm = (int)gm2; p.gn = (int)gn2;
         if (w_layout == SLN_WEIGHTS_TILED256H) {
-            const bool stamp = sln_knob("SLN_CONV_STAMP", 0), four = sln_knob("SLN_CONV_PHASES", 2) == 4;
+            const bool stamp = sln_knob("SLN_CONV_STAMP", 0) != 0;
             const dim3 g2((unsigned)nb2), b2(512);
             const bool m16 = sln_knob("SLN_CONV_MFMA16", 1) != 0;
-            if (stamp && four) hipLaunchKernelGGL((conv_fwd256h_kernel<true, 4>), g2, b2, 0, (hipStream_t)stream, p);
-            else if (stamp && m16) hipLaunchKernelGGL((conv_fwd256h_kernel<true, 2, 16>), g2, b2, 0, (hipStream_t)stream, p);
-            else if (m16 && !four) {
+            // (the four-phase body and the stamped 32x32x16 body of round 2 are no longer instantiated: build time)
+            if (stamp) hipLaunchKernelGGL((conv_fwd256h_kernel<true, 2, 16>), g2, b2, 0, (hipStream_t)stream, p);
+            else if (m16) {
                 // the instance that carries only the epilogue this launch needs (SLN_CONV_EPI=0: the all-in-one instance)
                 const bool w8 = epilogue_is_plain(p) && !(p.dbg & 16) && epilogue_is_w8(p) && !(p.dbg & 256) &&
                                 sln_knob("SLN_CONV_EPI", 1) != 0;
@@ -3086,8 +3099,6 @@ extern "C" int sln_conv2d_fwd_ms_f32(const uint16_t *x_parts, int nseg, const in
                 else if (p.mask_part0) hipLaunchKernelGGL((conv_fwd256h_kernel<false, 2, 16, 3>), g2, b2, 0, (hipStream_t)stream, p);
                 else hipLaunchKernelGGL((conv_fwd256h_kernel<false, 2, 16, 1>), g2, b2, 0, (hipStream_t)stream, p);
             }
-            else if (stamp) hipLaunchKernelGGL((conv_fwd256h_kernel<true, 2>), g2, b2, 0, (hipStream_t)stream, p);
-            else if (four) hipLaunchKernelGGL((conv_fwd256h_kernel<false, 4>), g2, b2, 0, (hipStream_t)stream, p);
             else hipLaunchKernelGGL((conv_fwd256h_kernel<false, 2>), g2, b2, 0, (hipStream_t)stream, p);
         }
         else if (parts == 2)
@@ -3103,7 +3114,16 @@ extern "C" int sln_conv2d_fwd_ms_f32(const uint16_t *x_parts, int nseg, const in
     const long nblk = (long)p.gm * p.gn;
     if (nblk > 2147483647L) return SLN_ERR_UNSUPPORTED;
     const dim3 g((unsigned)nblk), b(256);
+    const bool w8 = parts == 2 && epilogue_is_plain(p) && !(p.dbg & 16) && epilogue_is_w8(p) && !(p.dbg & 256) &&
+                    sln_knob("SLN_CONV_EPI", 1) != 0;
     if (parts == 2 && narrow) hipLaunchKernelGGL((conv_fwd_kernel<2, 64>), g, b, 0, (hipStream_t)stream, p);
+    else if (parts == 2 && w8) {       // the instance that carries only the epilogue this launch needs
+        if (p.res_parts) hipLaunchKernelGGL((conv_fwd_kernel<2, 128, 2>), g, b, 0, (hipStream_t)stream, p);
+        else if (p.residual && p.mask_part0) hipLaunchKernelGGL((conv_fwd_kernel<2, 128, 4>), g, b, 0, (hipStream_t)stream, p);
+        else if (p.residual) hipLaunchKernelGGL((conv_fwd_kernel<2, 128, 5>), g, b, 0, (hipStream_t)stream, p);
+        else if (p.mask_part0) hipLaunchKernelGGL((conv_fwd_kernel<2, 128, 3>), g, b, 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((conv_fwd_kernel<2, 128, 1>), g, b, 0, (hipStream_t)stream, p);
+    }
     else if (parts == 2) hipLaunchKernelGGL((conv_fwd_kernel<2, 128>), g, b, 0, (hipStream_t)stream, p);
     else if (narrow) hipLaunchKernelGGL((conv_fwd_kernel<3, 64>), g, b, 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((conv_fwd_kernel<3, 128>), g, b, 0, (hipStream_t)stream, p);
