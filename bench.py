@@ -161,7 +161,16 @@ def launch_ranks(n):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    import time
     rc = 0
+    while any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs):      # a rank died: its peers would wait in a collective
+            time.sleep(2.0)
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            break
+        time.sleep(0.2)
     for p in procs:
         rc = max(rc, abs(p.wait()))
     return rc
