@@ -1171,6 +1171,7 @@ __device__ __forceinline__ void w8_compute(const ConvParams &p, const float *sta
 #pragma unroll
                 for (int e = 0; e < 8; ++e) k.csum[e] += v[e];
             }
+            if (p.yparts) {                          // (fp32-only outputs: uniform per launch)
             const float rmax = (p.dbg & 512) ? amax4(amax4(0.f, v), v + 4) : amax8(v);      // (dbg 512: A/B)
             amx = fmaxf(amx, rmax);
             bf16x4 lo[2], hi[2];
@@ -1192,6 +1193,7 @@ __device__ __forceinline__ void w8_compute(const ConvParams &p, const float *sta
             } else {
                 *(bf16x8 *)p0 = w0;
                 *(bf16x8 *)p1 = w1;
+            }
             }
         }
         if (yp) yp += ostep;
@@ -1274,7 +1276,10 @@ __host__ __device__ __forceinline__ bool epilogue_is_w8(const ConvParams &p) {
     // an fp32 OUTPUT next to the parts still gains; dbg 32: A/B against the four-channel slab)
     // (round 3, later: with predicate-free full tiles the fp32 residual rows gain too -- dbg 1024 keeps them on
     // the four-channel slab for A/B; an fp32 MASK stays there)
-    return p.yparts && (p.Cout & 7) == 0 && (!p.residual || !(p.dbg & 1024)) && !p.mask && !(p.dbg & 32);
+    // (fp32-only outputs -- the plain data gradients of the FPN / RPN convolutions, ~20 large launches per step --
+    // run here as well: they were the last users of the all-in-one instance; dbg 2048: A/B)
+    return (p.yparts || (p.y && !(p.dbg & 2048))) && (p.Cout & 7) == 0 && (!p.residual || !(p.dbg & 1024)) && !p.mask &&
+           !(p.dbg & 32);
 }
 
 // Dispatch of a slab: the fixed-feature version whenever the rows are whole 16-B groups.
