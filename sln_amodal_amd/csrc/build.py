@@ -29,17 +29,23 @@ def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     hdrs = [os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith(".h")]
     hdrs.append(os.path.join(HERE, "..", "..", "include", "sln_amodal.h"))
-    objs = []
-    for name in EXACT + FAST:
+    objs, jobs = [], []
+    for name in FAST + EXACT:            # (conv.hip first: it takes ~4 min of the build, the others seconds each)
         src = os.path.join(HERE, name)
         obj = os.path.join(HERE, name.replace(".hip", ".o"))
         objs.append(obj)
         if force or _stale(obj, [src] + hdrs):
             flags = COMMON + (EXACT_FLAGS if name in EXACT else FAST_FLAGS)
-            cmd = [hipcc, "-c", "-x", "hip", src, "-o", obj] + flags
+            jobs.append([hipcc, "-c", "-x", "hip", src, "-o", obj] + flags)
+    if jobs:
+        from concurrent.futures import ThreadPoolExecutor
+
+        def run(cmd):
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
+        with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as pool:     # the translation units are independent
+            list(pool.map(run, jobs))
     if force or _stale(LIB, objs):
         cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs
         if verbose:
