@@ -107,7 +107,8 @@ __global__ __launch_bounds__(256) void grouped_wgrad3x3_kernel(const float *__re
                                                                const float *__restrict__ scale, int N, int H, int W,
                                                                int C, int stride, int OH, int OW, long pix_per_range,
                                                                float *__restrict__ partial) {
-    constexpr int NPROD = 9 * CG * CG, NACC = (NPROD + 255) / 256;
+    constexpr int NPROD = 9 * CG * CG, NACC = CG >= 16 ? 1 : (NPROD + 255) / 256;
+    constexpr int NP = CG * CG / 256;                // CG >= 16: (co, ci) pairs per thread, all nine taps each
     __shared__ float s_g[GW_TILE][CG];
     __shared__ float s_x[GW_TILE][9][CG + 1];        // (+1: the nine taps of a pixel on different banks)
     const int g = blockIdx.y, t = threadIdx.x;
@@ -121,6 +122,15 @@ __global__ __launch_bounds__(256) void grouped_wgrad3x3_kernel(const float *__re
         const int e = min(t + 256 * k, NPROD - 1);            // weight order: ((co * CG + ci) * 9 + tap)
         e_tap[k] = e % 9; e_ci[k] = (e / 9) % CG; e_co[k] = e / (9 * CG);
     }
+    // CG >= 16: a thread owns the pairs (co0 + (256 / CG) k, ci), k < NP, with all nine taps: per pixel nine reads of
+    // the shifted inputs and NP of the gradient feed 9 NP multiply-adds (the product-per-thread layout above needs
+    // two reads per multiply-add and is LDS-bound)
+    const int p_ci = t % CG, p_co0 = t / CG;
+    float pacc[CG >= 16 ? NP : 1][9];
+#pragma unroll
+    for (int k = 0; k < (CG >= 16 ? NP : 1); ++k)
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) pacc[k][tap] = 0.f;
     for (long base = p0; base < p1; base += GW_TILE) {
         __syncthreads();
         for (int i = t; i < GW_TILE * CG; i += 256) {
@@ -148,15 +158,38 @@ __global__ __launch_bounds__(256) void grouped_wgrad3x3_kernel(const float *__re
             s_x[r][tap][c] = v;
         }
         __syncthreads();
-#pragma unroll 4
-        for (int r = 0; r < GW_TILE; ++r)
+        if (CG >= 16) {
+#pragma unroll 2
+            for (int r = 0; r < GW_TILE; ++r) {
+                float xv[9];
 #pragma unroll
-            for (int k = 0; k < NACC; ++k) acc[k] += s_g[r][e_co[k]] * s_x[r][e_tap[k]][e_ci[k]];
+                for (int tap = 0; tap < 9; ++tap) xv[tap] = s_x[r][tap][p_ci];
+#pragma unroll
+                for (int k = 0; k < NP; ++k) {
+                    const float gv = s_g[r][p_co0 + (256 / CG) * k];
+#pragma unroll
+                    for (int tap = 0; tap < 9; ++tap) pacc[k][tap] += gv * xv[tap];
+                }
+            }
+        } else {
+#pragma unroll 4
+            for (int r = 0; r < GW_TILE; ++r)
+#pragma unroll
+                for (int k = 0; k < NACC; ++k) acc[k] += s_g[r][e_co[k]] * s_x[r][e_tap[k]][e_ci[k]];
+        }
     }
     float *out = partial + (size_t)blockIdx.x * C * CG * 9 + (size_t)g * NPROD;     // group g's CG x CG x 9 slice
+    if (CG >= 16) {
 #pragma unroll
-    for (int k = 0; k < NACC; ++k)
-        if (t + 256 * k < NPROD) out[t + 256 * k] = acc[k];
+        for (int k = 0; k < NP; ++k)
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap)
+                out[((size_t)(p_co0 + (256 / CG) * k) * CG + p_ci) * 9 + tap] = pacc[k][tap];
+    } else {
+#pragma unroll
+        for (int k = 0; k < NACC; ++k)
+            if (t + 256 * k < NPROD) out[t + 256 * k] = acc[k];
+    }
 }
 
 __global__ __launch_bounds__(256) void grouped_wgrad_reduce_kernel(const float *__restrict__ partial, int ranges, long n,
@@ -215,8 +248,11 @@ extern "C" int sln_grouped_conv3x3_dgrad_f32(const float *gy, const float *y_out
 // Weight gradient gw [C][C/groups][3][3] (the parameter's order), same g as above.  workspace: at least
 // sln_grouped_conv3x3_wgrad_workspace_bytes() bytes; two launches, no atomics, bit-reproducible.
 static inline int gw_ranges(long npix) {
-    long r = (npix + 4095) / 4096;           // >= 4096 pixels per range, at most 64 ranges per group
-    return (int)(r < 1 ? 1 : (r > 64 ? 64 : r));
+    // >= 256 pixels (eight LDS tiles) per range, at most 128 ranges per group: with 32 groups that is up to 4096
+    // blocks.  (The first version asked for 4096 pixels per range: a 21 x 21 map of 8 images ran as 32 blocks on
+    // 256 CUs, 1 ms per launch, 39 % of a ResNeXt train step.)
+    long r = (npix + 255) / 256;
+    return (int)(r < 1 ? 1 : (r > 128 ? 128 : r));
 }
 extern "C" size_t sln_grouped_conv3x3_wgrad_workspace_bytes(int N, int H, int W, int C, int groups, int stride) {
     if (N < 1 || H < 1 || W < 1 || C < 1 || groups < 1 || C % groups || stride < 1) return 0;
