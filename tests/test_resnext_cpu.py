@@ -55,3 +55,25 @@ def check(device, tol):
 
 def test_resnext_encoder_and_msc_heads_match_the_reference_modules_cpu():
     check("cpu", 1e-5)
+
+
+def test_reference_checkpoint_keys_load_into_the_encoder():
+    """A state dict with the reference's keys -- incl. SynchronizedBatchNorm2d's training accumulators and the
+    classifier, which an encoder does not have -- loads; a checkpoint that lacks a tensor raises."""
+    import pytest
+    from sln_amodal_amd.modal.resnext import GroupBottleneck, ResNeXt, ResNeXtEncoder, load_reference_state_dict
+    g = golden("module_resnext")
+    layers = [int(v) for v in g["layers"]]
+    full = ResNeXt(GroupBottleneck, layers)
+    key_init_(full)
+    sd = dict(full.state_dict())
+    for k in [k for k in sd if k.endswith("running_mean")]:
+        sd[k.replace("running_mean", "_tmp_running_mean")] = sd[k].clone()
+        sd[k.replace("running_mean", "_running_iter")] = torch.ones(1)
+    enc = ResNeXtEncoder(ResNeXt(GroupBottleneck, layers))
+    load_reference_state_dict(enc, sd)
+    assert torch.equal(enc.layer3[0].conv2.weight, full.layer3[0].conv2.weight)
+    assert torch.equal(enc.bn1.running_var, full.bn1.running_var)
+    del sd["layer2.0.conv1.weight"]
+    with pytest.raises(KeyError):
+        load_reference_state_dict(enc, sd)
