@@ -83,6 +83,16 @@ def measure(dev, B=16):
                                    "most of it is served by L2 / Infinity Cache -- measured FETCH_SIZE / WRITE_SIZE: "
                                    "profiles/ (pmc_roialign).  gather_form_ms: the deterministic write-once option "
                                    "(SLN_CROP_GATHER=1)" % (map_bytes >> 20)}
+    # ---- GLM tail: resize + max over three scales + softmax + argmax, 16 x 182 x 65 x 65 ----
+    lg = torch.randn(B, 65, 65, 182, device=dev, generator=g).permute(0, 3, 1, 2)
+    pyr = [torch.randn(B, s, s, 182, device=dev, generator=g).permute(0, 3, 1, 2) for s in (33, 49)]
+    t = _time(lambda: ops.msc_softmax_tail(lg, pyr))
+    by = 4 * (lg.numel() + sum(p_.numel() for p_ in pyr) + B * 65 * 65 * 183) + 8 * B * 65 * 65
+    out["glm_tail"] = {"kernel": "glm_tail_kernel<3>", "bound": "hbm", "bytes": by, "ms": round(t * 1e3, 4),
+                       "achieved": round(by / t / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                       "frac": round(by / t / 1e9 / PEAK_HBM_GBS, 4),
+                       "note": "every input read once + the [probs | argmax/255] map and the labels written; 135 MB: "
+                               "launch- and latency-bound at this size"}
     # ---- NMS: 16 images x 6000 boxes ----
     N = 6000
     tl = torch.rand(B, N, 2, device=dev, generator=g) * 900
