@@ -1077,6 +1077,18 @@ class _ConvFn(torch.autograd.Function):
             gzq = ch.pop("gzq", None)
             g_res = gy if (ch["with_res"] and want_res) else None   # already masked by the reader
             g_bias = ch.pop("gbias") if want_bias else None
+            if gz.shape[1] != N * OH * OW:
+                # the reader saw this output re-viewed as [k M, Cout / k] (the mask head's deconv-as-1x1 under its
+                # pointwise logits conv, nn_ops.deconv2x2_relu_conv1x1): the same memory
+                if gz.shape[1] * gz.shape[2] != N * OH * OW * Co or Co % 8:
+                    raise RuntimeError("chained gradient: the reader's view of this output does not match")
+                gz = gz.view(gz.shape[0], N * OH * OW, Co)
+                if g_bias is not None and g_bias.numel() != Co:
+                    # the reader's sums run over ITS channels (Cout / k): this layer's bias is that vector k times
+                    # (bias.repeat(k)), whose gradient autograd sums over the copies -- the total goes to the first
+                    full = torch.zeros(Co, dtype=g_bias.dtype, device=g_bias.device)
+                    full[:g_bias.numel()] = g_bias
+                    g_bias = full
             CHAIN_STATS[1] += 1
         else:
             gz, g_res, g_bias = _grad_prep(gy, y, scale, want_res, want_bias, parts, slot=ctx.gzslot)

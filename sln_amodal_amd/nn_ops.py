@@ -305,6 +305,9 @@ def deconv2x2_relu(x, deconv):
     return y.reshape(N, 2 * H, 2 * W, Co).permute(0, 3, 1, 2)      # logical NCHW, NHWC in memory
 
 
+CHAIN_DECONV = os.environ.get("SLN_CHAIN_DECONV", "1") != "0"      # A/B switch
+
+
 def deconv2x2_relu_conv1x1(x, deconv, conv):
     """The mask head's tail (modal/modals.py:494-497): ConvTranspose2d(2, stride 2) + ReLU + 1x1 conv to
     the class logits.  A pointwise convolution commutes with the depth-to-space shuffle, so it runs on the
@@ -320,7 +323,12 @@ def deconv2x2_relu_conv1x1(x, deconv, conv):
     b2 = deconv.bias.repeat(4) if deconv.bias is not None else None
     # (the 4*Cout-channel map -- the largest activation of the head -- is read by the logits conv and as its own
     # ReLU mask only: parts only, no fp32 copy)
-    y = hip._ConvFn.apply(x, w2, b2, None, None, None, True, (1, 1), (1, 1), (0, 0, 0, 0), None, None, None,
+    # the logits conv is the only reader of that map: its data gradient prepares the deconv's gradient in its
+    # epilogue (ReLU mask from part 0, parts, bias sums) -- no fp32 gradient of the 1.7-GB map, no stand-alone
+    # preparation pass (0.84 ms per step); the handed-over parts are [4M, Cout] rows = the [M, 4 Cout] the
+    # deconv-as-1x1 wants, as they lie in memory
+    ch = {} if CHAIN_DECONV else None
+    y = hip._ConvFn.apply(x, w2, b2, None, None, None, True, (1, 1), (1, 1), (0, 0, 0, 0), None, None, ch,
                           deconv.weight, None, PARTS_ONLY)
     N, _, H, W = y.shape
     y4 = y.permute(0, 2, 3, 1).reshape(N, H, W * 4, Co).permute(0, 3, 1, 2)     # pixel (i, 4j + 2a + b)
@@ -330,7 +338,7 @@ def deconv2x2_relu_conv1x1(x, deconv, conv):
         po = getattr(y, "_sln_po", None)
         if po is not None:
             y4._sln_po = (y4._sln_parts[1], po[1], po[2])
-    z = conv_bn_act(y4, conv)
+    z = conv_bn_act(y4, conv, chain_in=ch)
     K = z.shape[1]
     z = z.permute(0, 2, 3, 1).reshape(N, H, W, 2, 2, K).permute(0, 5, 1, 3, 2, 4)
     return z.reshape(N, K, 2 * H, 2 * W)
