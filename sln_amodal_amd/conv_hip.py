@@ -1067,7 +1067,7 @@ class _ConvFn(torch.autograd.Function):
             # is a new tensor, caught by the pointer; the version guards the in-place case anyway)
             ref = ch.pop("gu_ref", None)
             ok = "gz" in ch and ((ref is not None and gy.data_ptr() == ref.data_ptr() and
-                                  gy._version == ch.pop("gu_version", None)) if ch["with_res"]
+                                  gy._version == ch.pop("gu_version", None)) if (ch["with_res"] or ch.get("keep_dx"))
                                  else gy.stride() == (0, 0, 0, 0))
             del ref
             if not ok:
@@ -1159,7 +1159,10 @@ class _ConvFn(torch.autograd.Function):
                 ci["gzq"] = ci["gz_slot"].scale if parts == 2 else None
                 gx = None
                 CHAIN_STATS[0] += 1
-            elif ctx.chain_in is not None and ctx.chain_in["with_res"]:
+            elif ctx.chain_in is not None and (ctx.chain_in["with_res"] or ctx.chain_in.get("keep_dx")):
+                # (keep_dx: the producer's output reaches this conv through an op whose gradient w.r.t. it is the
+                # identity -- the FPN merge: lateral + upsampled top -- so this data gradient is BOTH that op's
+                # incoming gradient, still needed as fp32 for the other addend, and the producer's gy)
                 ci = ctx.chain_in
                 gx, gz_up, gb_up = _fwd(gz, N, OH, OW, wt, Ci, KH, KW, (1, 1), dil, dil[0] * (KH - 1) - pt,
                                         dil[1] * (KW - 1) - pl, H, W, None, None,

@@ -78,6 +78,7 @@ class CropGradPool(object):
 # 1 = the write-once gather backward (no atomics: the same bits on every run; 1.75 ms at 16 x 1024^2, 1600 rois),
 # default = one-launch zero fill + atomic scatter (0.7 ms; fp32 atomic order varies in the last bit between runs)
 GATHER_BACKWARD = os.environ.get("SLN_CROP_GATHER", "0") == "1"
+CHAIN_FPN_LATERAL = os.environ.get("SLN_CHAIN_FPN_LATERAL", "1") != "0"      # A/B switch (FPN.forward)
 
 
 def _gather_backward(sources, shapes, device):
@@ -339,11 +340,16 @@ class FPN(nn.Module):
         p5 = conv(c5, self.P5_conv1)
         p4 = nn_ops.upsample2x_add(conv(c4, self.P4_conv1, pair=fan(c4)), p5)
         p3 = nn_ops.upsample2x_add(conv(c3, self.P3_conv1, pair=fan(c3)), p4)
-        p2 = nn_ops.upsample2x_add(conv(c2, self.P2_conv1, pair=fan(c2)), p3)
+        # the finest merged map is read by its 3x3 conv only, and the merge's gradient w.r.t. the lateral is the
+        # identity: that conv's data gradient (kept as fp32 for the upsampled addend) also prepares the lateral
+        # conv's gradient in its epilogue (conv_hip keep_dx chain: no stand-alone pass over the 1-GB map).  The
+        # coarser merged maps have a second reader (the next merge) and stay on the ordinary path.
+        ch2 = {"keep_dx": True} if CHAIN_FPN_LATERAL else None
+        p2 = nn_ops.upsample2x_add(conv(c2, self.P2_conv1, pair=fan(c2), chain_out=ch2), p3)
         p5 = conv(p5, self.P5_conv2[1], same=True)
         p4 = conv(p4, self.P4_conv2[1], same=True)
         p3 = conv(p3, self.P3_conv2[1], same=True)
-        p2 = conv(p2, self.P2_conv2[1], same=True)
+        p2 = conv(p2, self.P2_conv2[1], same=True, chain_in=ch2)
         p6 = p5[:, :, ::2, ::2]  # MaxPool2d(kernel 1, stride 2) == strided subsample
         p6 = p6.contiguous(memory_format=torch.channels_last)
         return [p2, p3, p4, p5, p6]
