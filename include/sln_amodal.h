@@ -445,6 +445,15 @@ int sln_conv_grad_prep_f32(const float *gy, const float *y, const uint16_t *y_pa
                            int64_t M, int C, int C_pad, int parts, float *gu, uint16_t *gz_parts, float *gbias,
                            const float *q_scale, float *q_amax, int32_t *q_saturated,
                            sln_stream_t stream);
+/* The same preparation for a layer whose output went through a max-pool (sln_maxpool_fwd_f32's geometry and
+ * winning taps): the layer's gradient is gathered from the POOLED gradient g_pool [N,OH,OW,C] on the fly -- no
+ * pool-backward launch and no fp32 gradient map of the layer's [N,H,W,C] output (the backbone stem: modals.py:311-317).
+ * y: the layer's fp32 output (ReLU pattern) or NULL; C % 8 == 0; gz_parts [parts][N*H*W][C]; parts may carry
+ * SLN_SUMS_PREZEROED; gz_parts NULL with parts 2: amax-only pass. */
+int sln_conv_grad_prep_pooled_f32(const float *g_pool, const uint8_t *argmax, int N, int H, int W, int K, int S,
+                                  int pad_top, int pad_left, int OH, int OW, const float *y, const float *scale,
+                                  int C, int parts, uint16_t *gz_parts, float *gbias, const float *q_scale,
+                                  float *q_amax, int32_t *q_saturated, sln_stream_t stream);
 int sln_scale_update_f32(float *amax, float *scale, float *history, int32_t *cursor, int n,
                          int64_t history_stride, int window, int target_log2, sln_stream_t stream);
 int sln_conv2d_fwd_f32(const uint16_t *x_parts, int N, int H, int W, int Cin,

@@ -806,6 +806,30 @@ def _grad_prep(gy, y, scale, want_gu, want_bias, parts, slot=None):
     return gz, (gu if want_gu else None), gb
 
 
+def _grad_prep_pooled(pooled, y, scale, want_bias, parts, slot):
+    """_grad_prep for a layer whose output went through a max-pool: the layer's gradient is gathered from the
+    pooled gradient inside the preparation kernel.  pooled = (g [N,C,OH,OW] channels-last, winning taps
+    [N,OH,OW,C] uint8, (N, C, H, W, kernel, stride, pad_top, pad_left, OH, OW)) as nn_ops._MaxPoolFn left it."""
+    g, arg, (N, C, H, W, kernel, stride, pt, pl, OH, OW) = pooled
+    g = _nhwc(g)
+    M = N * H * W
+    gz = torch.empty((parts, M, C), dtype=torch.bfloat16, device=g.device)
+    gb, gb_flag = _zeroed(C, g.device) if want_bias else (None, 0)
+    if parts == 2 and slot is None:
+        raise RuntimeError("two-part gradient preparation needs a scale slot")
+
+    def launch(dst):
+        _lib.check(_lib.lib().sln_conv_grad_prep_pooled_f32(
+            ops._ptr(g), ops._ptr(arg), N, H, W, kernel, stride, pt, pl, OH, OW, ops._ptr(y), ops._ptr(scale), C,
+            parts | (gb_flag if dst is not None else 0), ops._ptr(dst), ops._ptr(gb),
+            *_q3(slot if parts == 2 else None), ops._stream()), "sln_conv_grad_prep_pooled_f32")
+    if parts == 2 and slot.fresh:
+        launch(None)
+        slot.book.settle(slot)
+    launch(gz)
+    return gz, None, gb
+
+
 # ------------------------------------------------------------------ bias folded into the frozen-BN shift
 # shift' = bias * bn_scale + bn_shift of every conv with a bias and a frozen BN (the whole detector: the
 # reference's convs all carry a bias, modals.py:264-355).  The biases train, so the value changes every step
@@ -1285,11 +1309,19 @@ class _StemFn(torch.autograd.Function):
     ReLU passes and the NCHW -> NHWC copy of their output."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, bn_scale, bn_shift, relu, stride, pads):
+    def forward(ctx, x, weight, bias, bn_scale, bn_shift, relu, stride, pads, pool_handoff=None):
         parts = PARTS
         if PARTS_NOGRAD and not any(ctx.needs_input_grad):
             parts = PARTS_NOGRAD
         Co, Ci, KH, KW = weight.shape
+        # the max-pool that is this output's ONLY reader leaves its incoming gradient here instead of scattering it
+        # into a full-size map (nn_ops._MaxPoolFn.backward): the gradient preparation gathers from it
+        ctx.pool_handoff = None
+        if pool_handoff is not None and Co % 8 == 0 and not ctx.needs_input_grad[0] and \
+                (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]):
+            pool_handoff.clear()
+            pool_handoff["armed"] = True
+            ctx.pool_handoff = pool_handoff
         xc = _nhwc(x.detach())
         N, _, H, W = xc.shape
         pt, pb, pl, pr = pads
@@ -1346,8 +1378,16 @@ class _StemFn(torch.autograd.Function):
         want_bias = has_bias and ctx.needs_input_grad[2]
         gx = gw = g_bias = None
         need_x = ctx.needs_input_grad[0]
+        pooled = ctx.pool_handoff.pop("pooled", None) if ctx.pool_handoff is not None else None
+        if pooled is not None and gy.stride() != (0, 0, 0, 0):
+            raise RuntimeError("stem: the pool handed its gradient over, but another gradient arrived as well -- "
+                               "the stem output has a second reader")
         if need_w or want_bias or need_x:
-            gz, _, g_bias = _grad_prep(gy, y, scale, False, want_bias, parts, slot=ctx.gzslot)
+            if pooled is not None:
+                gz, _, g_bias = _grad_prep_pooled(pooled, y, scale, want_bias, parts, ctx.gzslot)
+                POOL_HANDOFF_STATS[0] += 1
+            else:
+                gz, _, g_bias = _grad_prep(gy, y, scale, False, want_bias, parts, slot=ctx.gzslot)
             gzq = ctx.gzslot.scale if parts == 2 else None
         if need_x:     # (module-level use only: the model's image carries no gradient)
             H, W, stride, pt, pl = ctx.geom
@@ -1370,7 +1410,7 @@ class _StemFn(torch.autograd.Function):
             _prof_end(e0, 2.0 * N * OH * OW * Co * K, "conv_wgrad_kernel<%d>" % parts,
                       "wgrad stem N%d %dx%d K%d->%d" % (N, OH, OW, K, Co), _nbytes(gz, xp), _nbytes(gw_t))
             gw = gw_t.view(Co, Kp)[:, :K].reshape(Co, KH, KW, Ci).permute(0, 3, 1, 2)
-        return gx, gw, g_bias, None, None, None, None, None
+        return gx, gw, g_bias, None, None, None, None, None, None
 
 
 def is_stem(conv, x):
@@ -1380,12 +1420,16 @@ def is_stem(conv, x):
             conv.out_channels % 8 == 0)
 
 
-def stem_conv_bn_act(x, conv, bn, relu, pads):
+POOL_HANDOFF_STATS = [0]      # stem gradient preparations that gathered from the pooled gradient
+
+
+def stem_conv_bn_act(x, conv, bn, relu, pads, pool_handoff=None):
     from .nn_ops import bn_affine
     scale = shift = None
     if bn is not None:
         scale, shift = bn_affine(bn)
-    return _StemFn.apply(x, conv.weight, conv.bias, scale, shift, bool(relu), tuple(conv.stride), tuple(pads))
+    return _StemFn.apply(x, conv.weight, conv.bias, scale, shift, bool(relu), tuple(conv.stride), tuple(pads),
+                         pool_handoff)
 
 
 _DUMMY = {}

@@ -290,11 +290,58 @@ __global__ __launch_bounds__(256) void col2im_kernel(const float *__restrict__ c
 // bf16 parts of gz, and accumulates the per-channel sum of gz (bias gradient).
 // A thread keeps one channel quad and walks rows (no index division, bias sums stay in
 // registers until the end); two rows are in flight per iteration.
+// Source of a gradient that is still "behind" a max-pool (the backbone stem: conv -> BN -> ReLU -> 3x3/2 pool): the
+// pooled gradient [N,OH,OW,C] and the pool's winning taps; the row the preparation wants is then gathered here --
+// the sum over the windows whose winner is this pixel (csrc/maxpool.hip: the same walk) -- instead of being read
+// from a 1-GB fp32 map that a separate pool-backward kernel wrote.
+struct PoolSrc {
+    const float *g;            // NULL: the gradient is read from gy as usual
+    const unsigned char *arg;
+    int H, W, K, S, pt, pl, OH, OW;
+};
+
+__device__ __forceinline__ void pooled_row(const PoolSrc &ps, long m, int c, int C, float g[4]) {
+    const int iw = (int)(m % ps.W);
+    const long t = m / ps.W;
+    const int ih = (int)(t % ps.H);
+    const long n = t / ps.H;
+    g[0] = g[1] = g[2] = g[3] = 0.f;
+    const int oh_lo = max(0, (ih + ps.pt - ps.K + ps.S) / ps.S), oh_hi = min(ps.OH - 1, (ih + ps.pt) / ps.S);
+    const int ow_lo = max(0, (iw + ps.pl - ps.K + ps.S) / ps.S), ow_hi = min(ps.OW - 1, (iw + ps.pl) / ps.S);
+    for (int oh = oh_lo; oh <= oh_hi; ++oh) {
+        const int kh = ih - (oh * ps.S - ps.pt);
+        if (kh < 0 || kh >= ps.K) continue;
+        for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+            const int kw = iw - (ow * ps.S - ps.pl);
+            if (kw < 0 || kw >= ps.K) continue;
+            const long o = ((n * ps.OH + oh) * ps.OW + ow) * C + c;
+            const uchar4 a = *(const uchar4 *)(ps.arg + o);
+            const float4 gv = *(const float4 *)(ps.g + o);
+            const unsigned tap = (unsigned)(kh * ps.K + kw);
+            if (a.x == tap) g[0] += gv.x;
+            if (a.y == tap) g[1] += gv.y;
+            if (a.z == tap) g[2] += gv.z;
+            if (a.w == tap) g[3] += gv.w;
+        }
+    }
+}
+
 __device__ __forceinline__ void grad_prep_row(const float *__restrict__ gy, const float *__restrict__ y,
                                               const __bf16 *__restrict__ y16, int Cp, long m, int c, int C,
-                                              bool vec, float g[4]) {
+                                              bool vec, float g[4], const PoolSrc &ps) {
     // ReLU pattern: the layer's fp32 output y, or part 0 of an output that exists as parts only (y16, rows of
     // Cp 16-bit words: h0 > 0)
+    if (ps.g) {            // (launcher: C % 4 == 0, fp32 pattern or none)
+        pooled_row(ps, m, c, C, g);
+        if (y) {
+            const float4 yy = *(const float4 *)(y + m * C + c);
+            if (!(yy.x > 0.f)) g[0] = 0.f;
+            if (!(yy.y > 0.f)) g[1] = 0.f;
+            if (!(yy.z > 0.f)) g[2] = 0.f;
+            if (!(yy.w > 0.f)) g[3] = 0.f;
+        }
+        return;
+    }
     g[0] = g[1] = g[2] = g[3] = 0.f;
     if (y16) {
         const h16x4 k4 = *(const h16x4 *)(y16 + m * Cp + c);      // (c + 3 < Cp: Cp % 8 == 0, c % 4 == 0)
@@ -367,7 +414,7 @@ __global__ __launch_bounds__(256) void grad_prep_kernel(const float *__restrict_
                                                         const float *__restrict__ scale, long M, int C,
                                                         int Cp, float *__restrict__ gu,
                                                         __bf16 *__restrict__ parts,
-                                                        float *__restrict__ gbias, SplitScale q) {
+                                                        float *__restrict__ gbias, SplitScale q, PoolSrc ps) {
     __shared__ float s_bias[1024];
     __shared__ unsigned s_word[2];
     const int q4 = Cp / 4;
@@ -390,14 +437,14 @@ __global__ __launch_bounds__(256) void grad_prep_kernel(const float *__restrict_
             long m = (long)blockIdx.x * R + r0;
             for (; m + rstep < M; m += 2 * rstep) {
                 float g0[4], g1[4];
-                grad_prep_row(gy, y, y16, Cp, m, c, C, vec, g0);
-                grad_prep_row(gy, y, y16, Cp, m + rstep, c, C, vec, g1);
+                grad_prep_row(gy, y, y16, Cp, m, c, C, vec, g0, ps);
+                grad_prep_row(gy, y, y16, Cp, m + rstep, c, C, vec, g1, ps);
                 grad_prep_emit<P>(g0, m, c, C, Cp, vec, sc, acc, pstride, gu, parts, qs, amx, sat);
                 grad_prep_emit<P>(g1, m + rstep, c, C, Cp, vec, sc, acc, pstride, gu, parts, qs, amx, sat);
             }
             if (m < M) {
                 float g0[4];
-                grad_prep_row(gy, y, y16, Cp, m, c, C, vec, g0);
+                grad_prep_row(gy, y, y16, Cp, m, c, C, vec, g0, ps);
                 grad_prep_emit<P>(g0, m, c, C, Cp, vec, sc, acc, pstride, gu, parts, qs, amx, sat);
             }
         }
@@ -2972,12 +3019,49 @@ extern "C" int sln_conv_grad_prep_f32(const float *gy, const float *y, const uin
     long grid = sln_div_up(M, (long)(256 / tw) * 2);
     if (grid > 2048) grid = 2048;
     const SplitScale q = {q_scale, q_amax, q_saturated};
+    const PoolSrc nopool = {};
     if (parts == 2)
         hipLaunchKernelGGL(grad_prep_kernel<2>, dim3((unsigned)grid), dim3(256), 0, st, gy, y,
-                           (const __bf16 *)y_part0, scale, (long)M, C, C_pad, gu, (__bf16 *)gz_parts, gbias, q);
+                           (const __bf16 *)y_part0, scale, (long)M, C, C_pad, gu, (__bf16 *)gz_parts, gbias, q, nopool);
     else
         hipLaunchKernelGGL(grad_prep_kernel<3>, dim3((unsigned)grid), dim3(256), 0, st, gy, y,
-                           (const __bf16 *)nullptr, scale, (long)M, C, C_pad, gu, (__bf16 *)gz_parts, gbias, q);
+                           (const __bf16 *)nullptr, scale, (long)M, C, C_pad, gu, (__bf16 *)gz_parts, gbias, q, nopool);
+    return sln_launch_status();
+}
+
+// The same preparation for a layer whose output went through a max-pool (K x K, stride S, clipped windows:
+// sln_maxpool_fwd_f32's geometry and winning taps): the layer's gradient is gathered from the POOLED gradient
+// g_pool [N,OH,OW,C] on the fly -- no pool-backward launch, no fp32 gradient map of the layer's output.
+// y: the layer's fp32 output (its ReLU pattern) or NULL; C % 8 == 0.
+extern "C" int sln_conv_grad_prep_pooled_f32(const float *g_pool, const uint8_t *argmax, int N, int H, int W, int K,
+                                             int S, int pad_top, int pad_left, int OH, int OW, const float *y,
+                                             const float *scale, int C, int parts, uint16_t *gz_parts, float *gbias,
+                                             const float *q_scale, float *q_amax, int32_t *q_saturated,
+                                             sln_stream_t stream) {
+    sln_enter();
+    const bool sums_zero = (parts & SLN_SUMS_PREZEROED) != 0;
+    parts &= ~SLN_SUMS_PREZEROED;
+    if (N < 0 || H < 1 || W < 1 || C < 8 || (C & 7) || parts < 2 || parts > 3 || K < 1 || K > 15 || S < 1 || pad_top < 0 ||
+        pad_left < 0 || pad_top >= K || pad_left >= K || OH < 1 || OW < 1)
+        return SLN_ERR_INVALID_ARG;
+    if (!g_pool || !argmax || (!gz_parts && !(parts == 2 && q_amax))) return SLN_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (!sums_zero && gz_parts && gbias && hipMemsetAsync(gbias, 0, sizeof(float) * C, st) != hipSuccess)
+        return SLN_ERR_LAUNCH;
+    const long M = (long)N * H * W;
+    if (M == 0) return SLN_OK;
+    int tw = 1;
+    while (tw < C / 4 && tw < 256) tw <<= 1;
+    long grid = sln_div_up(M, (long)(256 / tw) * 2);
+    if (grid > 2048) grid = 2048;
+    const SplitScale q = {q_scale, q_amax, q_saturated};
+    const PoolSrc ps = {g_pool, argmax, H, W, K, S, pad_top, pad_left, OH, OW};
+    if (parts == 2)
+        hipLaunchKernelGGL(grad_prep_kernel<2>, dim3((unsigned)grid), dim3(256), 0, st, g_pool, y, (const __bf16 *)nullptr,
+                           scale, M, C, C, (float *)nullptr, (__bf16 *)gz_parts, gbias, q, ps);
+    else
+        hipLaunchKernelGGL(grad_prep_kernel<3>, dim3((unsigned)grid), dim3(256), 0, st, g_pool, y, (const __bf16 *)nullptr,
+                           scale, M, C, C, (float *)nullptr, (__bf16 *)gz_parts, gbias, q, ps);
     return sln_launch_status();
 }
 

@@ -79,6 +79,7 @@ class CropGradPool(object):
 # default = one-launch zero fill + atomic scatter (0.7 ms; fp32 atomic order varies in the last bit between runs)
 GATHER_BACKWARD = os.environ.get("SLN_CROP_GATHER", "0") == "1"
 CHAIN_FPN_LATERAL = os.environ.get("SLN_CHAIN_FPN_LATERAL", "1") != "0"      # A/B switch (FPN.forward)
+STEM_POOL_HANDOFF = os.environ.get("SLN_STEM_POOL_HANDOFF", "1") != "0"      # A/B switch (_Stem.forward)
 
 
 def _gather_backward(sources, shapes, device):
@@ -412,8 +413,11 @@ class _Stem(nn.Sequential):
     """C1: 7x7/2 conv + BN + ReLU + SamePad + 3x3/2 max-pool (modals.py:311-317)."""
 
     def forward(self, x):
-        x = nn_ops.conv_bn_act(x, self[0], self[1], relu=True)
-        return nn_ops.max_pool_same(x, 3, 2)
+        # the pool is the conv output's only reader: in backward it hands its incoming gradient to the conv's
+        # gradient preparation, which gathers from it (no pool-backward pass over the 1-GB map)
+        h = {} if STEM_POOL_HANDOFF else None
+        x = nn_ops.conv_bn_act(x, self[0], self[1], relu=True, pool_handoff=h)
+        return nn_ops.max_pool_same(x, 3, 2, handoff=h)
 
 
 class ResNet(nn.Module):

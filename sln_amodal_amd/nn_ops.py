@@ -69,7 +69,7 @@ def bn_affine(bn):
 
 
 def conv_bn_act(x, conv, bn=None, relu=False, residual=None, same=False, link=None, chain_in=None,
-                chain_out=None, parts_only=False, pair=None, grad_inbox=None):
+                chain_out=None, parts_only=False, pair=None, grad_inbox=None, pool_handoff=None):
     """x [B,C,H,W] (any memory format; channels-last preferred).
     conv: nn.Conv2d parameter holder (weight, bias, stride, padding, dilation).
     bn:   frozen nn.BatchNorm2d or None.  same: apply SamePad2d first.
@@ -83,7 +83,10 @@ def conv_bn_act(x, conv, bn=None, relu=False, residual=None, same=False, link=No
     pair: dict shared by the two strided 1x1 convs that read the same x (a stage's first block).
     grad_inbox: dict in which ANOTHER reader of x leaves its gradient w.r.t. x during the backward pass
           (conv_hip.GradInbox): this conv's data gradient adds it in its epilogue and returns the sum, the other
-          reader returns nothing -- no accumulation pass by autograd.  HIP backend only; ignored elsewhere."""
+          reader returns nothing -- no accumulation pass by autograd.  HIP backend only; ignored elsewhere.
+    pool_handoff: dict shared by a 3-channel stem conv and the max-pool that is its output's only reader
+          (max_pool_same(..., handoff=)): the pool's backward leaves its incoming gradient there and the stem's
+          gradient preparation gathers from it (no pool-backward launch, no fp32 gradient of the stem output)."""
     if CALIBRATING is not None and bn is not None:
         # statistics pass (synthetic.calibrate_*): the raw convolution on the same backend, its output's
         # statistics into the frozen BN, then the un-fused normalisation / shortcut / ReLU
@@ -143,7 +146,7 @@ def conv_bn_act(x, conv, bn=None, relu=False, residual=None, same=False, link=No
             return ops.GroupedConv3x3.apply(x, conv.weight, scale, shift, bool(relu), conv.groups, stride[0])
         return ops.grouped_conv3x3(x, conv.weight, conv.groups, stride[0], scale, shift, relu)
     if hip is not None and not isinstance(x, hip.MultiScale) and hip.is_stem(conv, x) and residual is None:
-        return hip.stem_conv_bn_act(x, conv, bn, relu, (pt, pb, pl, pr))   # 3-channel 7x7/2 stems
+        return hip.stem_conv_bn_act(x, conv, bn, relu, (pt, pb, pl, pr), pool_handoff)   # 3-channel 7x7/2 stems
     if BACKEND != "torch" and x.is_cuda:
         # no silent aten/MIOpen fallback on the GPU
         raise RuntimeError("conv %s -> %s k%s groups=%d dtype=%s has no HIP path (nn_ops.BACKEND=%r); "
@@ -171,8 +174,9 @@ class _MaxPoolFn(torch.autograd.Function):
     backward gathers -- every input gradient written once, no memset."""
 
     @staticmethod
-    def forward(ctx, x, kernel, stride, pad_top, pad_left, OH, OW):
+    def forward(ctx, x, kernel, stride, pad_top, pad_left, OH, OW, handoff=None):
         from . import _lib, ops
+        ctx.handoff = handoff
         xc = x if x.is_contiguous(memory_format=torch.channels_last) else \
             x.contiguous(memory_format=torch.channels_last)
         N, C, H, W = xc.shape
@@ -195,19 +199,25 @@ class _MaxPoolFn(torch.autograd.Function):
         N, C, H, W, kernel, stride, pad_top, pad_left, OH, OW = ctx.cfg
         gc = g if g.is_contiguous(memory_format=torch.channels_last) else \
             g.contiguous(memory_format=torch.channels_last)
+        if ctx.handoff is not None and ctx.handoff.get("armed"):
+            # the producing stem conv gathers from the pooled gradient itself (conv_hip._grad_prep_pooled): what
+            # goes back through autograd is a zero-stride placeholder that nothing reads
+            from . import conv_hip
+            ctx.handoff["pooled"] = (gc, arg, ctx.cfg)
+            return conv_hip._dummy_grad(g.device).expand(N, C, H, W), None, None, None, None, None, None, None
         gx = torch.empty((N, C, H, W), dtype=torch.float32, device=g.device, memory_format=torch.channels_last)
         _lib.check(_lib.lib().sln_maxpool_bwd_f32(ops._ptr(gc), ops._ptr(arg), N, H, W, C, kernel, stride, pad_top,
                                                   pad_left, OH, OW, ops._ptr(gx), ops._stream()), "sln_maxpool_bwd_f32")
-        return gx, None, None, None, None, None, None
+        return gx, None, None, None, None, None, None, None
 
 
 def _hip_pool_ok(x):
     return BACKEND != "torch" and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] % 4 == 0
 
 
-def max_pool_same(x, kernel, stride):
+def max_pool_same(x, kernel, stride, handoff=None):
     """SamePad2d + MaxPool2d (modal/modals.py:316-317).  Zero padding is safe: the
-    input is post-ReLU."""
+    input is post-ReLU.  handoff: see conv_bn_act(pool_handoff=)."""
     pt, pb = same_pad(x.shape[2], kernel, stride)
     pl, pr = same_pad(x.shape[3], kernel, stride)
     H, W = x.shape[2], x.shape[3]
@@ -215,7 +225,7 @@ def max_pool_same(x, kernel, stride):
         # a window clipped at the border equals the zero-padded one for the non-negative input
         OH = (H + pt + pb - kernel) // stride + 1
         OW = (W + pl + pr - kernel) // stride + 1
-        return _MaxPoolFn.apply(x, kernel, stride, pt, pl, OH, OW)
+        return _MaxPoolFn.apply(x, kernel, stride, pt, pl, OH, OW, handoff)
     if pt == 0 and pl == 0 and pb < kernel and pr < kernel and \
             -(-(H - kernel) // stride) + 1 == -(-H // stride) and -(-(W - kernel) // stride) + 1 == -(-W // stride):
         # bottom/right padding only (the even sizes of the path): a clipped last window equals a

@@ -762,6 +762,40 @@ def test_stem_forward_and_weight_gradient_match_fp64(case, parts, monkeypatch):
         assert (gb.double() - rb).abs().max().item() / rb.abs().max().item() < 2e-5, (case, parts, rnd)
 
 
+def test_stem_gradient_preparation_gathers_from_the_pooled_gradient(monkeypatch):
+    """C1 = 7x7/2 conv + BN + ReLU + SamePad + 3x3/2 max-pool (modal/modals.py:311-317): in backward the pool hands
+    its incoming gradient to the conv's gradient preparation, which gathers from it (sln_conv_grad_prep_pooled_f32)
+    -- no pool-backward pass, no fp32 gradient of the conv output.  Same sums in the same order as the two-kernel
+    path: the weight gradient is bit-identical, the bias gradient (atomic column sums) agrees to rounding."""
+    from sln_amodal_amd import conv_hip
+    from sln_amodal_amd.modal import modals
+    from tests._util import key_init_
+    monkeypatch.setattr(conv_hip, "PARTS", 2)
+    c1 = modals.ResNet("resnet50").C1.cuda().eval()
+    key_init_(c1)
+    for p in c1[1].parameters():
+        p.requires_grad = False
+    g = torch.Generator(device="cuda").manual_seed(4)
+    x = torch.randn(3, 3, 150, 122, device="cuda", generator=g)
+    up = None
+    out = {}
+    for on in (False, True, False, True):
+        monkeypatch.setattr(modals, "STEM_POOL_HANDOFF", on)
+        conv_hip.update_scales()
+        c1.zero_grad(set_to_none=True)
+        before = conv_hip.POOL_HANDOFF_STATS[0]
+        y = c1(x)
+        if up is None:
+            up = torch.randn(y.shape, device="cuda", generator=g)
+        (y * up).sum().backward()
+        assert conv_hip.POOL_HANDOFF_STATS[0] - before == (1 if on else 0)
+        out[on] = (y.detach().clone(), c1[0].weight.grad.clone(), c1[0].bias.grad.clone())
+    assert torch.equal(out[True][0], out[False][0])
+    assert torch.equal(out[True][1], out[False][1])
+    assert torch.allclose(out[True][2], out[False][2], rtol=1e-5, atol=1e-6 * float(out[False][2].abs().max()))
+    assert float(out[True][1].abs().max()) > 0
+
+
 def test_stem_without_bn_bias_relu_and_forward_only():
     from sln_amodal_amd import conv_hip
     g = torch.Generator(device="cuda").manual_seed(5)
