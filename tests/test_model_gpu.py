@@ -446,3 +446,43 @@ def test_crop_gradients_are_added_inside_the_rpn_data_gradient(monkeypatch):
     out = m.predict(inp, mode="training", priorities=pr)
     loss, _ = m.compute_losses(out, batch["rpn_match"], batch["rpn_bbox"])
     loss.backward()
+
+
+def test_p2_lateral_gradient_prepared_by_the_finest_fpn_conv(monkeypatch):
+    """modals.CHAIN_FPN_LATERAL: the finest 3x3 FPN conv's data gradient also prepares the P2 lateral's gradient
+    (identity through the merge).  Chains work from the second pass on (the first one bootstraps the gradient's
+    scale slot), so two passes per mode; every FPN / backbone gradient of the second pass agrees with the unchained
+    path's, and the chained mode really hands one more gradient over."""
+    from sln_amodal_amd import conv_hip
+    from sln_amodal_amd.modal import modals
+    from sln_amodal_amd.modal.modals import FPN, ResNet
+    torch.manual_seed(0)
+    resnet = ResNet("resnet50", stage5=True)
+    fpn = FPN(*resnet.stages(), out_channels=256).eval()
+    key_init_(fpn)
+    fpn = fpn.cuda()
+    for m in fpn.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            for p in m.parameters():
+                p.requires_grad = False
+    g = torch.Generator(device="cuda").manual_seed(1)
+    x = torch.randn(2, 3, 128, 128, device="cuda", generator=g)
+    ups, grads, used = None, [], []
+    for chained in (False, True):
+        monkeypatch.setattr(modals, "CHAIN_FPN_LATERAL", chained)
+        for _ in range(2):
+            conv_hip.update_scales()
+            for p in fpn.parameters():
+                p.grad = None
+            outs = fpn(x)
+            if ups is None:
+                ups = [torch.randn(o.shape, device="cuda", generator=g) for o in outs]
+            before = conv_hip.CHAIN_STATS[1]
+            sum((o * u).sum() for o, u in zip(outs, ups)).backward()
+        used.append(conv_hip.CHAIN_STATS[1] - before)
+        grads.append({n: p.grad.clone() for n, p in fpn.named_parameters() if p.grad is not None})
+    assert used[1] == used[0] + 1, used
+    assert grads[0].keys() == grads[1].keys() and "P2_conv1.weight" in grads[0]
+    for n in grads[0]:
+        a, b = grads[1][n], grads[0][n]
+        assert (a - b).norm().item() <= 2e-5 * max(b.norm().item(), 1e-12), n
