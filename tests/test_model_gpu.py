@@ -486,3 +486,34 @@ def test_p2_lateral_gradient_prepared_by_the_finest_fpn_conv(monkeypatch):
     for n in grads[0]:
         a, b = grads[1][n], grads[0][n]
         assert (a - b).norm().item() <= 2e-5 * max(b.norm().item(), 1e-12), n
+
+
+def test_mask_head_tail_gradients_with_the_chained_deconv(monkeypatch):
+    """nn_ops.CHAIN_DECONV: the logits conv's data gradient prepares the deconv's gradient (re-viewed [4M, Cout]
+    parts, the bias sum credited to the first of the four bias copies).  Second pass of each mode (chains need a
+    scale history): input, deconv and logits gradients agree with the unchained path's."""
+    from sln_amodal_amd import conv_hip, nn_ops
+    torch.manual_seed(3)
+    deconv = torch.nn.ConvTranspose2d(256, 256, kernel_size=2, stride=2).cuda()
+    conv5 = torch.nn.Conv2d(256, 2, kernel_size=1).cuda()
+    g = torch.Generator(device="cuda").manual_seed(2)
+    feat = torch.randn(24, 256, 16, 16, device="cuda", generator=g).relu_().contiguous(memory_format=torch.channels_last)
+    up = torch.randn(24, 2, 32, 32, device="cuda", generator=g)
+    params = list(deconv.parameters()) + list(conv5.parameters())
+    res, used = [], []
+    for chained in (False, True):
+        monkeypatch.setattr(nn_ops, "CHAIN_DECONV", chained)
+        for _ in range(2):
+            conv_hip.update_scales()
+            for p in params:
+                p.grad = None
+            x = feat.clone().requires_grad_(True)
+            before = conv_hip.CHAIN_STATS[1]
+            z = nn_ops.deconv2x2_relu_conv1x1(x, deconv, conv5)
+            (z * up).sum().backward()
+        used.append(conv_hip.CHAIN_STATS[1] - before)
+        res.append([x.grad.clone()] + [p.grad.clone() for p in params])
+    assert used == [0, 1], used
+    for a, b in zip(res[1], res[0]):
+        assert a.shape == b.shape
+        assert (a - b).norm().item() <= 2e-5 * max(b.norm().item(), 1e-12)
