@@ -935,7 +935,8 @@ class _ConvFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias, bn_scale, bn_shift, residual, relu, stride, dil, pads, link=None,
                 chain_in=None, chain_out=None, owner=None, pair=None, parts_only=False, inbox=None):
         ctx.inbox = None
-        if inbox is not None and stride == (1, 1) and ctx.needs_input_grad[0] and chain_in is None:
+        if inbox is not None and stride == (1, 1) and ctx.needs_input_grad[0] and \
+                (chain_in is None or chain_in.get("soft")):
             ctx.inbox = inbox              # (the plain stride-1 data gradient below is the one that adds it)
             inbox.clear()
             inbox["armed"] = True
@@ -1074,6 +1075,14 @@ class _ConvFn(torch.autograd.Function):
             ch = None                      # only one of the two readers took part: ordinary path
             if gy is None:
                 raise RuntimeError("chained gradient: no gradient arrived for a two-reader activation")
+        if ch is not None and ch.get("soft") and ch.get("consumer") and \
+                not ("gz" in ch and gy is not None and gy.stride() == (0, 0, 0, 0)):
+            # a SOFT chain (an FPN output under the RPN conv): the reader hands the prepared gradient over only when
+            # it knows its data gradient is this activation's WHOLE gradient (the crops' share arrived through its
+            # inbox); otherwise the ordinary gradient arrives here and is prepared as usual
+            for key in ("gz", "gzq", "gbias"):
+                ch.pop(key, None)
+            ch = None
         if ch is not None and ch.get("readers") == 2:
             if gy is not None or "gz" not in ch:
                 raise RuntimeError("chained gradient: a two-reader activation has a third consumer, or "
@@ -1197,10 +1206,15 @@ class _ConvFn(torch.autograd.Function):
                 ci["gz"], ci["gbias"], ci["gu_ref"], ci["gu_version"] = gz_up, gb_up, gx, gx._version
                 ci["gzq"] = ci["gz_slot"].scale if parts == 2 else None
                 CHAIN_STATS[0] += 1
-            elif ctx.chain_in is not None:
+            elif ctx.chain_in is not None and not (ctx.chain_in.get("soft") and
+                                                   (ctx.inbox is None or "g" not in ctx.inbox)):
                 ci = ctx.chain_in
+                # (soft chain: taken only when the other reader's gradient is in the inbox -- then this data
+                # gradient plus that deposit, added as the epilogue's residual, is the producer's whole gradient)
+                extra = ctx.inbox.take() if (ci.get("soft") and ctx.inbox is not None) else None
                 _, gz_up, gb_up = _fwd(gz, N, OH, OW, wt, Ci, KH, KW, (1, 1), dil, dil[0] * (KH - 1) - pt,
-                                       dil[1] * (KW - 1) - pl, H, W, ci["scale"], None, None, False, cin=Co,
+                                       dil[1] * (KW - 1) - pl, H, W, ci["scale"], None,
+                                       _nhwc(extra) if extra is not None else None, False, cin=Co,
                                        out_parts=True,
                                        want_y=False, want_colsum=ci["want_bias"], yslot=ci["gz_slot"],
                                        **mask_kw(mask_x), **qs)

@@ -80,6 +80,7 @@ class CropGradPool(object):
 GATHER_BACKWARD = os.environ.get("SLN_CROP_GATHER", "0") == "1"
 CHAIN_FPN_LATERAL = os.environ.get("SLN_CHAIN_FPN_LATERAL", "1") != "0"      # A/B switch (FPN.forward)
 STEM_POOL_HANDOFF = os.environ.get("SLN_STEM_POOL_HANDOFF", "1") != "0"      # A/B switch (_Stem.forward)
+CHAIN_FPN_OUTPUTS = os.environ.get("SLN_CHAIN_FPN_OUTPUTS", "1") != "0"      # A/B switch (FPN.forward)
 
 
 def _gather_backward(sources, shapes, device):
@@ -347,10 +348,20 @@ class FPN(nn.Module):
         # coarser merged maps have a second reader (the next merge) and stay on the ordinary path.
         ch2 = {"keep_dx": True} if CHAIN_FPN_LATERAL else None
         p2 = nn_ops.upsample2x_add(conv(c2, self.P2_conv1, pair=fan(c2), chain_out=ch2), p3)
+        # P2..P4 are read by the RPN's shared conv and by the heads' crops, nothing else: when the crops' gradient
+        # reaches the RPN conv through its inbox (model.rpn_forward), that conv's data gradient is the map's WHOLE
+        # gradient and prepares it for the 3x3 conv here (SOFT chain: taken only then; P5 also feeds P6)
+        soft = [({"soft": True} if CHAIN_FPN_OUTPUTS else None) for _ in range(3)]
         p5 = conv(p5, self.P5_conv2[1], same=True)
-        p4 = conv(p4, self.P4_conv2[1], same=True)
-        p3 = conv(p3, self.P3_conv2[1], same=True)
-        p2 = conv(p2, self.P2_conv2[1], same=True, chain_in=ch2)
+        p4 = conv(p4, self.P4_conv2[1], same=True, chain_out=soft[2])
+        p3 = conv(p3, self.P3_conv2[1], same=True, chain_out=soft[1])
+        p2 = conv(p2, self.P2_conv2[1], same=True, chain_in=ch2, chain_out=soft[0])
+        for t, c in zip((p2, p3, p4), soft):
+            if c is not None:
+                try:
+                    t._sln_chain = c
+                except Exception:
+                    pass
         p6 = p5[:, :, ::2, ::2]  # MaxPool2d(kernel 1, stride 2) == strided subsample
         p6 = p6.contiguous(memory_format=torch.channels_last)
         return [p2, p3, p4, p5, p6]
@@ -486,14 +497,14 @@ class RPN(nn.Module):
         self.softmax = nn.Softmax(dim=2)
         self.conv_bbox = nn.Conv2d(512, 4 * anchors_per_location, kernel_size=1, stride=1)
 
-    def forward(self, x, grad_inbox=None):
+    def forward(self, x, grad_inbox=None, chain_in=None):
         B = x.shape[0]
         # the shared map has exactly two readers (the two 1x1 heads): whichever data gradient runs second
         # adds the first one, applies the ReLU mask and hands conv_shared its prepared gradient
         ch = {"readers": 2} if CHAIN_TWO_READERS else None
         # (its only readers are the two 1x1 heads and their ReLU mask: no fp32 copy of the 512-channel map)
-        x = nn_ops.conv_bn_act(x, self.conv_shared, relu=True, same=True, chain_out=ch, parts_only=True,
-                               grad_inbox=grad_inbox)
+        x = nn_ops.conv_bn_act(x, self.conv_shared, relu=True, same=True, chain_in=chain_in, chain_out=ch,
+                               parts_only=True, grad_inbox=grad_inbox)
         # NHWC output == the reference's permute(0,2,3,1).contiguous()
         logits = nn_ops.conv_bn_act(x, self.conv_class, chain_in=ch).permute(0, 2, 3, 1).reshape(B, -1, 2)
         probs = self.softmax(logits)

@@ -249,7 +249,9 @@ class MaskRCNN(nn.Module):
             if nn_ops.BACKEND in ("auto", "hip"):
                 self._crop_inboxes = [conv_hip.GradInbox() for _ in range(4)]
         boxes = (self._crop_inboxes or []) + [None] * len(maps)
-        outs = [self.rpn(p, boxes[i]) for i, p in enumerate(maps)]
+        # (with the inbox the RPN conv can also prepare the FPN output conv's gradient: its soft chain, FPN.forward)
+        outs = [self.rpn(p, boxes[i], getattr(p, "_sln_chain", None) if boxes[i] is not None else None)
+                for i, p in enumerate(maps)]
         rpn_class_logits, rpn_class, rpn_bbox = [torch.cat(list(o), dim=1) for o in zip(*outs)]
         return maps, rpn_class_logits, rpn_class, rpn_bbox
 

@@ -436,6 +436,24 @@ def test_crop_gradients_are_added_inside_the_rpn_data_gradient(monkeypatch):
     for n in grads[0]:
         a, b = grads[1][n], grads[0][n]
         assert (a - b).norm().item() <= 2e-5 * max(b.norm().item(), 1e-12), n
+    # P2..P4: with the deposit in its inbox the RPN conv's data gradient is the map's whole gradient and prepares it
+    # for the FPN output conv (modals.CHAIN_FPN_OUTPUTS, a soft chain): three more hand-overs, the same gradients
+    from sln_amodal_amd.modal import modals
+    used = []
+    for chained in (False, True):
+        monkeypatch.setattr(modals, "CHAIN_FPN_OUTPUTS", chained)
+        for p in m.parameters():
+            p.grad = None
+        before = conv_hip.CHAIN_STATS[1]
+        out = m.predict(inp, mode="training", priorities=pr)
+        loss, _ = m.compute_losses(out, batch["rpn_match"], batch["rpn_bbox"])
+        loss.backward()
+        used.append(conv_hip.CHAIN_STATS[1] - before)
+        grads.append({n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None})
+    assert used[1] == used[0] + 3, used
+    for n in grads[-1]:
+        a, b = grads[-1][n], grads[-2][n]
+        assert (a - b).norm().item() <= 2e-5 * max(b.norm().item(), 1e-12), n
     # without the RPN losses the conv that should add the deposit never runs: an error, not a silent loss
     out = m.predict(inp, mode="training", priorities=pr)
     _, parts = m.compute_losses(out, batch["rpn_match"], batch["rpn_bbox"])
