@@ -260,3 +260,48 @@ def test_zoom_index_map_is_scipys():
     m = rng.rand(37, 53, 2, 3) > 0.5
     sc = (128 / 37, 128 / 53)
     assert np.array_equal(scipy.ndimage.zoom(m, zoom=[sc[0], sc[1], 1, 1], order=0), utils.resize_layer(m, sc))
+
+
+def test_grad_inbox_protocol_on_the_host():
+    """conv_hip.GradInbox (host logic, no kernels): a deposit is taken only by an armed, still open box; the
+    consumer closes it; a deposit nobody consumed raises when the backward pass ends."""
+    import pytest
+    import torch
+    from sln_amodal_amd.conv_hip import GradInbox
+
+    box = GradInbox()
+    assert not box.offer(torch.ones(2))                 # not armed: the depositor keeps its gradient
+    box["armed"] = True
+
+    class Deposit(torch.autograd.Function):             # stands for the crops' backward
+        @staticmethod
+        def forward(ctx, x):
+            return x * 2
+
+        @staticmethod
+        def backward(ctx, g):
+            return None if box.offer(g * 2) else g * 2
+
+    class Consume(torch.autograd.Function):             # stands for the conv whose data gradient adds the deposit
+        @staticmethod
+        def forward(ctx, x):
+            return x * 3
+
+        @staticmethod
+        def backward(ctx, g):
+            extra = box.take()
+            return g * 3 + (extra if extra is not None else 0)
+
+    x = torch.ones(2, requires_grad=True)
+    y1 = Consume.apply(x)                                # created first: differentiated last
+    y2 = Deposit.apply(x)
+    (y1.sum() + y2.sum()).backward()
+    assert torch.equal(x.grad, torch.full((2,), 5.0)) and "g" not in box and box.get("closed")
+    assert not box.offer(torch.ones(2))                  # closed: too late
+    # a pass in which the consumer takes no part: loud
+    box.clear()
+    box["armed"] = True
+    x.grad = None
+    with pytest.raises(RuntimeError, match="never consumed"):
+        Deposit.apply(x).sum().backward()
+    assert not GradInbox.pending and "g" not in box
