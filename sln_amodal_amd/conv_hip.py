@@ -1075,8 +1075,13 @@ class _ConvFn(torch.autograd.Function):
             ch = None                      # only one of the two readers took part: ordinary path
             if gy is None:
                 raise RuntimeError("chained gradient: no gradient arrived for a two-reader activation")
-        if ch is not None and ch.get("soft") and ch.get("consumer") and \
-                not ("gz" in ch and gy is not None and gy.stride() == (0, 0, 0, 0)):
+        if ch is not None and ch.get("soft") and ch.get("consumer") and "gz" in ch and \
+                not (gy is not None and gy.stride() == (0, 0, 0, 0)):
+            # the reader consumed the inbox deposit and handed its prepared gradient over, yet something other than
+            # its placeholder arrives: a further reader added to it -- its share is in neither tensor
+            raise RuntimeError("soft chain: the reader handed the prepared gradient over but the activation "
+                               "has another consumer")
+        if ch is not None and ch.get("soft") and ch.get("consumer") and "gz" not in ch:
             # a SOFT chain (an FPN output under the RPN conv): the reader hands the prepared gradient over only when
             # it knows its data gradient is this activation's WHOLE gradient (the crops' share arrived through its
             # inbox); otherwise the ordinary gradient arrives here and is prepared as usual
@@ -1136,11 +1141,18 @@ class _ConvFn(torch.autograd.Function):
         if need_w:
             # the gradient tensor is allocated BEFORE the event below: whatever used its memory before has been
             # queued on this stream by now and is complete when the side stream passes the event
+            rst = _reduce_state(weight.device)
+            sink_used = False
             if DETERMINISTIC_WGRAD and GRAD_SINK is not None and own.is_leaf and \
-                    own.data_ptr() == weight.data_ptr() and tuple(own.shape) == (Co, Ci, KH, KW):
+                    own.data_ptr() == weight.data_ptr() and tuple(own.shape) == (Co, Ci, KH, KW) and \
+                    id(own) not in rst[1] and id(own) not in _side_state(weight.device)[1]:
                 # the parameter's slot of its all-reduce bucket: autograd adopts the view as .grad (no pack /
-                # unpack copies around the collective)
+                # unpack copies around the collective).  Only the weight's FIRST gradient of a pass goes there:
+                # a weight used several times per pass (the RPN convs: five pyramid levels) gets private memory
+                # for the later ones, which autograd adds to the first -- written to the same slot they would
+                # overwrite each other before the sum is formed.
                 gw_t = GRAD_SINK(own, (Co, Ci, KH, KW))
+                sink_used = gw_t is not None
             if gw_t is None:
                 gw_t = torch.empty((Co, Ci, KH, KW) if DETERMINISTIC_WGRAD else (Co, KH, KW, Ci), dtype=torch.float32,
                                    device=weight.device)
@@ -1152,10 +1164,9 @@ class _ConvFn(torch.autograd.Function):
                 ready = torch.cuda.Event()
                 ready.record()                      # gz (and x) are complete here; the data gradient starts below
                 defer = False                       # (the side stream reduces its own gradients at once)
-            rst = _reduce_state(weight.device)
-            if defer:
-                rst[1].add(id(own))
-            if (side is not None or defer) and not (rst[2] or _side_state(weight.device)[2]):
+            if defer or sink_used:
+                rst[1].add(id(own))                 # (marks live until the pass ends: _end_of_backward)
+            if (side is not None or defer or sink_used) and not (rst[2] or _side_state(weight.device)[2]):
                 rst[2] = True
                 torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward)
         if ctx.link_tail is not None and g_res is not None:

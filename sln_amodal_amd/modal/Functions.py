@@ -302,7 +302,8 @@ def refine_detections(rois, probs, deltas, window, config):
 def refine_detections_batched(rois, valid, probs, deltas, window, config, max_instances=100):
     """refine_detections (Functions.py:453-557, USE_NMS = False: the reference default) for B images at once,
     fixed capacity, no host sync: rois [B,R,4] normalised with `valid` [B,R] bool (proposal slots beyond an
-    image's count are not detections), probs [B,R,C], deltas [B,R,C,4], window (y1,x1,y2,x2) pixels.
+    image's count are not detections), probs [B,R,C], deltas [B,R,C,4], window (y1,x1,y2,x2) pixels -- one
+    for all images or [B,4], one per image.
     Per image exactly the reference's choice -- foreground rois, the 100 best scores, descending, ties in roi
     order (its two stable sorts) -- as rows [B,100,(y1,x1,y2,x2,class_id,score)], ZERO rows behind the
     per-image count (unmold_detections stops at the first class id 0, model.py:762-764), and counts [B]."""
@@ -310,8 +311,15 @@ def refine_detections_batched(rois, valid, probs, deltas, window, config, max_in
     class_scores, class_ids = torch.max(probs, dim=2)
     idx = class_ids.unsqueeze(2).unsqueeze(3).expand(B, R, 1, 4)
     deltas_specific = torch.gather(deltas, 2, idx).squeeze(2)
-    refined = coordinate_convert(rois.reshape(-1, 4), deltas_specific.reshape(-1, 4), config)
-    refined = torch.round(clip_to_window(window, refined)).view(B, R, 4)
+    refined = coordinate_convert(rois.reshape(-1, 4), deltas_specific.reshape(-1, 4), config).view(B, R, 4)
+    # every image is clipped to ITS OWN window (the reference runs one image per call, Functions.py:483)
+    win = utils.const_tensor(np.asarray(window, dtype=np.float32).reshape(-1, 4).tolist(), torch.float32, rois.device)
+    if win.shape[0] not in (1, B):
+        raise ValueError("refine_detections_batched: %d windows for %d images" % (win.shape[0], B))
+    win = win.expand(B, 4).unsqueeze(1)                      # [B,1,4]
+    lo = torch.cat((win[..., 0:2], win[..., 0:2]), dim=2)
+    hi = torch.cat((win[..., 2:4], win[..., 2:4]), dim=2)
+    refined = torch.round(torch.minimum(torch.maximum(refined, lo), hi))
     keep = (class_ids > 0) & valid
     if config.DETECTION_MIN_CONFIDENCE and config.USE_NMS:
         keep = keep & (class_scores >= config.DETECTION_MIN_CONFIDENCE)

@@ -348,13 +348,16 @@ class MaskRCNN(nn.Module):
         _, mrcnn_class, mrcnn_bbox = self.classifier(maps, rpn_rois, box_ind)
         nc = mrcnn_class.shape[1]
         _, _, window, _ = parse_image_meta(np.asarray(image_metas))
-        win = [float(v) for v in window[0]]
+        win = np.asarray(window, dtype=np.float32).reshape(-1, 4)      # one window per image
+        if win.shape[0] == 1 and B > 1:
+            win = np.repeat(win, B, axis=0)
         if cfg.USE_NMS:
             dets = []
             for b in range(B):
                 n = int(num_rois[b])
                 d, _ = detection_layer(cfg, rpn_rois[b:b + 1, :n], mrcnn_class.view(B, R, nc)[b, :n],
-                                       mrcnn_bbox.view(B, R, nc, 4)[b, :n], image_metas)
+                                       mrcnn_bbox.view(B, R, nc, 4)[b, :n],
+                                       np.asarray(image_metas)[min(b, len(image_metas) - 1):][:1])
                 row = rpn_rois.new_zeros(R, 6)          # (per-class NMS keeps what survives: no cap)
                 if len(d):
                     row[:d.shape[0]] = d

@@ -1,0 +1,221 @@
+"""Convergence / dynamics tests of the train step, collected LAST (tests/conftest.py FILE_ORDER): they assert that
+the assembled step LEARNS (reference loop: model.py:383-460), not a parity with the oracle -- a red test here must
+not hide the kernel-vs-oracle sweeps from a `-x` run.  Each failure message carries the six losses over the run,
+the clip norm, the optimiser's skipped-step counter and the fp16 saturation counter."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.test_model_gpu import _small_model
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _hip_backend():
+    from sln_amodal_amd import nn_ops
+    old = nn_ops.BACKEND
+    nn_ops.BACKEND = "hip"       # raise instead of silently falling back
+    yield
+    nn_ops.BACKEND = old
+
+
+def _prepared(seed=3):
+    """Model + one fixed batch + fixed sampling priorities, frozen BN calibrated, RPN warm-started."""
+    from sln_amodal_amd import synthetic
+    m, cfg = _small_model()
+    batch = synthetic.make_batch(cfg, 2, 256, 256, seed=seed, anchors_f64=m.anchors_f64)
+    synthetic.calibrate_batchnorm(m, batch["images"])
+    synthetic.calibrate_glm(m, batch["images"])
+    synthetic.warm_start_rpn(m, [batch], iters=40)
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    pr = {"pos": torch.rand(2, 1000, device="cuda", generator=gen),
+          "neg": torch.rand(2, 1000, device="cuda", generator=gen)}
+    return m, cfg, batch, pr
+
+
+def run_fixed_batch(m, batch, pr, steps, lr, report):
+    """`steps` train steps on one batch; returns the report rows (step, total, six losses, clip norm) and the
+    optimiser's skipped-step count."""
+    opt = m.make_optimizer(lr)
+    rows = []
+    for it in range(steps):
+        loss, parts = m.train_step(batch, opt, priorities=pr)
+        if it in report or it == steps - 1:
+            row = {"step": it, "total": float(loss), "norm": float(m.last_grad_norm)}
+            row.update({k: float(v) for k, v in parts.items()})
+            rows.append(row)
+    return rows, (opt.skipped_steps() if hasattr(opt, "skipped_steps") else 0)
+
+
+def _fmt(rows):
+    return "\n".join(str({k: round(v, 4) for k, v in r.items()}) for r in rows)
+
+
+DET = ("rpn_class", "rpn_bbox", "mrcnn_class", "mrcnn_bbox")
+
+
+def test_train_step_learns_one_fixed_batch_like_the_aten_path():
+    """The whole step (HIP conv stack with every backward fusion, losses, clip, SGD) LEARNS one fixed batch, and
+    learns it like the same step on aten fp32 convolutions started from the same weights: 80 steps at lr 0.001
+    (model.py:383-460).
+
+    Why lr 0.001 and a side-by-side run (round-3 post-mortem): at the reference's lr 0.01 the
+    gradient norm of this model is ~480 against the clip of 5.0, so every step is a NORMALISED step of length
+    lr * 5 with momentum 0.9 on top; the warm-started RPN is pushed off its optimum first (rpn_bbox 0.07 -> 0.9 by
+    step 20, total 3.0 -> 3.6..3.9 -- on aten convolutions too, and the reference's own loop does the same on the
+    e2e scene: 4.01 -> 4.98 -> 3.95 -> 6.13) and the run only then descends.  Through that phase the trajectory is
+    chaotic: five runs of the SAME build ended at -0.43, -0.78, -0.75, -1.09, -1.05 (gpurun_out r4_bisect*.log; the
+    fp32 atomics of the RoIAlign scatter differ in the last bit run to run), the driver's -0.16 was one more draw,
+    and none of the eleven A/B switches nor SLN_CONV_PARTS=3 moved the distribution.  At lr 0.001 the run is a
+    descent from step 0 on both backends and the two agree: that is what this test pins."""
+    from sln_amodal_amd import conv_hip, nn_ops
+    m, cfg, batch, pr = _prepared()
+    start = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    hip, skipped = run_fixed_batch(m, batch, pr, 80, 0.001, (0, 20, 40, 79))
+    saturated = conv_hip.saturation_count()
+    m.load_state_dict(start)
+    nn_ops.BACKEND = "torch"
+    try:
+        aten, _ = run_fixed_batch(m, batch, pr, 80, 0.001, (0, 20, 40, 79))
+    finally:
+        nn_ops.BACKEND = "hip"
+    msg = "HIP\n%s\naten\n%s\nskipped=%d saturated=%d" % (_fmt(hip), _fmt(aten), skipped, saturated)
+    print(msg)
+    assert skipped == 0 and saturated == 0, msg
+    assert all(np.isfinite(v) for r in hip for v in r.values()), msg
+    det = lambda r: sum(r[k] for k in DET)
+    # the same start: step 0 is the same forward (each backend on its OWN proposals: a near-tie in the NMS may pick
+    # another roi, so not the 1e-4 of test_loss_parity_hip_conv_vs_aten_conv_same_proposals)
+    assert abs(hip[0]["total"] - aten[0]["total"]) <= 5e-3, msg
+    # it learns: the total and the detector's own four losses fall (observed: total -0.33, both backends)
+    assert hip[-1]["total"] < hip[0]["total"] - 0.2, msg
+    assert det(hip[-1]) < det(hip[0]) - 0.15, msg
+    # ... and like aten: every reported step's total within 0.1, the final losses within 0.05 each
+    for a, b in zip(hip, aten):
+        assert abs(a["total"] - b["total"]) <= 0.1, msg
+    for k in DET + ("layer", "amodal"):
+        assert abs(hip[-1][k] - aten[-1][k]) <= 0.05, (k, msg)
+
+
+def test_train_step_at_the_reference_learning_rate_stays_finite_and_fits_the_masks():
+    """lr 0.01 (the reference's), 80 steps: the chaotic regime described above.  What holds in every run: nothing
+    is skipped or saturated, every loss stays finite, and the two mask losses -- whose gradient does not pass
+    through the clipped-away RPN phase -- fall (0.688 -> 0.52..0.58 in 20 recorded runs)."""
+    from sln_amodal_amd import conv_hip
+    m, cfg, batch, pr = _prepared()
+    rows, skipped = run_fixed_batch(m, batch, pr, 80, 0.01, (0, 20, 40, 79))
+    msg = "%s\nskipped=%d saturated=%d" % (_fmt(rows), skipped, conv_hip.saturation_count())
+    print(msg)
+    assert skipped == 0 and conv_hip.saturation_count() == 0, msg
+    assert all(np.isfinite(v) for r in rows for v in r.values()), msg
+    assert rows[-1]["layer"] < rows[0]["layer"] - 0.03, msg
+    assert rows[-1]["total"] < rows[0]["total"], msg
+
+
+def test_config3_full_size_train_step_resnet101_16x1024():
+    """BASELINE configs[2] at size: ResNet-101 + DeepLab-v2 SLN, 16 x 1024x1024, stage 'all', ONE
+    train step through the product path (the conv kernels' int-index paths: M = 16*256*256 output
+    rows, ~70 GB resident).  Finite losses, every trainable parameter updated, and the three largest
+    layer shapes of the step against aten fp32 at 1e-5 of the output scale."""
+    import torch.nn.functional as F
+    from sln_amodal_amd import nn_ops, synthetic
+    from sln_amodal_amd.config import Config
+    from sln_amodal_amd.model import MaskRCNN
+
+    class C(Config):
+        NAME = "full"
+        IMAGE_MAX_DIM = 1024
+        IMAGE_MIN_DIM = 1024
+        ARCHITECTURE = "resnet101"
+        BATCH_SIZE = 16
+
+    torch.manual_seed(0)
+    cfg = C()
+    m = MaskRCNN(cfg, "/tmp/sln_logs").apply_amodal_heads().cuda()
+    m.set_trainable(".*", exclusive_off=False)
+    for p in m.GLM_modual.parameters():
+        p.requires_grad = False
+    batch = synthetic.make_batch(cfg, 16, 1024, 1024, seed=1234, anchors_f64=m.anchors_f64)
+    synthetic.calibrate_batchnorm(m, batch["images"][:4])
+    synthetic.calibrate_glm(m, batch["images"][:2])
+    synthetic.warm_start_rpn(m, [batch], iters=10)
+    opt = m.make_optimizer(cfg.LEARNING_RATE)
+    before = {n: p.detach().clone() for n, p in m.named_parameters() if p.requires_grad}
+    loss, parts = m.train_step(batch, opt)
+    assert bool(torch.isfinite(loss)) and float(loss) > 0
+    assert all(bool(torch.isfinite(v)) for v in parts.values())
+    assert float(m.last_grad_norm) > 0 and np.isfinite(float(m.last_grad_norm))
+    assert opt.skipped_steps() == 0
+    same = [n for n, p in m.named_parameters() if p.requires_grad and torch.equal(p.detach(), before[n])]
+    assert not same, same[:10]
+    # it really was the full-size step (58 GB with fp32 copies of every activation, 37 GB since the
+    # bottleneck / RPN / mask-head activations are kept as parts only)
+    assert torch.cuda.max_memory_allocated() > 25 * 2 ** 30
+    del before, batch, opt
+    m.zero_grad(set_to_none=True)
+    # ---- the step's largest layer shapes, HIP vs aten fp32 ----
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    shapes = [("C2 3x3 64->64 @256^2", m.fpn.C2[1].conv2, m.fpn.C2[1].bn2, (16, 64, 256, 256), True),
+              ("C2 1x1 64->256 @256^2", m.fpn.C2[1].conv3, m.fpn.C2[1].bn3, (16, 64, 256, 256), False),
+              ("C4 1x1 256->1024 @64^2", m.fpn.C4[3].conv3, m.fpn.C4[3].bn3, (16, 256, 64, 64), False),
+              ("RPN 3x3 256->512 @256^2", m.rpn.conv_shared, None, (16, 256, 256, 256), True)]
+    for name, conv, bn, shape, same in shapes:
+        x = (torch.randn(shape, device="cuda", generator=gen)).contiguous(memory_format=torch.channels_last)
+        with torch.no_grad():
+            nn_ops.BACKEND = "hip"
+            got = nn_ops.conv_bn_act(x, conv, bn, relu=True, same=same)
+            nn_ops.BACKEND = "torch"
+            want = nn_ops.conv_bn_act(x, conv, bn, relu=True, same=same)
+            nn_ops.BACKEND = "hip"
+        err = float((got - want).abs().max()) / max(float(want.abs().max()), 1e-12)
+        assert tuple(got.shape) == tuple(want.shape), name
+        assert err <= 1e-5, (name, err)
+        del x, got, want
+
+
+def test_config5_resnext101_msc_train_step_full_depth():
+    """configs[4] differentiated end to end on the HIP path: ResNeXt-101 (32 groups) + ASPP under the multi-scale
+    wrapper in training mode (logits of every scale + their maximum, modal/msc_deeplab.py:45-46), frozen BN,
+    cross-entropy on all four outputs, 4 x 321^2 images: finite loss, a gradient for every trainable tensor, SGD
+    steps reduce the loss; prints the step time."""
+    import time
+    from sln_amodal_amd import conv_hip
+    from sln_amodal_amd.modal.resnext import DeepLabV2_ResNeXt101_MSC
+    from tests._util import key_init_
+    from tests.test_resnext_cpu import damp_
+    net = DeepLabV2_ResNeXt101_MSC(21)
+    key_init_(net)
+    damp_(net)
+    net = net.cuda().train()
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.eval()
+            m.weight.requires_grad = m.bias.requires_grad = False
+    g = torch.Generator(device="cuda").manual_seed(2)
+    x = torch.randn(4, 3, 321, 321, device="cuda", generator=g).contiguous(memory_format=torch.channels_last)
+    params = [p for p in net.parameters() if p.requires_grad]
+    opt = torch.optim.SGD(params, lr=0.02, momentum=0.9)
+    losses, dt = [], 0.0
+    target = None
+    for it in range(6):
+        conv_hip.update_scales()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        outs = net(x)
+        assert len(outs) == 4 and tuple(outs[0].shape) == (4, 21, 11, 11)
+        if target is None:
+            target = torch.randint(0, 21, (4, 11, 11), device="cuda", generator=g)
+        loss = sum(F.cross_entropy(F.interpolate(o, size=(11, 11), mode="bilinear", align_corners=False), target)
+                   for o in outs)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        if it == 0:
+            assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in params)
+        opt.step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        losses.append(float(loss))
+    assert all(l == l for l in losses) and losses[-1] < losses[0], losses
+    print("ResNeXt-101 MSC train step, 4 x 321^2, three scales: %.1f ms; loss %.3f -> %.3f" % (dt * 1e3, losses[0], losses[-1]))

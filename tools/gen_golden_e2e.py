@@ -13,6 +13,7 @@ used) and turns the checkpoint write into a no-op.  Weights are the name-keyed d
 initialisation of tests/_util.e2e_init_ (regenerated from the keys on the test side, not stored).
 
     python tools/gen_golden_e2e.py --masks   # writes tests/golden/e2e_relu_masks_0.npz only
+    python tools/gen_golden_e2e.py --steps   # writes tests/golden/e2e_multistep_0.npz only (run_multistep)
 
 --masks re-runs scene 0's train step with three more observers: a forward hook on every nn.ReLU of the
 detector (modals.py:276-299, 316, 383, 430, 476) that records the SIGN BITMAP of its output, in call
@@ -148,7 +149,7 @@ MASK_WATCH = WATCH + [
 MASK_SLICE = 8192
 
 
-def main(only_masks=False):
+def main(only_masks=False, multistep=False):
     ref_modals, ref_F = ref_harness.install()
     import scipy.misc
     scipy.misc.imresize = imresize
@@ -182,6 +183,10 @@ def main(only_masks=False):
     if only_masks:
         del model
         run_mask_scene(locals())
+        return
+    if multistep:
+        del model
+        run_multistep(locals())
         return
     rec_opt = {}
 
@@ -480,5 +485,114 @@ def run_mask_scene(env):
          **{"grad/" + n: v for n, v in rec["grad"].items()}, **arrs)
 
 
+def run_multistep(env, steps=5):
+    """Scene 0 through `steps` consecutive optimiser steps of the reference's own loop (train_model with
+    epochs = steps, STEPS_PER_EPOCH = 1: one optimiser, momentum carried over; model.py:356-366, 383-444).  Per
+    step the observers record what the loop consumed (the augmented image / boxes / RPN targets the DataLoader
+    produced, the two randperm draws, the proposals) and what it produced (the six losses, the clip norm, the
+    watched parameter slices after the update) -> tests/golden/e2e_multistep_0.npz.  Step 0 must be the
+    e2e_train_0 fixture, bit for bit (checked)."""
+    ref_model, ref_config, ref_dl, nn = env["ref_model"], env["ref_config"], env["ref_dl"], env["nn"]
+    ref_train, scenes, tmp, loss_names = env["ref_train"], env["scenes"], env["tmp"], env["loss_names"]
+    real = {k: env[k] for k in ("real_loader", "real_randperm", "real_clip", "real_step", "real_save",
+                                "real_predict", "real_losses")}
+    image, label = scenes[0]
+    model, cfg = build_reference_model(ref_model, ref_config, ref_dl, nn)
+    params = dict(model.named_parameters())
+    ds = StubDataset(ref_train, [image], [label], tmp)
+    log = []
+    cur = {}
+
+    def rec_randperm(n, *a, **k):
+        p = real["real_randperm"](n, *a, **k)
+        cur.setdefault("perms", []).append(p.numpy().copy())
+        return p
+
+    real_proposal = ref_model.proposal_layer
+
+    def rec_proposal(*a, **k):
+        r = real_proposal(*a, **k)
+        cur["rpn_rois"] = r.detach().clone().numpy()
+        return r
+
+    def rec_predict(self, input, mode):
+        cur["inputs"] = [t.detach().clone() if torch.is_tensor(t) else np.array(t) for t in input]
+        return real["real_predict"](self, input, mode)
+
+    def rec_clip(parameters, max_norm, *a, **k):
+        total = real["real_clip"](parameters, max_norm, *a, **k)
+        cur["total_norm"] = float(total)
+        return total
+
+    def rec_step(self, *a, **k):
+        r = real["real_step"](self, *a, **k)
+        cur["after"] = grab(params, "data")
+        log.append(dict(cur))
+        cur.clear()
+        return r
+
+    def wrap_loss(name):
+        def f(*a, **k):
+            r = real["real_losses"][name](*a, **k)
+            cur.setdefault("losses", {})[name] = float(r[0] if isinstance(r, tuple) else r)
+            if name == "compute_rpn_class_loss":
+                cur["rpn_match"] = a[0].detach().clone().numpy()
+            if name == "compute_rpn_bbox_loss":
+                cur["rpn_bbox_t"] = a[0].detach().clone().numpy()
+            return r
+        return f
+
+    before = grab(params, "data")
+    seed = 1000
+    random.seed(seed); np.random.seed(seed); torch.manual_seed(seed)
+    torch.randperm = rec_randperm
+    ref_model.proposal_layer = rec_proposal
+    ref_model.MaskRCNN.predict = rec_predict
+    torch.nn.utils.clip_grad_norm_ = rec_clip
+    torch.optim.SGD.step = rec_step
+    torch.save = lambda *a, **k: None
+    torch.utils.data.DataLoader = lambda d, **k: real["real_loader"](d, **dict(k, num_workers=0))
+    for n in loss_names:
+        setattr(ref_model, n, wrap_loss(n))
+    try:
+        model.train_model(ds, ds, 0.01, steps, "all")
+    finally:
+        torch.randperm = real["real_randperm"]
+        ref_model.proposal_layer = real_proposal
+        ref_model.MaskRCNN.predict = real["real_predict"]
+        torch.nn.utils.clip_grad_norm_ = real["real_clip"]
+        torch.optim.SGD.step = real["real_step"]
+        torch.save = real["real_save"]
+        torch.utils.data.DataLoader = real["real_loader"]
+        for n in loss_names:
+            setattr(ref_model, n, real["real_losses"][n])
+    assert len(log) == steps, len(log)
+    molded0 = image.astype(np.float32) - cfg.MEAN_PIXEL
+    arrs = {}
+    for k, st in enumerate(log):
+        images, _metas, gt_class_ids, gt_boxes, gt_layer = st["inputs"]
+        got = images[0].permute(1, 2, 0).numpy()
+        flipped = not np.allclose(got, molded0)
+        if flipped:
+            assert np.allclose(got, molded0[:, ::-1])
+        assert len(st["perms"]) == 3 and len(st["perms"][0]) == 1, [len(p) for p in st["perms"]]
+        losses = np.array([st["losses"][n] for n in loss_names], dtype=np.float64)
+        print("step %d: flipped=%s losses=%s total=%.6f grad norm=%.4f rois=%d" % (
+            k, flipped, np.round(losses, 5).tolist(), losses.sum(), st["total_norm"], st["rpn_rois"].shape[1]))
+        arrs.update({"s%d/flipped" % k: np.array(flipped), "s%d/gt_boxes" % k: gt_boxes.numpy(),
+                     "s%d/gt_class_ids" % k: gt_class_ids.numpy(), "s%d/rpn_match" % k: st["rpn_match"],
+                     "s%d/rpn_bbox_target" % k: st["rpn_bbox_t"], "s%d/perm_pos" % k: st["perms"][1],
+                     "s%d/perm_neg" % k: st["perms"][2], "s%d/rpn_rois" % k: st["rpn_rois"],
+                     "s%d/losses" % k: losses, "s%d/total_norm" % k: np.array(st["total_norm"])})
+        arrs.update({"s%d/after/%s" % (k, n): v for n, v in st["after"].items()})
+    base = np.load(os.path.join(ROOT, "tests", "golden", "e2e_train_0.npz"))
+    assert np.array_equal(arrs["s0/losses"], base["losses"]), (arrs["s0/losses"], base["losses"])
+    for n in WATCH:
+        assert np.array_equal(arrs["s0/after/" + n], base["after/" + n]), n
+    save("e2e_multistep_0", native=np.array("oracle"), dim=np.array(DIM), lr=np.array(0.01), steps=np.array(steps),
+         image_u8=image, label=label, loss_names=np.array(loss_names), names=np.array(WATCH),
+         **{"before/" + n: v for n, v in before.items()}, **arrs)
+
+
 if __name__ == "__main__":
-    main(only_masks="--masks" in sys.argv)
+    main(only_masks="--masks" in sys.argv, multistep="--steps" in sys.argv)
