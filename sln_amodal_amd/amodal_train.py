@@ -186,7 +186,7 @@ def build_coco_results(dataset, image_ids, rois, class_ids, scores, masks):
     return results
 
 
-def main(argv=None):
+def parse_args(argv=None):
     ap = argparse.ArgumentParser(description="Train / evaluate SLN-Amodal on MI355X.")
     ap.add_argument("command", metavar="<command>", help="'train' or 'evaluate'")
     ap.add_argument("--dataset", default=None, metavar="/path/to/dataset/")
@@ -199,12 +199,17 @@ def main(argv=None):
     ap.add_argument("--image-dim", default=1024, type=int)
     ap.add_argument("--batch", default=None, type=int, help="images per GPU")
     ap.add_argument("--steps-per-epoch", default=None, type=int)
-    args = ap.parse_args(argv)
+    return ap.parse_args(argv)
 
-    rank, local, world = parallel.init_distributed()
-    device = torch.device("cuda", local)
-    torch.cuda.set_device(local)
 
+def build_run(args):
+    """Everything of a run that needs no GPU -- the reference's plumbing around the hot path
+    (amodal_train.py:560-640): the command's config class with the CLI overrides, the model with the
+    head surgery, the checkpoints that exist, GLM frozen.  Returns (config, model, model_path); the model
+    is still on the host.  BASELINE.json configs[0] (`evaluate`, ResNet-50, 2 x 512^2) exercises exactly
+    this on CPU in tests/test_model_cpu.py; main() then needs the MI355X."""
+    if args.command not in ("train", "evaluate"):
+        raise SystemExit("'{}' is not recognized. Use 'train' or 'evaluate'".format(args.command))
     base = Amodalfig if args.command == "train" else InferenceConfig
 
     class RunConfig(base):
@@ -217,7 +222,7 @@ def main(argv=None):
         config.BATCH_SIZE = args.batch
     if args.steps_per_epoch:
         config.STEPS_PER_EPOCH = args.steps_per_epoch
-    if rank == 0:
+    if int(os.environ.get("RANK", "0")) == 0:
         config.display()
     torch.manual_seed(0)
     model = MaskRCNN(config=config, model_dir=args.logs)
@@ -231,9 +236,23 @@ def main(argv=None):
         model.GLM_modual.load_state_dict(torch.load(GLM_MODEL_PATH, map_location="cpu"))
     if args.command != "train" and model_path and model_path.lower() != "none":
         model.load_weights(model_path)
-    model.to(device)
     for p in model.GLM_modual.parameters():
         p.requires_grad = False
+    return config, model, model_path
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    config, model, model_path = build_run(args)
+    if not torch.cuda.is_available():
+        raise RuntimeError("amodal_train %s: the run itself needs an MI355X -- sln_amodal_amd has no CPU path "
+                           "(NMS, RoIAlign, the conv stacks and the inference tail live in "
+                           "libsln_amodal_hip.so); the plumbing up to here (config, model, checkpoints) ran" %
+                           args.command)
+    rank, local, world = parallel.init_distributed()
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(local)
+    model.to(device)
     data = AmodalDataset(config, model, None if args.synthetic else args.dataset, args.limit,
                          seed=1234 + rank, device=device, rank=rank, world=world)
 
@@ -280,8 +299,6 @@ def main(argv=None):
                 n += 1
             if n >= limit:
                 break
-    else:
-        raise SystemExit("'{}' is not recognized. Use 'train' or 'evaluate'".format(args.command))
 
 
 if __name__ == "__main__":

@@ -82,8 +82,12 @@ __global__ __launch_bounds__(OPT_THREADS) void sgd_clip_kernel(float *const *__r
                                                                int32_t *__restrict__ skipped) {
     const int t = threadIdx.x;
     // A non-finite gradient norm (an inf / NaN anywhere in the step's gradients) skips the whole update --
-    // weights and momentum buffers untouched, counted on the device -- the way the reference's loop
-    // `continue`s past a batch it cannot use (model.py:416-418, 433-434); no host round trip decides it.
+    // weights and momentum buffers untouched, counted on the device; no host round trip decides it.  This is a
+    // GUARD OF THIS BUILD, not reference behaviour: the reference would apply the NaN (its `continue`s at
+    // model.py:416-418, 433-434 skip batches without ground truth, not non-finite gradients).  The count is
+    // therefore surfaced everywhere a step is driven -- ClippedSGD.skipped_steps(), asserted zero by the GPU
+    // training tests and by bench.py, logged per epoch by MaskRCNN.train_epoch -- so that a kernel bug which
+    // produces a NaN gradient reads as an error, not as slow learning.
     const double sq = sqnorm[0];
     if (!(sq >= 0.0 && sq < INFINITY)) {
         if (skipped && blockIdx.x == 0 && t == 0) atomicAdd(skipped, 1);

@@ -478,9 +478,10 @@ class MaskRCNN(nn.Module):
           * fp16 x 2 operand blocks that had to clamp a value to +-65504 (conv_hip.saturation_count():
             the clamped tensor's scale follows its new maximum from the next step on -- the amax is taken
             before the clamp -- so the count says how many blocks of how many steps ran under-estimated);
-          * optimiser steps skipped on the device for a non-finite gradient norm (ClippedSGD.skipped_steps():
-            the reference's loop `continue`s past batches it cannot use, model.py:416-418, 433-434).  The
-            loss of such a step is left out of the epoch mean instead of turning it into NaN.
+          * optimiser steps skipped on the device for a non-finite gradient norm (ClippedSGD.skipped_steps();
+            a guard of this build -- the reference would apply the NaN: its `continue`s, model.py:416-418,
+            433-434, skip batches without ground truth).  The loss of such a step is left out of the epoch
+            mean instead of turning it into NaN, and the count is logged as an ERROR line.
         Both are logged and kept in `self.epoch_health`."""
         dev = self.anchors.device
         loss_sum = torch.zeros((), device=dev)
@@ -507,6 +508,9 @@ class MaskRCNN(nn.Module):
         if conv_hip is not None:
             conv_hip.check_ranks()
         self.epoch_health = health
+        if health["skipped_optimizer_steps"]:
+            log("ERROR: {} of {} optimiser steps were skipped for a non-finite gradient norm".format(
+                health["skipped_optimizer_steps"], step))
         if health["non_finite_losses"] or health["conv_saturated_blocks"] or health["skipped_optimizer_steps"]:
             log("epoch health: {}".format(health))
         return mean

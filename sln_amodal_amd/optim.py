@@ -58,7 +58,7 @@ class ClippedSGD(object):
 
     def skipped_steps(self):
         """Steps whose update was skipped on the device because the gradient norm was inf / NaN (host sync)."""
-        return int(self.skipped.item()) if self.skipped is not None else 0
+        return (int(self.skipped.item()) if self.skipped is not None else 0) + getattr(self, "_skipped_loaded", 0)
 
     def state_dict(self):
         """Momentum buffers by position in the flattened parameter groups + the groups' hyper-parameters
@@ -72,7 +72,7 @@ class ClippedSGD(object):
             k += len(g["params"])
             groups.append(d)
         return {"state": {idx[id(p)]: {"momentum_buffer": b} for p, b in self.state.items() if id(p) in idx},
-                "param_groups": groups}
+                "param_groups": groups, "skipped_steps": self.skipped_steps()}
 
     def load_state_dict(self, sd):
         flat = [p for g in self.param_groups for p in g["params"]]
@@ -83,6 +83,7 @@ class ClippedSGD(object):
                 raise ValueError("loaded state dict contains a parameter group of a different size")
             g.update({key: v for key, v in d.items() if key != "params"})
         self.state = {}
+        self._skipped_loaded = int(sd.get("skipped_steps", 0))     # (added to the device counter's value)
         with torch.no_grad():
             for i, st in sd["state"].items():
                 p = flat[int(i)]

@@ -305,3 +305,45 @@ def test_grad_inbox_protocol_on_the_host():
     with pytest.raises(RuntimeError, match="never consumed"):
         Deposit.apply(x).sum().backward()
     assert not GradInbox.pending and "g" not in box
+
+
+def test_cli_evaluate_plumbing_runs_on_the_host_and_refuses_to_compute_there(tmp_path, capsys):
+    """BASELINE.json configs[0]: `amodal_train.py evaluate`, ResNet-50, 2 synthetic 512 x 512 images -- the
+    CPU-runnable plumbing of the reference (amodal_train.py:560-640, 667-671): argument surface, InferenceConfig
+    with the CLI overrides, model construction + head surgery, a checkpoint written in the reference's layout and
+    loaded back through --model.  The run itself must then fail LOUDLY on a host without a GPU (no CPU fallback
+    of the hot path exists); tests/test_model_gpu.py::test_cli_evaluate_synthetic_runs is the same command on
+    the MI355X."""
+    import torch
+    from sln_amodal_amd import amodal_train
+    argv = ["evaluate", "--synthetic", "--arch", "resnet50", "--image-dim", "512", "--limit", "2",
+            "--logs", str(tmp_path)]
+    args = amodal_train.parse_args(argv)
+    assert (args.command, args.synthetic, args.arch, args.image_dim, args.limit) == \
+        ("evaluate", True, "resnet50", 512, 2)
+    cfg, model, path = amodal_train.build_run(args)
+    assert "IMAGE_MAX_DIM" in capsys.readouterr().out            # config.display(), like the reference
+    assert isinstance(cfg, amodal_train.InferenceConfig)
+    assert (cfg.BATCH_SIZE, cfg.IMAGES_PER_GPU, cfg.DETECTION_MIN_CONFIDENCE) == (1, 1, 0)
+    assert tuple(cfg.IMAGE_SHAPE) == (512, 512, 3) and cfg.ARCHITECTURE == "resnet50"
+    assert cfg.BACKBONE_SHAPES.tolist() == [[128, 128], [64, 64], [32, 32], [16, 16], [8, 8]]
+    assert model.anchors.shape == (3 * (128 ** 2 + 64 ** 2 + 32 ** 2 + 16 ** 2 + 8 ** 2), 4)
+    # head surgery (amodal_train.py:606-613): 439-channel mask input, 1 + 1 classes
+    assert tuple(model.mask.conv1.weight.shape) == (256, 439, 3, 3)
+    assert model.classifier.linear_class.out_features == 2 and model.classifier.linear_bbox.out_features == 8
+    assert len(model.fpn.C4) == 6                                # ResNet-50
+    assert not any(p.requires_grad for p in model.GLM_modual.parameters())
+    # --model PATH: a checkpoint in the reference's layout goes through load_weights on the host
+    ck = str(tmp_path / "mask_rcnn_t_0001.pth")
+    sd = model.state_dict()
+    torch.save(sd, ck)
+    key = "mask.conv5.bias"
+    with torch.no_grad():
+        sd[key].add_(1.0)
+    _, model2, path2 = amodal_train.build_run(amodal_train.parse_args(argv + ["--model", ck]))
+    assert path2 == ck and torch.equal(model2.state_dict()[key] + 1.0, sd[key])
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="needs an MI355X"):
+            amodal_train.main(argv)
+    with pytest.raises(SystemExit):
+        amodal_train.build_run(amodal_train.parse_args(["frobnicate"]))
