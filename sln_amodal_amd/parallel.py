@@ -16,8 +16,11 @@ import torch
 import torch.distributed as dist
 
 
-def init_distributed(backend=None):
-    """Initialise from torchrun's env (RANK, WORLD_SIZE, LOCAL_RANK, MASTER_*)."""
+def init_distributed(backend=None, timeout_s=None):
+    """Initialise from torchrun's env (RANK, WORLD_SIZE, LOCAL_RANK, MASTER_*).  timeout_s (or SLN_DIST_TIMEOUT_S;
+    default 1800): how long a collective may wait for a peer before the process group aborts it -- a rank that
+    died (its backward raised, it ran out of memory) must take its peers down with an error, not leave them
+    waiting: the launcher (torchrun / bench.py) then sees non-zero exit codes and can start afresh."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -30,7 +33,10 @@ def init_distributed(backend=None):
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        import datetime
+        tmo = float(timeout_s if timeout_s is not None else os.environ.get("SLN_DIST_TIMEOUT_S", "1800"))
+        dist.init_process_group(backend=backend, rank=rank, world_size=world,
+                                timeout=datetime.timedelta(seconds=tmo))
     return rank, local, world
 
 
@@ -89,6 +95,9 @@ class GradientAllReducer(object):
         self._next = 0          # collectives are issued strictly in bucket order on every rank
         self._hooks = []
         self.stats = {"in_place_bytes": 0, "copied_bytes": 0, "copied_tensors": 0}
+        # the order in which this pass's collectives were issued, and (kept until the next finish()) the previous
+        # pass's: must be the same sequence on every rank -- 0, 1, 2, ... -- whatever order the gradients arrived in
+        self.trace, self.last_trace = [], []
 
     # ------------------------------------------------------------------ slots
     def _storage(self, bi):
@@ -178,6 +187,7 @@ class GradientAllReducer(object):
                 torch._foreach_zero_(missing)
             if dst:
                 torch._foreach_copy_(dst, src)       # one multi-tensor launch (layout conversion included)
+        self.trace.append(bi)
         self._work[bi] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
 
     def finish(self):
@@ -196,6 +206,7 @@ class GradientAllReducer(object):
             self._work[bi] = None
         self._pending = [len(b) for b in self.buckets]
         self._next = 0
+        self.last_trace, self.trace = self.trace, []
 
     def __call__(self, params=None):
         self.finish()

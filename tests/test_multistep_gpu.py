@@ -137,8 +137,8 @@ def test_ten_steps_hip_convolutions_against_aten_convolutions():
     system amplifies any such difference through ReLU switches step over step (the control shows by how much), so
     the HIP replica is held to the CONTROL's behaviour, per parameter group and step: update cosine no more than
     0.005 below the control's, weight drift from the aten replica at most 1.5 x the control's (+ 1e-4); the six
-    losses within 1e-3 of aten's over the first four steps, afterwards within 5 x the control's largest loss
-    difference so far.  Measured (profiles/r4_*_gpu_suite.log): HIP and control are indistinguishable -- drift
+    losses within 1e-3 of aten's over the first four steps, afterwards within max(5e-3, 5 x the control's largest
+    loss difference so far).  Measured (profiles/r4_*_gpu_suite.log): HIP and control are indistinguishable -- drift
     ratios 0.99 .. 1.22 over all groups and steps, cosines equal to three digits (step 9: 0.9692 / 0.9679)."""
     from sln_amodal_amd import conv_hip, nn_ops
     sat0 = conv_hip.saturation_count()
@@ -182,7 +182,7 @@ def test_ten_steps_hip_convolutions_against_aten_convolutions():
                           max(cdrift.values()), drift[worst] / (cdrift[worst] + 1e-12), worst))
         print(report[-1])
         dc_max = max(dc_max, dc)
-        if dl > (1e-3 if k < 4 else max(1e-3, 5 * dc_max)):
+        if dl > (1e-3 if k < 4 else max(5e-3, 5 * dc_max)):
             bad.append("step %d losses" % k)
         if any(cos[grp] < ccos[grp] - 0.005 for grp in GROUPS):
             bad.append("step %d cosine" % k)

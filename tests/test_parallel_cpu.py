@@ -52,10 +52,10 @@ def _worker(rank, world, port, hooks, out):
         red.attach()
     opt = torch.optim.SGD(params, lr=0.1)
     g = torch.Generator().manual_seed(rank)             # disjoint data shards
-    for step in range(3):
+    for step in range(5):
         x = torch.randn(4, 7, generator=g)
         opt.zero_grad(set_to_none=True)
-        if step == 1 and rank == 1:
+        if step in (1, 2) and rank == 1:     # two consecutive steps (a rank whose shard has no positive rois)
             # this rank's loss does not reach model[2]: its gradients never arrive HERE but do on rank 0
             # (a rank without positive rois); the collectives must still be issued in the same order
             model[1](model[0](x)).square().mean().backward()
@@ -63,6 +63,12 @@ def _worker(rank, world, port, hooks, out):
             model[2](model[1](model[0](x))).square().mean().backward()
         local = [p.grad.clone() if p.grad is not None else torch.zeros_like(p) for p in params]
         red.finish() if hooks else red(params)
+        # the recorded launch order of this pass: bucket 0, 1, 2 on EVERY rank, also on the rank whose first
+        # bucket's gradients never arrived (its hooks fired for bucket 1 first)
+        tr = torch.tensor(red.last_trace, dtype=torch.int64)
+        traces = [torch.zeros_like(tr) for _ in range(world)]
+        dist.all_gather(traces, tr)
+        assert all(t_.tolist() == [0, 1, 2] for t_ in traces), (rank, step, [t_.tolist() for t_ in traces])
         gathered = [torch.zeros_like(torch.cat([l.reshape(-1) for l in local])) for _ in range(world)]
         dist.all_gather(gathered, torch.cat([l.reshape(-1) for l in local]))
         mean = sum(gathered) / world
@@ -108,3 +114,78 @@ def test_bench_refuses_a_gpu_count_it_cannot_give():
     assert r.returncode != 0
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert "--gpus 2 requested" in r.stderr
+
+
+def _failing_worker(rank, world, port, out):
+    """Rank 1's backward raises in the middle of the pass (after its first bucket went out)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from sln_amodal_amd import parallel
+    parallel.init_distributed(backend="gloo", timeout_s=20)
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(7, 13), torch.nn.ReLU(), torch.nn.Linear(13, 3))
+    params = list(model[0].parameters()) + list(model[2].parameters())
+    red = parallel.GradientAllReducer(params, bucket_bytes=64).attach()
+    assert len(red.buckets) >= 2
+
+    class Boom(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x.clone()
+
+        @staticmethod
+        def backward(ctx, g):
+            if rank == 1:
+                raise RuntimeError("injected failure in rank 1's backward")
+            return g
+
+    x = torch.randn(4, 7)
+    h = Boom.apply(model[1](model[0](x)))          # model[2]'s gradients (bucket 0) are out before this node runs
+    model[2](h).square().mean().backward()
+    red.finish()
+    out.put(rank)                                   # never reached by rank 1; rank 0 must not get here either
+
+
+def _healthy_pair(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from sln_amodal_amd import parallel
+    parallel.init_distributed(backend="gloo", timeout_s=60)
+    t = torch.full((3,), float(rank + 1))
+    dist.all_reduce(t)
+    assert t.tolist() == [3.0, 3.0, 3.0]
+    dist.destroy_process_group()
+    out.put(rank)
+
+
+def test_a_rank_that_raises_mid_backward_takes_its_peer_down_and_the_job_can_restart():
+    """No hang: rank 1 dies with its exception, rank 0 -- waiting in the collective of a bucket rank 1 never
+    launched -- is released with an error by the process group (peer gone / timeout_s) and exits non-zero, both
+    well inside the limit; a fresh pair on a new port then runs normally (what torchrun's restart does)."""
+    import time
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_failing_worker, args=(r, 2, port, q)) for r in range(2)]
+    t0 = time.time()
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(max(1.0, 90 - (time.time() - t0)))
+    hung = [p.is_alive() for p in procs]
+    for p in procs:
+        if p.is_alive():
+            p.terminate()
+            p.join(10)
+    assert hung == [False, False], "a rank was still waiting after 90 s"
+    assert all(p.exitcode not in (0, None) for p in procs), [p.exitcode for p in procs]
+    assert q.empty()
+    q2 = ctx.Queue()
+    port = _free_port()
+    again = [ctx.Process(target=_healthy_pair, args=(r, 2, port, q2)) for r in range(2)]
+    for p in again:
+        p.start()
+    for p in again:
+        p.join(120)
+    assert [p.exitcode for p in again] == [0, 0]
+    assert sorted(q2.get(timeout=5) for _ in range(2)) == [0, 1]

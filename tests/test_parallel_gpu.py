@@ -49,7 +49,39 @@ def _worker(rank, world, port, out):
     synthetic.warm_start_rpn(m, [batch], iters=10)
     parallel.broadcast_parameters(m)                   # ... replaced by rank 0's here
     opt = m.make_optimizer(0.01)
-    red = parallel.GradientAllReducer([p for p in m.parameters() if p.requires_grad]).attach()
+    # ---- gradients through the bucket-slot sink == the mean of the ranks' plain gradients, also for weights used
+    # several times per pass (rpn.conv_shared / conv_class / conv_bbox run on five pyramid levels: five weight
+    # gradients that autograd sums -- only the FIRST may be written into the slot) ----
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    pr = {"pos": torch.rand(2, 1000, device="cuda", generator=gen), "neg": torch.rand(2, 1000, device="cuda", generator=gen)}
+    inp = [batch["images"], None, batch["gt_class_ids"], batch["gt_boxes"], batch["gt_layer"]]
+    named = [(n, p) for n, p in m.named_parameters() if p.requires_grad]
+
+    def backward_once():
+        m.zero_grad(set_to_none=True)
+        o = m.predict(inp, mode="training", priorities=pr)
+        loss, _ = m.compute_losses(o, batch["rpn_match"], batch["rpn_bbox"])
+        loss.backward()
+
+    backward_once()                                    # no reducer, no sink: this rank's plain gradients
+    plain = {n: (p.grad.detach().clone() if p.grad is not None else torch.zeros_like(p)) for n, p in named}
+    for n in plain:
+        dist.all_reduce(plain[n])
+        plain[n] /= world
+    red = parallel.GradientAllReducer([p for _, p in named]).attach()
+    backward_once()
+    red.finish()
+    worst = ("", 0.0)
+    for n, p in named:
+        err = float((p.grad - plain[n]).norm() / plain[n].norm().clamp_min(1e-20))
+        if err > worst[1]:
+            worst = (n, err)
+        # (the RoIAlign scatter's fp32 atomics differ in the last bit from pass to pass: not bit-equal)
+        assert err <= 1e-4, (rank, n, err)
+    print("rank", rank, "sink vs plain mean: worst relative error %.2e (%s)" % (worst[1], worst[0]), flush=True)
+    for n in ("rpn.conv_shared.weight", "rpn.conv_class.weight", "rpn.conv_bbox.weight"):
+        assert float(dict(named)[n].grad.norm()) > 0
+    m.zero_grad(set_to_none=True)
     for _ in range(3):
         loss, _parts = m.train_step(batch, opt, lambda params: red.finish())
     assert bool(torch.isfinite(loss))
@@ -60,11 +92,11 @@ def _worker(rank, world, port, out):
     total = st["in_place_bytes"] + st["copied_bytes"]
     print("rank", rank, "gradient bytes in place %d, copied %d in %d tensors" %
           (st["in_place_bytes"], st["copied_bytes"], st["copied_tensors"]), flush=True)
-    assert total == 3 * sum(p.numel() * 4 for p in red.params)
+    assert total == 4 * sum(p.numel() * 4 for p in red.params)      # (the check above + three steps)
     # (what is copied: the biases, and the three weights whose gradient is produced in another layout and
     # re-laid by autograd -- the classifier's whole-window 7x7 "FC" conv, 51 MB of this model's 180 MB, the
     # 2x2 deconv and the 3-channel stem)
-    assert st["in_place_bytes"] >= 0.65 * total and st["copied_tensors"] <= 3 * 90, st
+    assert st["in_place_bytes"] >= 0.65 * total and st["copied_tensors"] <= 4 * 95, st
     for p in red.params:
         assert p.grad is None or p.grad.data_ptr() == red.slot_view(p).data_ptr()
     flat = torch.cat([p.detach().reshape(-1).double() for p in m.parameters()] +
