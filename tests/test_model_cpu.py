@@ -347,3 +347,35 @@ def test_cli_evaluate_plumbing_runs_on_the_host_and_refuses_to_compute_there(tmp
             amodal_train.main(argv)
     with pytest.raises(SystemExit):
         amodal_train.build_run(amodal_train.parse_args(["frobnicate"]))
+
+
+def test_batched_refine_detections_clips_every_image_to_its_own_window():
+    """refine_detections_batched with one window per image == the batch-1 refine_detections of each image with
+    its window (Functions.py:453-557: the reference runs one image per call); a portrait and a landscape window
+    in one batch."""
+    from sln_amodal_amd.config import Config
+    from sln_amodal_amd.modal import Functions as F
+    cfg = Config()
+    B, R, C = 2, 60, 2
+    g = torch.Generator().manual_seed(0)
+    tl = torch.rand(B, R, 2, generator=g) * 0.6
+    rois = torch.cat([tl, tl + 0.05 + torch.rand(B, R, 2, generator=g) * 0.35], 2)
+    probs = torch.softmax(torch.randn(B, R, C, generator=g), 2)
+    deltas = torch.randn(B, R, C, 4, generator=g) * 0.3
+    valid = torch.ones(B, R, dtype=torch.bool)
+    valid[1, 50:] = False
+    wins = [[0, 128, 1024, 896], [192, 0, 832, 1024]]
+    det, live, count = F.refine_detections_batched(rois, valid, probs, deltas, wins, cfg)
+    clipped = 0
+    for b in range(B):
+        n = int(valid[b].sum())
+        want, _ = F.refine_detections(rois[b, :n], probs[b, :n], deltas[b, :n], wins[b], cfg)
+        assert int(count[b]) == want.shape[0] and torch.equal(det[b, :want.shape[0]], want)
+        assert not bool(det[b, want.shape[0]:].any()) and int(live[b].sum()) == want.shape[0]
+        y1, x1, y2, x2 = wins[b]
+        assert float(want[:, 0].min()) >= y1 and float(want[:, 2].max()) <= y2
+        assert float(want[:, 1].min()) >= x1 and float(want[:, 3].max()) <= x2
+        clipped += int(((want[:, 0] == y1) | (want[:, 1] == x1) | (want[:, 2] == y2) | (want[:, 3] == x2)).sum())
+    assert clipped > 0                       # the windows do clip something: image 0's window on image 1 would differ
+    one, _, _ = F.refine_detections_batched(rois, valid, probs, deltas, wins[0], cfg)
+    assert not torch.equal(one[1], det[1])

@@ -1,10 +1,24 @@
 #!/bin/bash
 # Everything profiles/ holds for one revision, in one gpurun call (from the repo root on the GPU box):
 #   tools/collect_evidence.sh <tag>
+# The GPU suite runs FIRST, without -x, into <tag>_gpu_suite.log; on a red run nothing else is produced (no
+# *_bench_n1.json: a number measured on a revision whose tests fail is not evidence).  SKIP_SUITE=1 only for a
+# revision whose suite log of the SAME tree already exists next to it.
 set -u
-tag=${1:-r3}
+tag=${1:-r4}
 root=$(pwd)
 out=$root/gpurun_out
+mkdir -p $out
+if [ "${SKIP_SUITE:-0}" != "1" ]; then
+    python3 -m pytest tests -m gpu -q > $out/${tag}_gpu_suite.log 2>&1
+    rc=$?
+    tail -3 $out/${tag}_gpu_suite.log
+    if [ $rc -ne 0 ]; then
+        echo "collect_evidence: GPU suite rc=$rc -- refusing to write ${tag}_bench_n1.json"
+        grep -E "^(FAILED|ERROR)" $out/${tag}_gpu_suite.log | head -20
+        exit 1
+    fi
+fi
 python3 bench.py > $out/${tag}_bench_n1.json 2> $out/${tag}_bench_n1.err
 ms=$(python3 -c "import json;print(json.load(open('$out/${tag}_bench_n1.json'))['ms_per_step'])")
 cd /tmp && export TMPDIR=/tmp
