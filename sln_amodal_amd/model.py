@@ -35,6 +35,13 @@ FUSED_GLM_TAIL = os.environ.get("SLN_FUSED_GLM_TAIL", "1") != "0"
 # the crops' gradient w.r.t. P2..P5 added inside the RPN conv's data gradient (rpn_forward); "0": A/B switch
 FUSE_CROP_GRADS = os.environ.get("SLN_FUSE_CROP_GRADS", "1") != "0"
 
+# the frozen GLM (52 % of the forward FLOPs, independent of the detector until the mask head crops its output) on a
+# second stream next to the backbone / FPN / RPN forward: both are sequences of whole-CU convolution launches, so
+# the gain is the other branch's tail rounds filled and a memory-bound launch running next to a matrix-bound one.
+# "1" enables it (measured in DESIGN.md section 13); off by default: every kernel's own duration stretches when it
+# shares the chip, which the per-kernel roofline of bench.py would read as a slower kernel.
+GLM_STREAM = os.environ.get("SLN_GLM_STREAM", "0") == "1"
+
 LAYER_REGEX = {
     "new": r"(fpn.C1.*)|(classifier.*)|(mask.*)|(layer_decoder.*)|(rpn.*)",
     "rpn": r"(fpn.C3.*)|(fpn.C4.*)|(fpn.C5.*)|(fpn.P5\_.*)|(fpn.P4\_.*)|(fpn.P3\_.*)|(fpn.P2\_.*)|(rpn.*)",
@@ -269,7 +276,18 @@ class MaskRCNN(nn.Module):
             # lockstep: a detect() / validation pass may run on one rank alone)
             conv_hip.update_scales(sync=(mode == "training" and torch.is_grad_enabled()))
         B, _, H, W = molded_images.shape
-        probs, gloable_lab = self.glm_probs(molded_images)
+        glm_side = None
+        if GLM_STREAM and molded_images.is_cuda:
+            main = torch.cuda.current_stream(molded_images.device)
+            glm_side = getattr(self, "_glm_stream", None)
+            if glm_side is None:
+                glm_side = self._glm_stream = torch.cuda.Stream(device=molded_images.device)
+            glm_side.wait_stream(main)               # (the operand scales' update and the images are complete)
+            with torch.cuda.stream(glm_side):
+                probs, gloable_lab = self.glm_probs(molded_images)
+            molded_images.record_stream(glm_side)
+        else:
+            probs, gloable_lab = self.glm_probs(molded_images)
         maps, rpn_class_logits, rpn_class, rpn_bbox = self.rpn_forward(molded_images)
         mrcnn_feature_maps = maps[:4]
         count = cfg.POST_NMS_ROIS_TRAINING if mode == "training" else cfg.POST_NMS_ROIS_INFERENCE
@@ -280,6 +298,10 @@ class MaskRCNN(nn.Module):
                                                 nms_threshold=cfg.RPN_NMS_THRESHOLD,
                                                 anchors=self.anchors, config=cfg, return_counts=True)
         scale = utils.const_tensor([H, W, H, W], torch.float32, molded_images.device)
+        if glm_side is not None:                     # first readers of the GLM's outputs follow
+            main.wait_stream(glm_side)
+            probs.record_stream(main)
+            gloable_lab.record_stream(main)
 
         if mode == "inference":
             return self._predict_inference(rpn_rois, num_rois, mrcnn_feature_maps, probs,

@@ -130,16 +130,30 @@ def _compare(pa, pb, wa0, wb0, names):
     return cos, drift
 
 
+CONTROL_EPS = 2.0 ** -19
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm())
+
+
 def test_ten_steps_hip_convolutions_against_aten_convolutions():
     """Same weights, same batches, same recorded draws and proposals, lr 0.002, 10 optimiser steps on three replicas
-    in one process: HIP conv stack, aten fp32 convolutions, and a CONTROL -- aten again, started from weights
-    perturbed by one part in 2^22 (the rounding of the HIP path's two-fp16-part operands).  The
-    system amplifies any such difference through ReLU switches step over step (the control shows by how much), so
-    the HIP replica is held to the CONTROL's behaviour, per parameter group and step: update cosine no more than
-    0.005 below the control's, weight drift from the aten replica at most 1.5 x the control's (+ 1e-4); the six
-    losses within 1e-3 of aten's over the first four steps, afterwards within max(5e-3, 5 x the control's largest
-    loss difference so far).  Measured (profiles/r4_*_gpu_suite.log): HIP and control are indistinguishable -- drift
-    ratios 0.99 .. 1.22 over all groups and steps, cosines equal to three digits (step 9: 0.9692 / 0.9679)."""
+    in one process: the HIP conv stack, aten fp32 convolutions, and a CONTROL -- aten again, started from weights
+    perturbed by a uniform relative 2^-19.  The system amplifies ANY forward difference through ReLU switches, most
+    of all into the stem (fpn.C1, under every ReLU of the net): what a replica may be held to is the behaviour of
+    another replica whose forward pass deviates from aten's at least as much.  Calibration
+    (tools/control_calibration.py, profiles/r4_control_calibration.log): step-0 forward deviation from aten of the
+    RPN / mask / class logits -- HIP 1.3e-6 / 6.9e-7 / 1.6e-6; control 2^-22: 7.7e-7 / 5.4e-7 / 9.6e-7; control 2^-19:
+    2.7e-6 / 2.0e-6 / 3.0e-6; stem drift after steps 1 / 2 / 3 -- HIP 2.3e-4 / 8.1e-4 / 2.3e-3, control 2^-19
+    1.2e-4 / 6.9e-4 / 2.2e-3 (2^-22: 1.8e-7 / 8.0e-6 / 2.1e-4); every other group of the HIP replica stays BELOW
+    1e-6 where the controls sit at their own perturbation.  (The first time this test ran, aten's two replicas had
+    been given different MIOpen algorithms by a cold find cache: that accidental control tracked the HIP replica
+    to three digits -- drift ratios 0.99 .. 1.22, profiles/r4_a_gpu_suite.log.)
+    Held: (a) the HIP forward pass is closer to aten's than the control's; (b) per step and group, update cosine
+    no more than 0.003 below the control's and weight drift at most 3 x the control's (+ 1e-6); (c) the six
+    losses within 1e-3 of aten's over the first four steps, then within max(5e-3, 5 x the control's largest loss
+    difference so far)."""
     from sln_amodal_amd import conv_hip, nn_ops
     sat0 = conv_hip.saturation_count()
     g = golden("e2e_multistep_0")
@@ -151,7 +165,7 @@ def test_ten_steps_hip_convolutions_against_aten_convolutions():
     with torch.no_grad():
         for p in m_ctl.parameters():
             if p.requires_grad:
-                p.mul_(1.0 + (torch.rand(p.shape, device="cuda", generator=gen) - 0.5) * 2.0 ** -21)
+                p.mul_(1.0 + (torch.rand(p.shape, device="cuda", generator=gen) - 0.5) * 2 * CONTROL_EPS)
     o_hip = m_hip.make_optimizer(0.002)
     nn_ops.BACKEND = "torch"
     o_ref, o_ctl = m_ref.make_optimizer(0.002), m_ctl.make_optimizer(0.002)
@@ -160,6 +174,23 @@ def test_ten_steps_hip_convolutions_against_aten_convolutions():
     p_hip, p_ref, p_ctl = (dict(m.named_parameters()) for m in (m_hip, m_ref, m_ctl))
     assert all(torch.equal(p_hip[n], p_ref[n]) for n in names)
     report, bad = [], []
+    # (a) forward deviation at step 0
+    batch, pr = _step_inputs(g, 0)
+    inp = [batch["images"], None, batch["gt_class_ids"], batch["gt_boxes"], batch["gt_layer"]]
+    outs = {}
+    with torch.no_grad():
+        for key, m, be in (("ref", m_ref, "torch"), ("ctl", m_ctl, "torch"), ("hip", m_hip, "hip")):
+            nn_ops.BACKEND = be
+            outs[key] = m.predict(inp, mode="training", priorities=pr)
+    nn_ops.BACKEND = "hip"
+    fwd = {key: max(_rel(outs[key][t], outs["ref"][t]) for t in ("rpn_class_logits", "mrcnn_mask", "mrcnn_class_logits"))
+           for key in ("hip", "ctl")}
+    report.append("forward deviation from aten (max over RPN / mask / class logits): hip %.2e control %.2e" %
+                  (fwd["hip"], fwd["ctl"]))
+    print(report[-1])
+    if not fwd["hip"] <= fwd["ctl"]:
+        bad.append("forward deviation")
+    assert fwd["hip"] <= 1e-4          # (the north-star tolerance, as in test_e2e_gpu)
     dc_max = 0.0
     for k in range(K):
         batch, pr = _step_inputs(g, k % int(g["steps"]))
@@ -184,9 +215,9 @@ def test_ten_steps_hip_convolutions_against_aten_convolutions():
         dc_max = max(dc_max, dc)
         if dl > (1e-3 if k < 4 else max(5e-3, 5 * dc_max)):
             bad.append("step %d losses" % k)
-        if any(cos[grp] < ccos[grp] - 0.005 for grp in GROUPS):
+        if any(cos[grp] < ccos[grp] - 0.003 for grp in GROUPS):
             bad.append("step %d cosine" % k)
-        if any(drift[grp] > 1.5 * cdrift[grp] + 1e-4 for grp in GROUPS):
+        if any(drift[grp] > 3 * cdrift[grp] + 1e-6 for grp in GROUPS):
             bad.append("step %d drift" % k)
     assert not bad, "%s\n%s" % (bad, "\n".join(report))
     assert o_hip.skipped_steps() == 0 and conv_hip.saturation_count() == sat0

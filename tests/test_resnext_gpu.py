@@ -133,3 +133,28 @@ def test_config5_resnext101_msc_forward_full_depth():
     assert tuple(y.shape) == (4, 182, 17, 17) and bool(torch.isfinite(y).all())
     print("ResNeXt-101 MSC forward, 4 x 513^2: %.1f ms (%.1f img/s)" % (dt * 1e3, 4 / dt))
 
+
+
+def test_bench_config_resnext_prints_the_contract_line():
+    """`bench.py --config resnext` (BASELINE.json configs[4]; its default is 32 x 321^2 per GPU) at a small shape: one
+    JSON line with the contract's keys, the dominant kernel's roofline and a finite loss."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    torch.cuda.empty_cache()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "resnext", "--batch", "2",
+                        "--dim", "129", "--steps", "2", "--warmup", "1"], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in out, k
+    assert out["n_gpus"] == 1 and out["value"] > 0 and out["config"]["images_per_gpu"] == 2
+    assert out["roofline"]["frac"] is not None and 0 < out["roofline"]["frac"] < 1
+    assert out["step_roofline"]["algorithmic_tflop_per_step"] > 0

@@ -69,6 +69,29 @@ def measure(dev, B=16):
     tk = _time(lambda: launch(K, 1))
     tz = _time(lambda: launch(0, 0))
     map_bytes = sum(g_.numel() * 4 for g_ in grads)
+    # the classifier's 7x7 crops through the same kernel (the committed counter pass averages over both kinds)
+    up7 = torch.randn(K, C_, 7, 7, device=dev, generator=g).contiguous(memory_format=torch.channels_last)
+
+    def launch7():
+        _lib.check(_lib.lib().sln_pyramid_crop_bwd_f32(ops._ptr(up7), C_, 0, ops._ptr(boxes), ops._ptr(ind),
+                                                       ops._ptr(lvl), K, 7, 7, B, C_, ptrs, hw, 1,
+                                                       ops._stream()), "sln_pyramid_crop_bwd_f32")
+    tk7 = _time(launch7)
+    measured = {}
+    try:      # HBM bytes the scatter kernel really moved (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE, committed pass; mean
+        # over its pool-16 and pool-7 launches) over the mean live duration of the same two launches
+        import json
+        import os
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        rel = os.path.join("profiles", "r3_v11_pmc_roialign.json")
+        pk = json.load(open(os.path.join(root, rel)))["pyr_bwd_patch_kernel"]
+        by_meas = pk["fetch_bytes_per_launch_x2"] + pk["write_bytes_per_launch"]
+        gbs = by_meas / (0.5 * (tk + tk7)) / 1e9
+        measured = {"measured_hbm_bytes_per_launch": by_meas, "measured_hbm_gbs": round(gbs, 1),
+                    "measured_hbm_frac": round(gbs / PEAK_HBM_GBS, 4), "measured_replayed_from": rel,
+                    "scatter_pool7_ms": round(tk7 * 1e3, 4)}
+    except Exception:
+        pass
     out["roialign_bwd"] = {"kernel": "pyr_zero_kernel + pyr_bwd_patch_kernel", "bound": "hbm",
                            "bytes_per_elem": 36, "elems": elems, "ms": round(t * 1e3, 4),
                            "achieved": round(elems * 36 / t / 1e9, 1), "peak": PEAK_HBM_GBS,
@@ -77,7 +100,7 @@ def measure(dev, B=16):
                            "scatter_kernel_only_frac": round(elems * 36 / tk / 1e9 / PEAK_HBM_GBS, 4),
                            "zero_fill_ms": round(tz * 1e3, 4), "zero_fill_bytes": map_bytes,
                            "zero_fill_gbs": round(map_bytes / tz / 1e9, 1),
-                           "gather_form_ms": round(t_gather * 1e3, 4),
+                           "gather_form_ms": round(t_gather * 1e3, 4), **measured,
                            "note": "ms = the whole op (zero fill + scatter, two launches). 36 B / element is the "
                                    "algorithmic model (4 B load + 4 x 8 B atomic RMW); the four maps total %d MB, so "
                                    "most of it is served by L2 / Infinity Cache -- measured FETCH_SIZE / WRITE_SIZE: "
