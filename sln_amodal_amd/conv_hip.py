@@ -1223,11 +1223,15 @@ class _ConvFn(torch.autograd.Function):
                 # (soft chain: taken only when the other reader's gradient is in the inbox -- then this data
                 # gradient plus that deposit, added as the epilogue's residual, is the producer's whole gradient)
                 extra = ctx.inbox.take() if (ci.get("soft") and ctx.inbox is not None) else None
+                # (the producer's BN scale multiplies the SUM of this data gradient and the deposit: post_scale, as in
+                # the keep_dx / with_res branches -- in the scale position it would leave the deposit unscaled)
                 _, gz_up, gb_up = _fwd(gz, N, OH, OW, wt, Ci, KH, KW, (1, 1), dil, dil[0] * (KH - 1) - pt,
-                                       dil[1] * (KW - 1) - pl, H, W, ci["scale"], None,
+                                       dil[1] * (KW - 1) - pl, H, W,
+                                       None if extra is not None else ci["scale"], None,
                                        _nhwc(extra) if extra is not None else None, False, cin=Co,
                                        out_parts=True,
                                        want_y=False, want_colsum=ci["want_bias"], yslot=ci["gz_slot"],
+                                       post_scale=ci["scale"] if extra is not None else None,
                                        **mask_kw(mask_x), **qs)
                 ci["gz"], ci["gbias"] = gz_up, gb_up
                 ci["gzq"] = ci["gz_slot"].scale if parts == 2 else None
