@@ -208,7 +208,7 @@ def main_resnext(args, rank, world, dev):
     the headline line.  The reference never instantiates this configuration, so there is no
     headline metric for it in BASELINE.json: `metric` names what is timed."""
     import torch.nn.functional as F
-    from sln_amodal_amd import conv_hip, parallel
+    from sln_amodal_amd import conv_hip, nn_ops, parallel
     from sln_amodal_amd.modal.resnext import DeepLabV2_ResNeXt101_MSC
     batch = args.batch if args.batch != 16 else 32
     dim = args.dim if args.dim != 1024 else 321
@@ -232,17 +232,24 @@ def main_resnext(args, rank, world, dev):
     xs = [torch.randn(batch, 3, dim, dim, device=dev, generator=g).contiguous(memory_format=torch.channels_last)
           for _ in range(2)]
     # algorithmic FLOPs of one forward pass (2 * MACs of every convolution call, grouped ones by their group width)
+    # (the modules are parameter holders: every convolution goes through nn_ops.conv_bn_act, counted there)
     fwd_flops = [0.0]
+    real_cba = nn_ops.conv_bn_act
 
-    def count(mod, inp, out):
-        kh, kw = mod.kernel_size
-        fwd_flops[0] += 2.0 * out.numel() * (mod.in_channels // mod.groups) * kh * kw
-    hooks = [m.register_forward_hook(count) for m in net.modules() if isinstance(m, torch.nn.Conv2d)]
-    with torch.no_grad():
-        conv_hip.update_scales()
-        outs = net(xs[0])
-    for h in hooks:
-        h.remove()
+    def counting_cba(x, conv, *a, **k):
+        y = real_cba(x, conv, *a, **k)
+        kh, kw = conv.kernel_size
+        fwd_flops[0] += 2.0 * y.numel() * (conv.in_channels // conv.groups) * kh * kw
+        return y
+    nn_ops.conv_bn_act = counting_cba
+    try:
+        with torch.no_grad():
+            conv_hip.update_scales()
+            outs = net(xs[0])
+    finally:
+        nn_ops.conv_bn_act = real_cba
+    if fwd_flops[0] <= 0:
+        raise SystemExit("bench.py --config resnext: no convolution was counted")
     oh = outs[0].shape[2]
     target = torch.randint(0, classes, (batch, oh, oh), device=dev, generator=g)
     params = [p for p in net.parameters() if p.requires_grad]

@@ -750,7 +750,7 @@ struct ConvParams {
     int Cin, Cout, KH, KW, sh, sw, dh, dw, pt, pl, relu;
     int M, Ktot, cin_chunks, gm, gn;
     int w_tiled;   // weights in conv_fwd256_kernel's LDS-image order (split_weights_tiled_kernel)
-    int dbg;   // ablation bits, debug sessions only (SLN_CONV_DBG): 1 no DMA in the k-loop, 2 no MFMA, 4 no fragment reads, 8 no wave-group stagger, 16 general epilogue
+    int dbg;   // ablation bits, debug sessions only (SLN_CONV_DBG): 1 no DMA in the k-loop, 2 no MFMA, 4 no fragment reads, 8 no wave-group stagger, 16 general epilogue, 4096 activation stages one ahead instead of two (conv_fwd256h_kernel)
     // Up to SLN_MAX_SEG image groups of different sizes share one launch (the GLM's three
     // scales): group s holds segN[s] images of segH x segW, its output rows start at
     // seg_m0[s] and its input pixels at seg_x0[s] of the flat [pixels][C] buffers.
@@ -1795,10 +1795,17 @@ __global__ __launch_bounds__(512) void conv_fwd256h_kernel(const ConvParams p) {
     unsigned long long sums[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
     constexpr int REGION = T2 * T2H * 2;      // one part of one operand: 256 rows x 64 B = 16 KB
-    constexpr int STAGE = 2 * P * REGION;     // A parts then B parts: 64 KB
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE + T2 * 4 + 16];   // ONE LDS object
-    float *s_colsum = (float *)(smem + 2 * STAGE);
-    unsigned *s_word = (unsigned *)(smem + 2 * STAGE + T2 * 4);
+    constexpr int OBUF = P * REGION;          // one stage of ONE operand (its two parts): 32 KB
+    // Round 4: the ACTIVATION stages are prefetched TWO stages ahead (three 32-KB buffers), the weight stages one
+    // (two buffers): a stage of a pointwise layer is 1.5 k cycles of MFMA work against a 4-5 k-cycle HBM round
+    // trip, so with one stage in flight the k-loop of the HBM-bound launches ran at the pace of the round trips
+    // (K = 1024 -> 256: 172-187 k cycles for 48 k of MFMA work); the weights of a Cout tile are served by the L2
+    // and stay one stage ahead.  3 + 2 buffers = 160 KB, the whole LDS of a CU: the column sums and the amax word
+    // live in the (by then idle) weight ring during the epilogue.  dbg 4096: one stage ahead, as before (A/B).
+    constexpr int BBASE = 3 * OBUF;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[5 * OBUF];   // ONE LDS object: 163 840 B
+    float *s_colsum = (float *)(smem + BBASE);
+    unsigned *s_word = (unsigned *)(smem + BBASE + T2 * 4);
     const float alpha = operand_unscale(p.x_scale, p.w_scale);
     const float yqs = p.yq.scale ? *p.yq.scale : 1.f;
     float amx = 0.f;
@@ -1810,7 +1817,6 @@ __global__ __launch_bounds__(512) void conv_fwd256h_kernel(const ConvParams p) {
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const int wr = wave >> 2, wc = wave & 3;
-    if (t < T2) s_colsum[t] = 0.f;
     const int bid = xcd_remap(blockIdx.x, p.gm * p.gn);
     const int m0 = (bid / p.gn) * T2;
     const int n0 = (bid % p.gn) * T2;
@@ -1884,21 +1890,26 @@ __global__ __launch_bounds__(512) void conv_fwd256h_kernel(const ConvParams p) {
             if (n_tap == ntap) { n_tap = 0; n_kh = 0; n_kw = 0; ++n_g; }
         }
     };
-    // piece g (0..7) of stage n_s: g&3 -> {A part 0 rows q=0, A part 0 q=1, A part 1 q=0, A part 1 q=1},
-    // g >= 4 the same for B.  Issued three per phase in phases 0 and 1, two in phase 2.
-    auto issue_piece = [&](int g) {
-        unsigned char *base = smem + (n_s & 1) * STAGE + wave * 2048;
+    // piece g (0..7): g&3 -> {part 0 rows q=0, part 0 q=1, part 1 q=0, part 1 q=1}; g < 4: of the ACTIVATION stage
+    // n_s (whose offsets a_voff hold) into activation buffer a_wr; g >= 4: of the WEIGHT stage bs into weight
+    // buffer bs & 1.
+    const int AD = (p.dbg & 4096) ? 1 : 2;    // stages the activations run ahead of the one being multiplied
+    int a_wr = 0, a_rd = 0;                   // activation ring: buffer being filled / being read (0..2)
+    auto issue_piece = [&](int g, int bs) {
         const int pp = (g >> 1) & 1, q = g & 1;
         if (g < 4) {
+            unsigned char *base = smem + a_wr * OBUF + wave * 2048;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(pp ? rsrc_a1 : rsrc_a0,
                                                      (lds_void *)(base + pp * REGION + q * 1024), 16, a_voff[q], 0,
                                                      0, 0);
         } else {
-            const unsigned soff = (unsigned)(n_s * P + pp) * (T2 * T2H * 2) + q * 1024;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)(base + (P + pp) * REGION + q * 1024), 16,
+            unsigned char *base = smem + BBASE + (bs & 1) * OBUF + wave * 2048;
+            const unsigned soff = (unsigned)(bs * P + pp) * (T2 * T2H * 2) + q * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)(base + pp * REGION + q * 1024), 16,
                                                      b_voff, soff, 0, 0);
         }
     };
+    auto ring_next = [](int &r) { r = r == 2 ? 0 : r + 1; };
 
     f32x16 acc[4][2];
 #pragma unroll
@@ -1946,10 +1957,20 @@ __global__ __launch_bounds__(512) void conv_fwd256h_kernel(const ConvParams p) {
 
     stage_offsets();
 #pragma unroll
-    for (int g = 0; g < 8; ++g) issue_piece(g);
+    for (int g = 0; g < 8; ++g) issue_piece(g, 0);          // activation and weight stage 0
     stage_advance();
+    ring_next(a_wr);
     if (nk > 1) stage_offsets();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (AD == 2 && nk > 1) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) issue_piece(g, 0);      // activation stage 1 stays in flight behind stage 0
+        stage_advance();
+        ring_next(a_wr);
+        if (nk > 2) stage_offsets();
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");    // (in order: everything but the four youngest pieces)
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
     const bool stagger = !(p.dbg & 8);
     if (wr == 1 && stagger) __builtin_amdgcn_s_barrier();      // the second wave group runs one barrier behind
@@ -1959,8 +1980,10 @@ __global__ __launch_bounds__(512) void conv_fwd256h_kernel(const ConvParams p) {
     bf16x8 b16[4][P];
     SLN_STAMP(ts_loop0);
     for (int s = 0; s < nk; ++s) {
-        const unsigned char *st = smem + (s & 1) * STAGE;
-        const bool more = s + 1 < nk;
+        const unsigned char *stA = smem + a_rd * OBUF;
+        const unsigned char *stB = smem + BBASE + (s & 1) * OBUF;
+        const bool moreB = s + 1 < nk;        // weight stage s + 1 is issued in this stage ...
+        const bool moreA = s + AD < nk;       // ... and activation stage s + AD (== n_s: the walker points at it)
 #pragma unroll
         for (int ph = 0; ph < NPH; ++ph) {
             // NPH = 4: phase = (k16 sub-step, half of the wave's 128 rows), 12 MFMAs; NPH = 2: phase =
@@ -1976,45 +1999,61 @@ __global__ __launch_bounds__(512) void conv_fwd256h_kernel(const ConvParams p) {
                     for (int j = 0; j < 4; ++j)
 #pragma unroll
                         for (int pp = 0; pp < P; ++pp)
-                            b16[j][pp] = *(const bf16x8 *)(st + (P + pp) * REGION + b_off16[j]);
+                            b16[j][pp] = *(const bf16x8 *)(stB + pp * REGION + b_off16[j]);
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int pp = 0; pp < P; ++pp)
-                        a[i][pp] = *(const bf16x8 *)(st + pp * REGION + a_off16[4 * ph + i]);
+                        a[i][pp] = *(const bf16x8 *)(stA + pp * REGION + a_off16[4 * ph + i]);
             } else {
             if (!hi) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
                     for (int pp = 0; pp < P; ++pp)
-                        b[j][pp] = *(const bf16x8 *)(st + (P + pp) * REGION + (b_off[j] ^ (sub * 32)));
+                        b[j][pp] = *(const bf16x8 *)(stB + pp * REGION + (b_off[j] ^ (sub * 32)));
             }
 #pragma unroll
             for (int i = 0; i < NA; ++i)
 #pragma unroll
                 for (int pp = 0; pp < P; ++pp)
-                    a[i][pp] = *(const bf16x8 *)(st + pp * REGION + (a_off[NA * hi + i] ^ (sub * 32)));
+                    a[i][pp] = *(const bf16x8 *)(stA + pp * REGION + (a_off[NA * hi + i] ^ (sub * 32)));
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (more && !(p.dbg & 1)) {    // n_s == s + 1 here; its offsets were computed in the last phase of stage s - 1
+            if (!(p.dbg & 1)) {
+                // the WEIGHT pieces first, then the activation pieces: the wait below lets the four youngest pieces
+                // (the activation stage two ahead) stay in flight, and memory operations complete in order.
+                // n_s == s + AD here; its offsets were computed in the last phase of the previous stage
                 if (NPH == 4) {
-                    if (ph == 0) { issue_piece(0); issue_piece(4); issue_piece(1); }
-                    if (ph == 1) { issue_piece(5); issue_piece(2); issue_piece(6); }
-                    if (ph == 2) { issue_piece(3); issue_piece(7); }
+                    if (ph == 0 && moreB) { issue_piece(4, s + 1); issue_piece(5, s + 1); issue_piece(6, s + 1); }
+                    if (ph == 1 && moreB) issue_piece(7, s + 1);
+                    if (ph == 1 && moreA) { issue_piece(0, 0); issue_piece(1, 0); }
+                    if (ph == 2 && moreA) { issue_piece(2, 0); issue_piece(3, 0); }
                 } else if (ph == 0) {
+                    if (moreB) {
 #pragma unroll
-                    for (int g = 0; g < 8; ++g) issue_piece((g >> 1) | ((g & 1) << 2));   // A, B alternating
+                        for (int g = 4; g < 8; ++g) issue_piece(g, s + 1);
+                    }
+                    if (moreA) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) issue_piece(g, 0);
+                    }
                 }
             }
             if (ph == NPH - 1) {
-                // own DMA pieces landed before the middle barrier of the last phase, which the first
-                // reads of the next stage lie behind for both groups; then the offsets of the stage
-                // after that (cheap VALU in the shortest read segment)
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                stage_advance();
-                if (s + 2 < nk) stage_offsets();
+                // own DMA pieces of the NEXT stage landed before the middle barrier of the last phase, which the
+                // first reads of the next stage lie behind for both groups (the activation stage after it may
+                // still be on its way); then the offsets of the activation stage to issue next (cheap VALU in the
+                // shortest read segment)
+                if (AD == 2 && moreA && !(p.dbg & 1)) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                if (moreA) {
+                    stage_advance();
+                    ring_next(a_wr);
+                    if (n_s < nk) stage_offsets();
+                }
+                ring_next(a_rd);
             } else {
                 // own fragment reads returned BEFORE the barrier: the other group may re-stage this
                 // buffer right behind it (phase 0 of the next stage)
@@ -2061,10 +2100,11 @@ __global__ __launch_bounds__(512) void conv_fwd256h_kernel(const ConvParams p) {
     SLN_STAMP(ts_loop1);
     if (wr == 0 && stagger) __builtin_amdgcn_s_barrier();      // re-align the two groups
     __syncthreads();
+    if (t < T2) s_colsum[t] = 0.f;      // (in the idle weight ring; ordered by the epilogue's first barrier)
 
     // ---- epilogue: four 64-row slabs through LDS ([64][260] floats), as in conv_fwd256_kernel ----
     float *stage = (float *)smem;
-    static_assert(64 * 260 * 4 <= 2 * STAGE, "staging slab must fit");
+    static_assert(64 * 260 * 4 <= BBASE, "staging slab must fit below the column sums");
     const bool plain = epilogue_is_plain(p) && !(p.dbg & 16);      // (dbg 16: A/B against epilogue_slab)
     SLN_STAMP(t0);
     auto stage_slab = [&](int h) {

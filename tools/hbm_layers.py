@@ -62,13 +62,14 @@ for (name, N, Cin, H, Cout, k) in LAYERS:
     print("%s  [%s]  M=%d  %.1f GFLOP" % (name, conv_hip._fwd_kernel_name(layout, 2), M, fl / 1e9))
     for vn, (f, bpp) in variants.items():
         row = []
+        base_dbg = int(os.environ.get("SLN_HBM_LAYERS_DBG", "0"))      # e.g. 4096: activations one stage ahead
         for dbg in ("0", "32", "1", "2"):
-            os.environ["SLN_CONV_DBG"] = dbg
+            os.environ["SLN_CONV_DBG"] = str(int(dbg) | base_dbg)
             t = timeit(f)
             row.append("%s %.3f ms" % ({"0": "full", "64": "nt", "32": "4-wide", "1": "noDMA", "2": "noMFMA"}[dbg], t))
             if dbg == "0":
                 row.append("%5.2f TB/s %4.0f TF" % (M * bpp / t / 1e9, fl / t / 1e9))
-        os.environ["SLN_CONV_DBG"] = "0"
+        os.environ["SLN_CONV_DBG"] = str(base_dbg)
         st = ""
         if layout == conv_hip.TILED256H:
             os.environ["SLN_CONV_STAMP"] = "1"
