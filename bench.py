@@ -38,7 +38,7 @@ def split_peak(parts):
 PEAK_HBM_GBS = 8000.0
 # HBM bytes per launch cannot be collected live (PMC needs rocprofv3 around the process): the bench line
 # REPLAYS the committed counter passes of the same command and marks them as such
-PMC_TRAFFIC = os.path.join("profiles", "r3_v11_pmc_traffic.json")
+PMC_TRAFFIC = os.path.join("profiles", "r4_v1_pmc_traffic.json")
 
 
 def step_gflop_per_image(stage, dim, arch):
@@ -53,8 +53,15 @@ def step_gflop_per_image(stage, dim, arch):
 
 
 def _file_commit(rel):
-    """Short SHA of the last commit that touched a committed evidence file ('' outside a git checkout)."""
+    """The revision a committed counter file was collected at: its own `collected_at_commit` field (written when
+    the file was committed; the GPU box has no .git), else the last commit that touched it."""
     import subprocess
+    try:
+        sha = json.load(open(os.path.join(ROOT, rel))).get("collected_at_commit")
+        if sha:
+            return sha
+    except Exception:
+        pass
     try:
         return subprocess.run(["git", "-C", ROOT, "log", "-1", "--format=%h", "--", rel], capture_output=True,
                               text=True, timeout=20).stdout.strip()

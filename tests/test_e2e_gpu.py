@@ -107,10 +107,16 @@ def _check_forward(out, g, b=0):
         assert e.max() < 1e-4, (key, "rows off", np.nonzero(e >= 1e-4)[0].tolist(), e.max())
 
 
-@pytest.mark.parametrize("scene", [0, 1])
-def test_training_predict_and_losses_match_reference(scene):
-    g = golden("e2e_train_%d" % scene)
-    m, cfg = e2e_model("cuda")
+# (name of the fixture, image size): two 128^2 scenes and scene 0 at 256^2 -- maps of 64^2 .. 4^2, i.e. whole 256-row
+# tiles of the convolution kernels with their predicate-free epilogue (tools/gen_golden_e2e.py --dim 256)
+TRAIN_FIXTURES = [("e2e_train_0", 128), ("e2e_train_1", 128), ("e2e_train_256_0", 256)]
+
+
+@pytest.mark.parametrize("name,dim", TRAIN_FIXTURES)
+def test_training_predict_and_losses_match_reference(name, dim):
+    g = golden(name)
+    assert int(g["dim"]) == dim
+    m, cfg = e2e_model("cuda", dim)
     inp, pr = _inputs([g])
     with torch.no_grad():
         own = m.predict(inp, mode="training", priorities=pr)
@@ -142,13 +148,13 @@ def test_batched_step_equals_the_mean_of_the_reference_per_image_losses():
     assert abs(float(loss) - want) <= 1e-4, (float(loss), want)
 
 
-@pytest.mark.parametrize("scene", [0, 1])
-def test_one_train_step_matches_the_reference_optimizer_step(scene):
+@pytest.mark.parametrize("name,dim", TRAIN_FIXTURES)
+def test_one_train_step_matches_the_reference_optimizer_step(name, dim):
     """predict -> losses -> backward -> clip 5.0 -> SGD (lr .01, momentum .9, wd 1e-4) on one image:
     the global gradient norm and the updates of 22 watched parameter tensors against the step the
     reference's train_epoch took (model.py:415-444)."""
-    g = golden("e2e_train_%d" % scene)
-    m, cfg = e2e_model("cuda")
+    g = golden(name)
+    m, cfg = e2e_model("cuda", dim)
     params = dict(m.named_parameters())
     names = [str(n) for n in g["names"]]
     for n in names:

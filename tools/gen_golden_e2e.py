@@ -14,6 +14,8 @@ initialisation of tests/_util.e2e_init_ (regenerated from the keys on the test s
 
     python tools/gen_golden_e2e.py --masks   # writes tests/golden/e2e_relu_masks_0.npz only
     python tools/gen_golden_e2e.py --steps   # writes tests/golden/e2e_multistep_0.npz only (run_multistep)
+    python tools/gen_golden_e2e.py --dim 256 # writes tests/golden/e2e_train_256_0.npz only: scene 0's train step at 256^2
+                                             # (six objects) -- maps of 64^2 .. 4^2: whole 256-row tiles of the conv kernels
 
 --masks re-runs scene 0's train step with three more observers: a forward hook on every nn.ReLU of the
 detector (modals.py:276-299, 316, 383, 430, 476) that records the SIGN BITMAP of its output, in call
@@ -149,7 +151,11 @@ MASK_WATCH = WATCH + [
 MASK_SLICE = 8192
 
 
-def main(only_masks=False, multistep=False):
+def main(only_masks=False, multistep=False, dim=None):
+    global DIM
+    big = dim is not None and dim != DIM
+    if big:
+        DIM = int(dim)
     ref_modals, ref_F = ref_harness.install()
     import scipy.misc
     scipy.misc.imresize = imresize
@@ -163,7 +169,7 @@ def main(only_masks=False, multistep=False):
     ref_utils.scipy.misc.imresize = imresize
 
     tmp = tempfile.mkdtemp()
-    scenes = [make_scene(101, 4), make_scene(202, 5)]
+    scenes = [make_scene(101, 4), make_scene(202, 5)] if not big else [make_scene(101, 6)]
 
     real_loader = torch.utils.data.DataLoader
     real_randperm = torch.randperm
@@ -179,7 +185,10 @@ def main(only_masks=False, multistep=False):
     # The optimizer OBJECT is the one train_model builds (model.py:352-358: SGD, momentum, weight decay
     # on every trainable parameter whose name does not contain 'bn'); two clip + step rounds
     # (model.py:441-444) on name-keyed seeded gradients, momentum included in the second.
-    model, cfg = build_reference_model(ref_model, ref_config, ref_dl, nn)
+    if big:
+        model = None
+    else:
+        model, cfg = build_reference_model(ref_model, ref_config, ref_dl, nn)
     if only_masks:
         del model
         run_mask_scene(locals())
@@ -189,6 +198,9 @@ def main(only_masks=False, multistep=False):
         run_multistep(locals())
         return
     rec_opt = {}
+    if big:
+        train_scenes(locals(), "e2e_train_%d_" % DIM)
+        return
 
     def synthetic_epoch(self, datagenerator, optimizer, steps):
         import zlib
@@ -235,7 +247,55 @@ def main(only_masks=False, multistep=False):
          **{"after1/" + n: v for n, v in rec_opt["after1"].items()})
     del model
 
-    # ------------------------------------------------------------------ one real training step per scene
+    train_scenes(locals(), "e2e_train_")
+
+    # ------------------------------------------------------------------ inference: detect()
+    model, cfg = build_reference_model(ref_model, ref_config, ref_dl, nn)
+    cfg.DETECTION_MIN_CONFIDENCE = 0          # InferenceConfig, amodal_train.py
+    rec = {}
+
+    def rec_predict_inf(self, input, mode):
+        out = real_predict(self, input, mode)
+        rec["molded"] = input[0].detach().clone()
+        rec["metas"] = np.array(input[1])
+        rec["out"] = out
+        return out
+
+    real_proposal = ref_model.proposal_layer
+
+    def rec_proposal(*a, **k):
+        r = real_proposal(*a, **k)
+        rec["rpn_rois"] = r.detach().clone()
+        return r
+
+    for si, (image, label) in enumerate(scenes):
+        ref_model.MaskRCNN.predict = rec_predict_inf
+        ref_model.proposal_layer = rec_proposal
+        try:
+            res = model.detect([image])
+        finally:
+            ref_model.MaskRCNN.predict = real_predict
+            ref_model.proposal_layer = real_proposal
+        detections, mrcnn_mask = rec["out"]
+        r = res[0]
+        print("detect scene %d: %d detections, %d after unmold, mask pixels %d" %
+              (si, detections.shape[1], r["rois"].shape[0], int(r["masks"].sum())))
+        save("e2e_detect_%d" % si, native=np.array("oracle"), dim=np.array(DIM), image_u8=image,
+             molded=rec["molded"].numpy(), image_metas=rec["metas"],
+             rpn_rois=rec["rpn_rois"].numpy(), detections=detections[0].numpy(),
+             mrcnn_mask=mrcnn_mask[0].numpy(),
+             final_rois=r["rois"], final_class_ids=r["class_ids"], final_scores=r["scores"],
+             final_masks=np.packbits(r["masks"].astype(np.uint8), axis=None),
+             final_masks_shape=np.array(r["masks"].shape))
+
+
+def train_scenes(env, prefix):
+    """One real training step of the reference's loop per scene -> tests/golden/<prefix><scene>.npz."""
+    ref_model, ref_config, ref_dl, nn, ref_F = (env[k] for k in ("ref_model", "ref_config", "ref_dl", "nn", "ref_F"))
+    ref_train, scenes, tmp, loss_names, orc = (env[k] for k in ("ref_train", "scenes", "tmp", "loss_names", "orc"))
+    real_loader, real_randperm, real_clip, real_step, real_save, real_predict, real_losses = (
+        env[k] for k in ("real_loader", "real_randperm", "real_clip", "real_step", "real_save", "real_predict",
+                         "real_losses"))
     for si, (image, label) in enumerate(scenes):
         model, cfg = build_reference_model(ref_model, ref_config, ref_dl, nn)
         params = dict(model.named_parameters())
@@ -327,7 +387,7 @@ def main(only_masks=False, multistep=False):
             probs = torch.softmax(rpn_class_logits, dim=2)
             rpn_rois = ref_F.proposal_layer([probs, rpn_bbox.detach()], proposal_count=cfg.POST_NMS_ROIS_TRAINING,
                                             nms_threshold=cfg.RPN_NMS_THRESHOLD, anchors=model.anchors, config=cfg)
-        save("e2e_train_%d" % si, native=np.array("oracle"), dim=np.array(DIM), lr=np.array(0.01),
+        save(prefix + "%d" % si, native=np.array("oracle"), dim=np.array(DIM), lr=np.array(0.01),
              flipped=np.array(flipped), image_u8=(image[:, ::-1] if flipped else image).copy(),
              images=images.numpy(), label=lab, gt_class_ids=gt_class_ids.numpy(),
              gt_boxes=gt_boxes.numpy(), rpn_match=rec["rpn_match"].numpy(),
@@ -347,45 +407,6 @@ def main(only_masks=False, multistep=False):
              **{"before/" + n: v for n, v in rec["before"].items()},
              **{"after/" + n: v for n, v in rec["after"].items()})
         del model
-
-    # ------------------------------------------------------------------ inference: detect()
-    model, cfg = build_reference_model(ref_model, ref_config, ref_dl, nn)
-    cfg.DETECTION_MIN_CONFIDENCE = 0          # InferenceConfig, amodal_train.py
-    rec = {}
-
-    def rec_predict_inf(self, input, mode):
-        out = real_predict(self, input, mode)
-        rec["molded"] = input[0].detach().clone()
-        rec["metas"] = np.array(input[1])
-        rec["out"] = out
-        return out
-
-    real_proposal = ref_model.proposal_layer
-
-    def rec_proposal(*a, **k):
-        r = real_proposal(*a, **k)
-        rec["rpn_rois"] = r.detach().clone()
-        return r
-
-    for si, (image, label) in enumerate(scenes):
-        ref_model.MaskRCNN.predict = rec_predict_inf
-        ref_model.proposal_layer = rec_proposal
-        try:
-            res = model.detect([image])
-        finally:
-            ref_model.MaskRCNN.predict = real_predict
-            ref_model.proposal_layer = real_proposal
-        detections, mrcnn_mask = rec["out"]
-        r = res[0]
-        print("detect scene %d: %d detections, %d after unmold, mask pixels %d" %
-              (si, detections.shape[1], r["rois"].shape[0], int(r["masks"].sum())))
-        save("e2e_detect_%d" % si, native=np.array("oracle"), dim=np.array(DIM), image_u8=image,
-             molded=rec["molded"].numpy(), image_metas=rec["metas"],
-             rpn_rois=rec["rpn_rois"].numpy(), detections=detections[0].numpy(),
-             mrcnn_mask=mrcnn_mask[0].numpy(),
-             final_rois=r["rois"], final_class_ids=r["class_ids"], final_scores=r["scores"],
-             final_masks=np.packbits(r["masks"].astype(np.uint8), axis=None),
-             final_masks_shape=np.array(r["masks"].shape))
 
 
 def run_mask_scene(env):
@@ -595,4 +616,5 @@ def run_multistep(env, steps=5):
 
 
 if __name__ == "__main__":
-    main(only_masks="--masks" in sys.argv, multistep="--steps" in sys.argv)
+    main(only_masks="--masks" in sys.argv, multistep="--steps" in sys.argv,
+         dim=int(sys.argv[sys.argv.index("--dim") + 1]) if "--dim" in sys.argv else None)
