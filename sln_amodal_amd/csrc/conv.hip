@@ -750,7 +750,7 @@ struct ConvParams {
     int Cin, Cout, KH, KW, sh, sw, dh, dw, pt, pl, relu;
     int M, Ktot, cin_chunks, gm, gn;
     int w_tiled;   // weights in conv_fwd256_kernel's LDS-image order (split_weights_tiled_kernel)
-    int dbg;   // ablation bits, debug sessions only (SLN_CONV_DBG): 1 no DMA in the k-loop, 2 no MFMA, 4 no fragment reads, 8 no wave-group stagger, 16 general epilogue, 4096 activation stages one ahead instead of two (conv_fwd256h_kernel)
+    int dbg;   // ablation bits, debug sessions only (SLN_CONV_DBG): 1 no DMA in the k-loop, 2 no MFMA, 4 no fragment reads, 8 no wave-group stagger, 16 general epilogue, 4096 activation stages one ahead instead of two (conv_fwd256h_kernel), 8192 eight-channel epilogue without its part stores, 16384 ... without its split arithmetic, 32768 no epilogue at all (conv_fwd256h_kernel)
     // Up to SLN_MAX_SEG image groups of different sizes share one launch (the GLM's three
     // scales): group s holds segN[s] images of segH x segW, its output rows start at
     // seg_m0[s] and its input pixels at seg_x0[s] of the flat [pixels][C] buffers.
@@ -1218,6 +1218,11 @@ __device__ __forceinline__ void w8_compute(const ConvParams &p, const float *sta
 #pragma unroll
                 for (int e = 0; e < 8; ++e) k.csum[e] += v[e];
             }
+            if (p.yparts && (p.dbg & 16384)) {       // ablation: the part stores without the split arithmetic
+                bf16x8 w0 = __builtin_bit_cast(bf16x8, a0), w1 = __builtin_bit_cast(bf16x8, a1);
+                *(bf16x8 *)p0 = w0;
+                *(bf16x8 *)p1 = w1;
+            } else
             if (p.yparts) {                          // (fp32-only outputs: uniform per launch)
             const float rmax = (p.dbg & 512) ? amax4(amax4(0.f, v), v + 4) : amax8(v);      // (dbg 512: A/B)
             amx = fmaxf(amx, rmax);
@@ -1234,7 +1239,9 @@ __device__ __forceinline__ void w8_compute(const ConvParams &p, const float *sta
             w0.s4 = hi[0].x; w0.s5 = hi[0].y; w0.s6 = hi[0].z; w0.s7 = hi[0].w;
             w1.s0 = lo[1].x; w1.s1 = lo[1].y; w1.s2 = lo[1].z; w1.s3 = lo[1].w;
             w1.s4 = hi[1].x; w1.s5 = hi[1].y; w1.s6 = hi[1].z; w1.s7 = hi[1].w;
-            if (nt) {
+            if (p.dbg & 8192) {            // ablation: the epilogue without its part stores
+                asm volatile("" ::"v"(w0), "v"(w1));
+            } else if (nt) {
                 __builtin_nontemporal_store(w0, (bf16x8 *)p0);
                 __builtin_nontemporal_store(w1, (bf16x8 *)p1);
             } else {
@@ -1955,6 +1962,11 @@ __global__ __launch_bounds__(512) void conv_fwd256h_kernel(const ConvParams p) {
         }
     }
 
+    // (Round 4, tried and removed: pulling this tile's shortcut / ReLU-mask rows towards the L2 / Infinity Cache
+    // here -- one 4-byte LDS-DMA load per 128-B line -- so that the epilogue would read them from cache between
+    // its stores.  Same box A/B: the train step 88.0 -> 86.0 img/s, the K = 256 expand layer with a parts shortcut
+    // 0.188 -> 0.221 ms: the extra reads compete with the k-loop's stages and much of what they fetch is gone
+    // again before the epilogue asks for it.  profiles/r4_g_prefetch_epilogue_inputs.txt)
     stage_offsets();
 #pragma unroll
     for (int g = 0; g < 8; ++g) issue_piece(g, 0);          // activation and weight stage 0
@@ -2101,6 +2113,11 @@ __global__ __launch_bounds__(512) void conv_fwd256h_kernel(const ConvParams p) {
     if (wr == 0 && stagger) __builtin_amdgcn_s_barrier();      // re-align the two groups
     __syncthreads();
     if (t < T2) s_colsum[t] = 0.f;      // (in the idle weight ring; ordered by the epilogue's first barrier)
+    if (p.dbg & 32768) {                 // ablation: prologue + k-loop only (one word per lane keeps the MFMAs alive)
+        if (MS == 16) { if (acc16[0][0][0] == 12345.678f && acc16[7][3][3] == 1.f) p.y[t] = 0.f; }
+        else if (acc[0][0][0] == 12345.678f) p.y[t] = 0.f;
+        return;
+    }
 
     // ---- epilogue: four 64-row slabs through LDS ([64][260] floats), as in conv_fwd256_kernel ----
     float *stage = (float *)smem;
