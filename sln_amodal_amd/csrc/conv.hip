@@ -750,7 +750,7 @@ struct ConvParams {
     int Cin, Cout, KH, KW, sh, sw, dh, dw, pt, pl, relu;
     int M, Ktot, cin_chunks, gm, gn;
     int w_tiled;   // weights in conv_fwd256_kernel's LDS-image order (split_weights_tiled_kernel)
-    int dbg;   // ablation bits, debug sessions only (SLN_CONV_DBG): 1 no DMA in the k-loop, 2 no MFMA, 4 no fragment reads, 8 no wave-group stagger, 16 general epilogue, 4096 activation stages one ahead instead of two (conv_fwd256h_kernel), 8192 eight-channel epilogue without its part stores, 16384 ... without its split arithmetic, 32768 no epilogue at all (conv_fwd256h_kernel)
+    int dbg;   // ablation bits, debug sessions only (SLN_CONV_DBG): 1 no DMA in the k-loop, 2 no MFMA, 4 no fragment reads, 8 no wave-group stagger, 16 general epilogue, 4096 activation stages one ahead instead of two (conv_fwd256h_kernel), 8192 eight-channel epilogue without its part stores, 16384 ... without its split arithmetic, 32768 no epilogue at all (conv_fwd256h_kernel), 131072 eight-channel epilogue without its column constants' loads
     // Up to SLN_MAX_SEG image groups of different sizes share one launch (the GLM's three
     // scales): group s holds segN[s] images of segH x segW, its output rows start at
     // seg_m0[s] and its input pixels at seg_x0[s] of the flat [pixels][C] buffers.
@@ -1083,6 +1083,11 @@ __device__ __forceinline__ void w8_cols(const ConvParams &p, int n0, int t, floa
     for (int e = 0; e < 8; ++e) { k.sc[e] = alpha; k.sf[e] = 0.f; k.ps8[e] = 1.f; k.csum[e] = 0.f; }
     k.rinv = 1.f;
     if (c >= p.Cout) return;
+    // (round 4: these loads stand at the head of every tile's epilogue, and skipping them -- dbg 131072, wrong
+    // results -- made a pointwise launch 6-16 % shorter; but DMA-ing the constants into LDS during the last k-loop
+    // stage and reading them from there changed nothing, 0.142 vs 0.139 ms and 87.7 vs 87.6 img/s: what the
+    // ablation removed was not their latency.  profiles/r4_i_column_constants.txt)
+    if (p.dbg & 131072) return;
     if (p.scale) {
         const float4 s0 = *(const float4 *)(p.scale + c), s1 = *(const float4 *)(p.scale + c + 4);
         k.sc[0] = s0.x * alpha; k.sc[1] = s0.y * alpha; k.sc[2] = s0.z * alpha; k.sc[3] = s0.w * alpha;

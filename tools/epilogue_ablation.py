@@ -46,7 +46,7 @@ for (name, N, Cin, H, Cout) in [("C4 conv3 1x1 256->1024 @64", 16, 256, 64, 1024
         row = []
         for label, dbg in (("full", 0), ("k-loop off", 3), ("k-loop off, no stores", 3 | 8192),
                            ("k-loop off, no split", 3 | 16384), ("k-loop off, neither", 3 | 8192 | 16384),
-                           ("no stores", 8192), ("no split", 16384), ("no epilogue", 32768),
+                           ("no stores", 8192), ("no split", 16384), ("no epilogue", 32768), ("no column constants", 131072), ("k-loop off, no column constants", 3 | 131072),
                            ("k-loop off, no epilogue", 3 | 32768), ("no fragment reads either", 7 | 32768)):
             os.environ["SLN_CONV_DBG"] = str(dbg)
             row.append("%s %.3f ms" % (label, timeit(f)))
