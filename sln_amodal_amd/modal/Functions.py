@@ -313,7 +313,11 @@ def refine_detections_batched(rois, valid, probs, deltas, window, config, max_in
     deltas_specific = torch.gather(deltas, 2, idx).squeeze(2)
     refined = coordinate_convert(rois.reshape(-1, 4), deltas_specific.reshape(-1, 4), config).view(B, R, 4)
     # every image is clipped to ITS OWN window (the reference runs one image per call, Functions.py:483)
-    win = utils.const_tensor(np.asarray(window, dtype=np.float32).reshape(-1, 4).tolist(), torch.float32, rois.device)
+    wn = np.asarray(window, dtype=np.float32).reshape(-1, 4)
+    if (wn == wn[:1]).all():       # one window for all images (what mold_inputs produces): a cached device constant
+        win = utils.const_tensor(wn[:1].tolist(), torch.float32, rois.device)
+    else:                          # (distinct windows per image: not cached -- the cache would grow with the data)
+        win = torch.as_tensor(wn, device=rois.device)
     if win.shape[0] not in (1, B):
         raise ValueError("refine_detections_batched: %d windows for %d images" % (win.shape[0], B))
     win = win.expand(B, 4).unsqueeze(1)                      # [B,1,4]
