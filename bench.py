@@ -80,7 +80,7 @@ def _pmc_for(kernel):
         return {}
 
 
-def dominant_kernel_roofline(prof, elapsed, parts):
+def dominant_kernel_roofline(prof, elapsed, parts, replay_traffic=True):
     """Roofline of the dominant kernel (the split-bf16 implicit-GEMM conv), from HIP
     events recorded around every launch inside the timed region, on the launch
     stream.  achieved = algorithmic (fp32-equivalent, 2*MACs) FLOPs / kernel time;
@@ -124,6 +124,8 @@ def dominant_kernel_roofline(prof, elapsed, parts):
                 "frac_of_hbm_peak": round(b_ / t_ / 1e9 / PEAK_HBM_GBS, 4)}
     traffic = None
     try:   # HBM bytes per launch from the committed rocprofv3 PMC passes (not collectable live)
+        if not replay_traffic:      # (the counter passes were collected on the headline workload only)
+            raise KeyError(name)
         pmc = json.load(open(os.path.join(ROOT, PMC_TRAFFIC)))[name]["last_step"]
         traffic = {"replayed": True, "source_commit": _file_commit(PMC_TRAFFIC),
                    "hbm_read_bytes_per_launch_raw": pmc["read_bytes_per_launch_raw"],
@@ -168,7 +170,7 @@ def dominant_kernel_roofline(prof, elapsed, parts):
                                        "frac": round(v[1] / v[0] / 1e12 / peak, 4),
                                        "algorithmic_read_bytes_per_launch": int(v[3] / v[2]),
                                        "algorithmic_write_bytes_per_launch": int(v[4] / v[2])},
-                                      **_pmc_for(k))
+                                      **(_pmc_for(k) if replay_traffic else {}))
                               for k, v in by.items() if k != name}}
 
 
@@ -286,7 +288,7 @@ def main_resnext(args, rank, world, dev):
         conv_hip.PROFILE = []
     barrier()
     t0 = time.perf_counter()
-    losses = [step(i) for i in range(args.steps)]
+    losses = [step(i).detach() for i in range(args.steps)]
     barrier()
     elapsed = time.perf_counter() - t0
     prof, conv_hip.PROFILE = conv_hip.PROFILE, None
@@ -304,14 +306,14 @@ def main_resnext(args, rank, world, dev):
                "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / max(args.steps, 1), 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "roofline": dominant_kernel_roofline(prof, elapsed, conv_hip.PARTS),
+               "roofline": dominant_kernel_roofline(prof, elapsed, conv_hip.PARTS, replay_traffic=False),
                "config": {"workload": "BASELINE.json configs[4]: ResNeXt-101 (3,4,23,3; 32 groups) + ASPP(6,12,18,24) under "
                                       "the multi-scale wrapper (scales 1 / 0.5 / 0.75 + maximum), train step, "
                                       "%d x %dx%d images/GPU, %d classes" % (batch, dim, dim, classes),
                           "images_per_gpu": batch, "image_dim": dim, "parallelism": "dp%d" % world,
                           "conv_operand_format": "2 x scaled fp16 (dense convolutions); grouped 3x3: fp32 direct kernels",
-                          "final_loss": round(float(losses[-1]), 5),
-                          "loss_trace": [round(float(l), 4) for l in losses[:: max(1, len(losses) // 8)]],
+                          "final_loss": round(float(losses[-1].detach()), 5),
+                          "loss_trace": [round(float(l.detach()), 4) for l in losses[:: max(1, len(losses) // 8)]],
                           "max_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
                           "note": "fp32 storage, not the fp16 storage configs[4] names: a wider format than asked"},
                "step_roofline": {"bound": "mfma", "kernel": "whole train step (all kernels)",
