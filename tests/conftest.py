@@ -21,8 +21,10 @@ def pytest_configure(config):
 # dynamics test leaves every parity sweep reported.  Files not listed keep their alphabetical place in between.
 FILE_ORDER = ["test_abi_cpu", "test_oracle_cpu", "test_native_gpu", "test_tail_cpu", "test_tail_gpu",
               "test_optim_gpu", "test_conv_gpu", "test_model_cpu", "test_model_gpu", "test_e2e_gpu",
-              "test_integration_gpu", "test_multistep_gpu", "test_parallel_cpu", "test_parallel_gpu",
-              "test_resnext_cpu", "test_resnext_gpu"]
+              "test_integration_gpu", "test_parallel_cpu", "test_parallel_gpu",
+              "test_resnext_cpu", "test_resnext_gpu", "test_multistep_gpu"]
+# (test_multistep_gpu: parity over several optimiser steps, held to a control replica's behaviour -- after every
+# single-step sweep, so that its tolerances, which live in an amplifying system, cannot hide them either)
 
 
 def _file_rank(item):
