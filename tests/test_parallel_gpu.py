@@ -83,7 +83,7 @@ def _worker(rank, world, port, out):
         # four runs) -- the ReLU-switch tolerance of the e2e tests.  The weights this check is about are the RPN's
         # (five gradients per pass into one slot): they see the FPN maps only, and a lost contribution is an O(1)
         # error.
-        assert err <= (1e-3 if n.startswith("rpn.") else 5e-3), (rank, n, err)
+        assert err <= (1e-5 if n.startswith("rpn.") else 5e-3), (rank, n, err)     # (RPN weights, recorded: <= 1.5e-7)
     print("rank", rank, "sink vs plain mean: worst relative error %.2e (%s); RPN weights %.2e (%s)" %
           (worst[1], worst[0], worst_rpn[1], worst_rpn[0]), flush=True)
     for n in ("rpn.conv_shared.weight", "rpn.conv_class.weight", "rpn.conv_bbox.weight"):
