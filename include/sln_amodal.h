@@ -475,6 +475,10 @@ int sln_conv2d_fwd_ms_f32(const uint16_t *x_parts, int nseg, const int32_t *seg_
 /* Tile edge (128 or 256) of the forward kernel the two functions above use for M output pixels,
  * Cout channels, K = KH*KW*Cin and `parts`: host-side rule, no GPU work (csrc/conv.hip). */
 int sln_conv_fwd_tile(int64_t M, int Cout, int64_t K, int parts);
+/* Which forward kernel the calling thread's last sln_conv2d_fwd*_f32 call launched: 0 conv_fwd_kernel (128 x 128),
+ * 1 conv_fwd256_kernel, 2 conv_fwd256h_kernel, 3 conv_fwd128x256h_kernel (pointwise layers: two blocks per CU).
+ * Profiling labels only. */
+int sln_conv_fwd_last_kernel(void);
 /* Tile edge (128 or 256) of the weight-gradient kernel sln_conv2d_wgrad_f32 uses (host-side rule). */
 int sln_conv_wgrad_tile(int64_t M, int Cout, int Cin, int taps, int parts);
 /* workspace (optional): sln_conv_wgrad_workspace_bytes() bytes lent by the caller make the split-K

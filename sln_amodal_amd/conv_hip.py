@@ -580,8 +580,12 @@ def _prof_end(e0, flops, name, shape="", rd_bytes=0, wr_bytes=0):
         PROFILE.append((e0, e1, flops, name, shape, rd_bytes, wr_bytes))
 
 
-def _fwd_kernel_name(layout, parts):
-    """Name of the kernel sln_conv2d_fwd_ms_f32 launches for a problem with this weight layout."""
+def _fwd_kernel_name(layout, parts, launched=False):
+    """Name of the kernel sln_conv2d_fwd_ms_f32 launches for a problem with this weight layout; launched=True: of the
+    kernel the call just made on this thread DID launch (the library decides between conv_fwd256h_kernel and its
+    128 x 256 sibling per epilogue kind)."""
+    if launched and PROFILE is not None and _lib.lib().sln_conv_fwd_last_kernel() == 3:
+        return "conv_fwd128x256h_kernel"
     if layout == TILED256H:
         return "conv_fwd256h_kernel"
     return ("conv_fwd256_kernel<%d>" if layout == TILED256 else "conv_fwd_kernel<%d>") % parts
@@ -652,7 +656,7 @@ def _fwd(xparts, N, H, W, w, Cout, KH, KW, stride, dil, pt, pl, OH, OW, scale, s
     if mask_parts is not None:
         PO_STATS[2] += 1
     _prof_end(e0, 2.0 * N * OH * OW * Cout * KH * KW * cin,
-              _fwd_kernel_name(layout, P),
+              _fwd_kernel_name(layout, P, launched=True),
               "fwd N%d %dx%d C%d->%d k%d s%d d%d" % (N, H, W, cin, Cout, KH, stride[0], dil[0]),
               _nbytes(xparts, wparts, residual, mask, res_parts[0] if res_parts is not None else None) +
               (_nbytes(mask_parts) // 2 if mask_parts is not None else 0), _nbytes(y, yp))
@@ -764,7 +768,7 @@ def conv_bn_act_ms(x, conv, bn, relu, residual, pads, parts_only=False):
         ops._ptr(y), ops._ptr(yp), None, ops._ptr(xq), ops._ptr(wq),
         *_q3(yslot if yp is not None else None), ops._ptr(rparts), ops._ptr(rq), None, ops._stream()),
         "sln_conv2d_fwd_ms_f32")
-    _prof_end(e0, flops, _fwd_kernel_name(layout, parts),
+    _prof_end(e0, flops, _fwd_kernel_name(layout, parts, launched=True),
               "fwd ms%s C%d->%d k%d s%d d%d" % ("+".join("%dx%d" % (h, w) for _, h, w in x.segs), Ci, Co, KH, sh, dh),
               _nbytes(xp, wp, res, rparts), _nbytes(y, yp))
     if fresh:

@@ -1265,11 +1265,14 @@ __device__ __forceinline__ void w8_compute(const ConvParams &p, const float *sta
 // thread; BEFORE a half's arithmetic and stores the global loads of the NEXT half (of this slab or the next)
 // are issued (w8_load).  Halves, not whole slabs: two sets of a whole slab's residual + mask rows next to the
 // 128 accumulator registers of the wave group whose slabs come last do not fit the 256-register budget.
-template <int NCOL8, int LD, int NTHREADS, int NSLAB, int RES, int MASK, bool FULL, typename StageFn, int DEPTH = 1>
+// (SR: rows per slab, 64 everywhere but in conv_fwd128x256h_kernel, whose 256 threads take 32-row slabs so that a
+// half slab's look-ahead set stays two rows per thread)
+template <int NCOL8, int LD, int NTHREADS, int NSLAB, int RES, int MASK, bool FULL, typename StageFn, int DEPTH = 1,
+          int SR = 64>
 __device__ __forceinline__ void epilogue_tile_w8(const ConvParams &p, const float *stage, int m0, int n0, int t,
                                                  float *s_colsum, float alpha, float yqs, float &amx,
                                                  StageFn stage_slab) {
-    constexpr int NQ = 64 / (NTHREADS / NCOL8);
+    constexpr int NQ = SR / (NTHREADS / NCOL8);
     constexpr int NH = NQ >= 2 ? 2 : 1, NQH = NQ / NH;
     constexpr int NSTEP = NSLAB * NH;               // half slabs of the tile, in order
     // (fp32 residual AND fp32 mask -- a block whose input is an ordinary tensor: rare -- would need 64 more
@@ -1281,7 +1284,7 @@ __device__ __forceinline__ void epilogue_tile_w8(const ConvParams &p, const floa
     W8Pre<NQH, RES, MASK> pre[D + 1];
 #pragma unroll
     for (int i = 0; i < D && i < NSTEP; ++i)
-        w8_load<NCOL8, NTHREADS, NQH, RES, MASK, FULL>(p, m0 + (i / NH) * 64, n0, t, (i % NH) * NQH, pre[i % (D + 1)]);
+        w8_load<NCOL8, NTHREADS, NQH, RES, MASK, FULL>(p, m0 + (i / NH) * SR, n0, t, (i % NH) * NQH, pre[i % (D + 1)]);
 #pragma unroll
     for (int i = 0; i < NSTEP; ++i) {
         const int h = i / NH, u = i % NH;
@@ -1290,9 +1293,9 @@ __device__ __forceinline__ void epilogue_tile_w8(const ConvParams &p, const floa
             __syncthreads();
         }
         if (i + D < NSTEP || D == 0)
-            w8_load<NCOL8, NTHREADS, NQH, RES, MASK, FULL>(p, m0 + ((i + D) / NH) * 64, n0, t, ((i + D) % NH) * NQH,
+            w8_load<NCOL8, NTHREADS, NQH, RES, MASK, FULL>(p, m0 + ((i + D) / NH) * SR, n0, t, ((i + D) % NH) * NQH,
                                                            pre[(i + D) % (D + 1)]);
-        w8_compute<NCOL8, LD, NTHREADS, NQH, RES, MASK, FULL>(p, stage, m0 + h * 64, n0, t, u * NQH, yqs, amx, k,
+        w8_compute<NCOL8, LD, NTHREADS, NQH, RES, MASK, FULL>(p, stage, m0 + h * SR, n0, t, u * NQH, yqs, amx, k,
                                                               pre[i % (D + 1)]);
         if (u == NH - 1) __syncthreads();
     }
@@ -2198,6 +2201,248 @@ __global__ __launch_bounds__(512) void conv_fwd256h_kernel(const ConvParams p) {
             for (int i = 0; i < 16; ++i) sln_stamp_sums[wave * 16 + i] = sums[i];
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// conv_fwd128x256h_kernel (round 4): the 128-row x 256-column sibling of conv_fwd256h_kernel for the launches that
+// the memory system bounds (pointwise layers, K = 256 .. 2048).  conv_fwd256h_kernel holds ONE 8-wave block per CU
+// whose two wave groups share the weight stage and run half a phase apart; all 256 CUs then move through prologue,
+// k-loop and epilogue together, the HBM idles during the k-loops and a tile's epilogue (half of a K = 256 tile's
+// time, tools/epilogue_ablation.py) is never overlapped with anything.  Here a block is ONE such wave group --
+// 4 waves, 128 rows x 256 columns, the same 8 x 4 tiles of v_mfma_f32_16x16x32_f16 per wave, the same weight
+// image -- with 80 KB of LDS, so that TWO blocks are resident per CU and drift apart: one tile's epilogue runs
+// under the other's k-loop, the way the three resident blocks of the 128^2 kernel cover for each other.
+// LDS (81 920 B): three 16-KB activation buffers (128 rows x 64 B x 2 parts; prefetched two stages ahead) and ONE
+// 32-KB weight buffer: all four weight tiles of a stage are read into registers in phase 0 (they are kept for
+// phase 1 anyway), so the buffer is free for stage s + 1 right behind that read -- a barrier, then the refill,
+// which has the rest of the stage to land.  Two barriers per stage.  The price: each block streams its own copy of
+// the weight stage (L2 -> LDS traffic of the weights doubles), which is why the matrix-bound 3x3 launches stay on
+// the 256^2 kernel.  Epilogue: the eight-channel slabs (EPI 1..5 as in conv_fwd256h_kernel), four 32-row slabs.
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void conv_fwd128x256h_kernel(const ConvParams p) {
+    constexpr int P = 2;
+    constexpr int TM = 128;                    // rows of the tile
+    constexpr int REGA = TM * T2H * 2;         // one part of an activation stage: 128 rows x 64 B = 8 KB
+    constexpr int ABUF = P * REGA;             // 16 KB
+    constexpr int REGB = T2 * T2H * 2;         // one part of a weight stage: 256 rows x 64 B = 16 KB
+    constexpr int BBASE = 3 * ABUF;            // 48 KB
+    __shared__ __attribute__((aligned(16))) unsigned char smem[BBASE + P * REGB];   // 81 920 B: two blocks per CU
+    constexpr int SLD = 260;
+    static_assert(32 * SLD * 4 + T2 * 4 + 16 <= BBASE + P * REGB, "staging slab + column sums must fit");
+    float *s_colsum = (float *)(smem + 32 * SLD * 4);
+    unsigned *s_word = (unsigned *)(smem + 32 * SLD * 4 + T2 * 4);
+    const float alpha = operand_unscale(p.x_scale, p.w_scale);
+    const float yqs = p.yq.scale ? *p.yq.scale : 1.f;
+    float amx = 0.f;
+    typedef __attribute__((address_space(3))) void lds_void;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;          // wave = its 64-column strip of the tile
+    const int bid = xcd_remap(blockIdx.x, p.gm * p.gn);
+    const int m0 = (bid / p.gn) * TM;
+    const int n0 = (bid % p.gn) * T2;
+
+    // ---- activation DMA slots of this lane: rows 32*wave + 16*q + lane/4 (q = 0, 1), as in conv_fwd256h_kernel ----
+    int a_ih0[2], a_iw0[2], a_H[2], a_W[2];
+    unsigned a_base[2], a_c0[2];
+    bool a_ok[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int drow = 32 * wave + 16 * q + (lane >> 2);
+        a_c0[q] = (unsigned)(((lane & 3) ^ ((drow >> 2) & 3)) * 8);
+        const int m = m0 + drow;
+        a_ok[q] = m < p.M;
+        int mm = a_ok[q] ? m : 0;
+        int sg = 0;
+        for (int k = 1; k < p.nseg; ++k)
+            if (mm >= p.seg_m0[k]) sg = k;
+        mm -= p.seg_m0[sg];
+        const int OHs = p.segOH[sg], OWs = p.segOW[sg];
+        a_H[q] = p.segH[sg]; a_W[q] = p.segW[sg];
+        const int n = mm / (OHs * OWs);
+        const int rem = mm - n * (OHs * OWs);
+        const int oh = rem / OWs, ow = rem - oh * OWs;
+        a_ih0[q] = oh * p.sh - p.pt;
+        a_iw0[q] = ow * p.sw - p.pl;
+        a_base[q] = (unsigned)(p.seg_x0[sg] + n * a_H[q] * a_W[q]);
+    }
+    const int ncc = (p.Cin + T2H - 1) / T2H;
+    const int ntap = p.KH * p.KW;
+    const int nk = ntap * ncc;
+    const int gfull = ncc / 2;
+    const unsigned x_part_bytes = (unsigned)(p.x_part_stride * 2);
+    const __amdgpu_buffer_rsrc_t rsrc_a0 = __builtin_amdgcn_make_buffer_rsrc((void *)p.x, 0, (int)x_part_bytes,
+                                                                             0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_a1 = __builtin_amdgcn_make_buffer_rsrc((void *)(p.x + p.x_part_stride), 0,
+                                                                             (int)x_part_bytes, 0x00020000);
+    const unsigned w_tile_bytes = (unsigned)nk * P * (T2 * T2H * 2);
+    const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(p.w + (long)(bid % p.gn) * nk * P * (T2 * T2H)), 0, (int)w_tile_bytes, 0x00020000);
+
+    int n_g = 0, n_tap = 0, n_half = 0, n_kh = 0, n_kw = 0, n_s = 0;     // the activation stage to issue next
+    unsigned a_voff[2];
+    auto stage_offsets = [&]() {
+        const int cc = 2 * n_g + n_half;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int ih = a_ih0[q] + n_kh * p.dh, iw = a_iw0[q] + n_kw * p.dw;
+            const unsigned ci = (unsigned)(cc * T2H) + a_c0[q];
+            const bool ok = a_ok[q] && (unsigned)ih < (unsigned)a_H[q] && (unsigned)iw < (unsigned)a_W[q] &&
+                            ci < (unsigned)p.Cin;
+            const unsigned off = ((a_base[q] + (unsigned)(ih * a_W[q] + iw)) * (unsigned)p.Cin + ci) * 2u;
+            a_voff[q] = ok ? off : 0xFFFFFFFFu;
+        }
+    };
+    auto stage_advance = [&]() {
+        ++n_s;
+        if (++n_half == (n_g < gfull ? 2 : 1)) {
+            n_half = 0;
+            ++n_tap;
+            if (++n_kw == p.KW) { n_kw = 0; ++n_kh; }
+            if (n_tap == ntap) { n_tap = 0; n_kh = 0; n_kw = 0; ++n_g; }
+        }
+    };
+    int a_wr = 0, a_rd = 0;
+    auto ring_next = [](int &r) { r = r == 2 ? 0 : r + 1; };
+    // the four activation pieces of stage n_s (offsets in a_voff) into buffer a_wr
+    auto issue_a = [&]() {
+        unsigned char *base = smem + a_wr * ABUF + wave * 2048;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int pp = g >> 1, q = g & 1;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(pp ? rsrc_a1 : rsrc_a0,
+                                                     (lds_void *)(base + pp * REGA + q * 1024), 16, a_voff[q], 0, 0, 0);
+        }
+    };
+    // the eight weight pieces of stage bs: this wave moves the 2-KB slices 2*wave and 2*wave + 1 (of eight) of both
+    // parts of the stage's LDS image
+    auto issue_b = [&](int bs) {
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const int pp = g >> 2, h = (g >> 1) & 1, q = g & 1;
+            const unsigned vw = (unsigned)(2 * wave + h);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                rsrc_b, (lds_void *)(smem + BBASE + pp * REGB + vw * 2048 + q * 1024), 16, vw * 2048u + (unsigned)lane * 16u,
+                (unsigned)(bs * P + pp) * (T2 * T2H * 2) + q * 1024, 0, 0);
+        }
+    };
+
+    f32x4v acc16[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc16[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    const int r16 = lane & 15, c16 = lane >> 4;
+    int a_off16[8], b_off16[4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = 16 * i + r16;
+        a_off16[i] = row * 64 + ((c16 ^ ((row >> 2) & 3)) * 16);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = 64 * wave + 16 * j + r16;
+        b_off16[j] = row * 64 + ((c16 ^ ((row >> 2) & 3)) * 16);
+    }
+
+    // ---- prologue: weight stage 0, activation stages 0 and 1 ----
+    stage_offsets();
+    issue_a();
+    issue_b(0);
+    stage_advance();
+    ring_next(a_wr);
+    if (nk > 1) {
+        stage_offsets();
+        issue_a();
+        stage_advance();
+        ring_next(a_wr);
+        if (nk > 2) stage_offsets();
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // all but the four youngest pieces (activation stage 1)
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    bf16x8 b16[4][P];
+    for (int s = 0; s < nk; ++s) {
+        const unsigned char *stA = smem + a_rd * ABUF;
+        const unsigned char *stB = smem + BBASE;
+        const bool moreB = s + 1 < nk, moreA = s + 2 < nk;      // (n_s == s + 2 when moreA)
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph) {
+            bf16x8 a[4][P];
+            if (ph == 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int pp = 0; pp < P; ++pp) b16[j][pp] = *(const bf16x8 *)(stB + pp * REGB + b_off16[j]);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int pp = 0; pp < P; ++pp)
+                    a[i][pp] = *(const bf16x8 *)(stA + pp * REGA + a_off16[4 * ph + i]);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (ph == 0) {
+                // every wave has the stage's weight tiles in registers: the weight buffer may be refilled.  Weight
+                // pieces first, then the activation pieces two stages ahead (the wait at the end of the stage lets
+                // the four youngest pieces fly on; memory operations complete in order).
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                if (moreB) issue_b(s + 1);
+                if (moreA) issue_a();
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mfma16_products(a[i], b16[j], acc16[4 * ph + i][j]);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ph == 1) {
+                if (moreA) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (moreA) {
+                    stage_advance();
+                    ring_next(a_wr);
+                    if (n_s < nk) stage_offsets();
+                }
+                ring_next(a_rd);
+                // everyone's pieces of stage s + 1 have landed, and everyone is done with activation buffer a_rd - 1
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+            }
+        }
+    }
+
+    // ---- epilogue: four 32-row slabs through LDS ([32][260] floats), eight channels per thread ----
+    float *stage = (float *)smem;
+    if (t < T2) s_colsum[t] = 0.f;            // (ordered by the first slab's barrier)
+    auto stage_slab = [&](int h) {            // rows 32 h .. 32 h + 31 = row tiles 2 h, 2 h + 1 of every wave
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    stage[(ii * 16 + 4 * (lane >> 4) + r) * SLD + wave * 64 + j * 16 + (lane & 15)] =
+                        acc16[2 * h + ii][j][r];
+    };
+    const bool full = m0 + TM <= p.M && n0 + T2 <= p.Cout;          // block-uniform
+#define SLN_W8H(R, K, F) epilogue_tile_w8<32, SLD, 256, 4, R, K, F, decltype(stage_slab), 1, 32>(p, stage, m0, n0, t, s_colsum, alpha, yqs, amx, stage_slab)
+    if (full) {
+        if (EPI == 2) SLN_W8H(2, 0, true); else if (EPI == 3) SLN_W8H(0, 2, true);
+        else if (EPI == 4) SLN_W8H(1, 2, true); else if (EPI == 5) SLN_W8H(1, 0, true); else SLN_W8H(0, 0, true);
+    } else {
+        if (EPI == 2) SLN_W8H(2, 0, false); else if (EPI == 3) SLN_W8H(0, 2, false);
+        else if (EPI == 4) SLN_W8H(1, 2, false); else if (EPI == 5) SLN_W8H(1, 0, false); else SLN_W8H(0, 0, false);
+    }
+#undef SLN_W8H
+    if (p.colsum && t < T2 && n0 + t < p.Cout && s_colsum[t] != 0.f) atomicAdd(p.colsum + n0 + t, s_colsum[t]);
+    if (p.yparts) amax_commit(amx, amx * yqs > SLN_F16_MAX, p.yq, s_word);
 }
 
 // ------------------------------------------------------------ weight gradient
@@ -3144,6 +3389,11 @@ extern "C" int sln_scale_update_f32(float *amax, float *scale, float *history, i
 // when Cout fills >= 176 of the last 256 columns, the tiles come in (nearly) whole rounds of the 256 CUs
 // and K is long enough to amortise the pipeline; else 128.  SLN_CONV_TILE256 = 0 never,
 // 1 (default) by this rule, 2 always (tests); read on every call.
+// Which forward kernel the last sln_conv2d_fwd*_f32 call of this thread launched (profiling labels): 0 the 128^2
+// kernel, 1 conv_fwd256_kernel, 2 conv_fwd256h_kernel, 3 conv_fwd128x256h_kernel.
+static thread_local int sln_last_fwd_kernel = 0;
+extern "C" int sln_conv_fwd_last_kernel(void) { return sln_last_fwd_kernel; }
+
 extern "C" int sln_conv_fwd_tile(int64_t M, int Cout, int64_t K, int parts) {
     const int mode = sln_knob("SLN_CONV_TILE256", 1);
     if (M < 1 || Cout < 1 || M > 2147483647L - T2) return BM;
@@ -3231,6 +3481,7 @@ extern "C" int sln_conv2d_fwd_ms_f32(const uint16_t *x_parts, int nseg, const in
     }
     const long gm2 = sln_div_up(M, T2), gn2 = sln_div_up(Cout, T2);
     const long nb2 = gm2 * gn2;
+    sln_last_fwd_kernel = use256 ? (w_layout == SLN_WEIGHTS_TILED256H ? 2 : 1) : 0;
     if (use256) {
         p.gm = (int)gm2; p.gn = (int)gn2;
         if (w_layout == SLN_WEIGHTS_TILED256H) {
@@ -3243,6 +3494,27 @@ extern "C" int sln_conv2d_fwd_ms_f32(const uint16_t *x_parts, int nseg, const in
                 // the instance that carries only the epilogue this launch needs (SLN_CONV_EPI=0: the all-in-one instance)
                 const bool w8 = epilogue_is_plain(p) && !(p.dbg & 16) && epilogue_is_w8(p) && !(p.dbg & 256) &&
                                 sln_knob("SLN_CONV_EPI", 1) != 0;
+                // pointwise layers whose epilogue ADDS A SHORTCUT (forward expand convolutions, the block-input data
+                // gradients): the 128 x 256 kernel, two blocks per CU at different phases.  Same-box table
+                // (profiles/r4_l_hbm_layers_128x256.txt): K = 256 -> 1024 with a parts / fp32 shortcut -11 %, with
+                // shortcut + mask -15 %, C5's 512 -> 2048 -9 ... -17 %; WITHOUT a shortcut the tile's epilogue is
+                // short and the second copy of the weight stream costs more than the overlap returns (K = 1024 ->
+                // 256 parts-only +16 %): those stay on the 256^2 kernel.  SLN_CONV_TILE128H: 0 never, 2 whenever the
+                // eight-channel epilogue applies (tests: also 3x3).
+                const int k128 = sln_knob("SLN_CONV_TILE128H", 1);
+                if (w8 && (k128 == 2 || (k128 == 1 && KH * KW == 1 && (p.res_parts || p.residual)))) {
+                    const long gm1 = sln_div_up(M, 128);
+                    if (gm1 * gn2 > 2147483647L) return SLN_ERR_UNSUPPORTED;
+                    p.gm = (int)gm1;
+                    const dim3 g1((unsigned)(gm1 * gn2)), b1(256);
+                    sln_last_fwd_kernel = 3;
+                    if (p.res_parts) hipLaunchKernelGGL((conv_fwd128x256h_kernel<2>), g1, b1, 0, (hipStream_t)stream, p);
+                    else if (p.residual && p.mask_part0) hipLaunchKernelGGL((conv_fwd128x256h_kernel<4>), g1, b1, 0, (hipStream_t)stream, p);
+                    else if (p.residual) hipLaunchKernelGGL((conv_fwd128x256h_kernel<5>), g1, b1, 0, (hipStream_t)stream, p);
+                    else if (p.mask_part0) hipLaunchKernelGGL((conv_fwd128x256h_kernel<3>), g1, b1, 0, (hipStream_t)stream, p);
+                    else hipLaunchKernelGGL((conv_fwd128x256h_kernel<1>), g1, b1, 0, (hipStream_t)stream, p);
+                    return sln_launch_status();
+                }
                 if (!w8) hipLaunchKernelGGL((conv_fwd256h_kernel<false, 2, 16>), g2, b2, 0, (hipStream_t)stream, p);
                 else if (p.res_parts) hipLaunchKernelGGL((conv_fwd256h_kernel<false, 2, 16, 2>), g2, b2, 0, (hipStream_t)stream, p);
                 else if (p.residual && p.mask_part0) hipLaunchKernelGGL((conv_fwd256h_kernel<false, 2, 16, 4>), g2, b2, 0, (hipStream_t)stream, p);
