@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libsln_amodal_hip.so")
+# (SLN_HIP_LIB: another build of the same library, for A/B runs of compile-time variants -- debug sessions)
+LIB_PATH = os.environ.get("SLN_HIP_LIB") or os.path.join(_HERE, "csrc", "libsln_amodal_hip.so")
 _lib = None
 
 _p = C.c_void_p

@@ -2218,6 +2218,12 @@ __global__ __launch_bounds__(512) void conv_fwd256h_kernel(const ConvParams p) {
 // which has the rest of the stage to land.  Two barriers per stage.  The price: each block streams its own copy of
 // the weight stage (L2 -> LDS traffic of the weights doubles), which is why the matrix-bound 3x3 launches stay on
 // the 256^2 kernel.  Epilogue: the eight-channel slabs (EPI 1..5 as in conv_fwd256h_kernel), four 32-row slabs.
+#ifndef SLN_128H_SLAB_ROWS
+#define SLN_128H_SLAB_ROWS 32      // (64: half the barriers, twice the look-ahead registers -- measured)
+#endif
+#ifndef SLN_128H_DEPTH
+#define SLN_128H_DEPTH 1
+#endif
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void conv_fwd128x256h_kernel(const ConvParams p) {
     constexpr int P = 2;
@@ -2228,9 +2234,10 @@ __global__ __launch_bounds__(256, 2) void conv_fwd128x256h_kernel(const ConvPara
     constexpr int BBASE = 3 * ABUF;            // 48 KB
     __shared__ __attribute__((aligned(16))) unsigned char smem[BBASE + P * REGB];   // 81 920 B: two blocks per CU
     constexpr int SLD = 260;
-    static_assert(32 * SLD * 4 + T2 * 4 + 16 <= BBASE + P * REGB, "staging slab + column sums must fit");
-    float *s_colsum = (float *)(smem + 32 * SLD * 4);
-    unsigned *s_word = (unsigned *)(smem + 32 * SLD * 4 + T2 * 4);
+    constexpr int SRH = SLN_128H_SLAB_ROWS;    // rows per epilogue slab
+    static_assert(SRH * SLD * 4 + T2 * 4 + 16 <= BBASE + P * REGB, "staging slab + column sums must fit");
+    float *s_colsum = (float *)(smem + SRH * SLD * 4);
+    unsigned *s_word = (unsigned *)(smem + SRH * SLD * 4 + T2 * 4);
     const float alpha = operand_unscale(p.x_scale, p.w_scale);
     const float yqs = p.yq.scale ? *p.yq.scale : 1.f;
     float amx = 0.f;
@@ -2421,18 +2428,18 @@ __global__ __launch_bounds__(256, 2) void conv_fwd128x256h_kernel(const ConvPara
     // ---- epilogue: four 32-row slabs through LDS ([32][260] floats), eight channels per thread ----
     float *stage = (float *)smem;
     if (t < T2) s_colsum[t] = 0.f;            // (ordered by the first slab's barrier)
-    auto stage_slab = [&](int h) {            // rows 32 h .. 32 h + 31 = row tiles 2 h, 2 h + 1 of every wave
+    auto stage_slab = [&](int h) {            // rows SRH h .. SRH (h + 1) - 1 = SRH / 16 row tiles of every wave
 #pragma unroll
-        for (int ii = 0; ii < 2; ++ii)
+        for (int ii = 0; ii < SRH / 16; ++ii)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     stage[(ii * 16 + 4 * (lane >> 4) + r) * SLD + wave * 64 + j * 16 + (lane & 15)] =
-                        acc16[2 * h + ii][j][r];
+                        acc16[(SRH / 16) * h + ii][j][r];
     };
     const bool full = m0 + TM <= p.M && n0 + T2 <= p.Cout;          // block-uniform
-#define SLN_W8H(R, K, F) epilogue_tile_w8<32, SLD, 256, 4, R, K, F, decltype(stage_slab), 1, 32>(p, stage, m0, n0, t, s_colsum, alpha, yqs, amx, stage_slab)
+#define SLN_W8H(R, K, F) epilogue_tile_w8<32, SLD, 256, TM / SRH, R, K, F, decltype(stage_slab), SLN_128H_DEPTH, SRH>(p, stage, m0, n0, t, s_colsum, alpha, yqs, amx, stage_slab)
     if (full) {
         if (EPI == 2) SLN_W8H(2, 0, true); else if (EPI == 3) SLN_W8H(0, 2, true);
         else if (EPI == 4) SLN_W8H(1, 2, true); else if (EPI == 5) SLN_W8H(1, 0, true); else SLN_W8H(0, 0, true);
