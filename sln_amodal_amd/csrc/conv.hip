@@ -2352,6 +2352,13 @@ __global__ __launch_bounds__(256, 2) void conv_fwd128x256h_kernel(const ConvPara
         b_off16[j] = row * 64 + ((c16 ^ ((row >> 2) & 3)) * 16);
     }
 
+    // (experiment, dbg 524288: the blocks that are dealt to the SECOND slot of a CU -- blockIdx / 8 / 32 odd, as far
+    // as the dispatcher deals blocks round-robin over XCDs, then CUs -- start half a stage late, so that the two
+    // blocks of a CU begin out of phase: one multiplies while the other reads its fragments)
+    if ((p.dbg & 524288) && (((blockIdx.x >> 3) >> 5) & 1)) {
+        const int n = (p.dbg >> 20) & 15;
+        for (int i = 0; i <= n; ++i) __builtin_amdgcn_s_sleep(8);      // 8 x 64 = 512 cycles each
+    }
     // ---- prologue: weight stage 0, activation stages 0 and 1 ----
     stage_offsets();
     issue_a();
