@@ -31,7 +31,7 @@ def load(d, counter):
 
 
 def label(name):
-    m = re.search(r"(conv_fwd256h_kernel|conv_wgrad256h_kernel|conv_fwd256_kernel<\d>|conv_wgrad256_kernel<\d>|"
+    m = re.search(r"(conv_fwd128x256h_kernel|conv_fwd256h_kernel|conv_wgrad256h_kernel|conv_fwd256_kernel<\d>|conv_wgrad256_kernel<\d>|"
                   r"conv_fwd_kernel<\d|conv_wgrad_kernel<\d|grad_prep_kernel|act_split_kernel|wgrad_reduce_kernel|"
                   r"pyr_fwd_kernel|pyr_bwd_patch_kernel)", name)
     if not m:
