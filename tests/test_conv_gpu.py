@@ -1013,3 +1013,75 @@ def test_strided_sibling_data_gradients_share_one_lattice_map():
     scale = xd.grad.abs().max().item()
     assert (grads[0].double() - xd.grad).abs().max().item() / scale < 5e-5
     assert (grads[0] - grads[1]).abs().max().item() / scale < 1e-6
+
+
+@pytest.mark.parametrize("shape", [
+    # N, H, W, Cin, Cout, k, dil: pointwise with whole tiles; ragged rows (M % 128 != 0) and columns; 3x3; K of one stage
+    (4, 64, 64, 256, 1024, 1, 1), (3, 37, 41, 256, 256, 1, 1), (2, 33, 33, 1024, 200, 1, 1), (2, 40, 40, 64, 256, 3, 1),
+    (5, 16, 16, 32, 256, 1, 1)])
+@pytest.mark.parametrize("kind", ["parts", "res16", "res32", "res32+mask16", "mask16+colsum"])
+def test_tile128x256_kernel_equals_the_256_kernel_bit_for_bit(shape, kind, tile_mode):
+    """conv_fwd128x256h_kernel (two 4-wave blocks per CU, one weight buffer refilled behind a barrier, activation stages
+    two ahead) walks K in the same stage order with the same MFMA sequence per output element as conv_fwd256h_kernel
+    and runs the same eight-channel epilogue: every output -- fp32, both parts -- must be BIT-identical between the
+    two kernels (the column sums, added tile by tile, to fp32 rounding), for every epilogue kind, on whole and ragged tiles; and 30 launches of the same
+    problem must reproduce themselves (a race in the hand-synchronised DMA rings shows up as a difference)."""
+    import os
+    from sln_amodal_amd import conv_hip
+    N, H, W, Cin, Cout, k, dil = shape
+    g = torch.Generator(device="cuda").manual_seed(H * 17 + Cin + len(kind))
+    x = torch.randn(N, Cin, H, W, device="cuda", generator=g).contiguous(memory_format=torch.channels_last)
+    w = torch.randn(Cout, Cin, k, k, device="cuda", generator=g) / (Cin * k * k) ** 0.5
+    res = torch.randn(N, Cout, H, W, device="cuda", generator=g).contiguous(memory_format=torch.channels_last)
+    sc = torch.rand(Cout, device="cuda", generator=g) + 0.5
+    sf = torch.randn(Cout, device="cuda", generator=g)
+    pad = dil * (k - 1) // 2
+    xp, xq = conv_hip.act_parts(x, 2)
+    rp, rq = conv_hip.act_parts(res, 2)
+    slot = conv_hip._slot(w, ("y128", H, W, kind))
+    A = (xp, N, H, W, conv_hip.wsrc(w, 2), Cout, k, k, (1, 1), (dil, dil), pad, pad, H, W)
+    tile_mode(2)
+    for _ in range(2):       # bootstrap the output's scale slot with a plain launch
+        conv_hip._fwd(*A, sc, sf, None, True, cin=Cin, out_parts=True, yslot=slot, xq=xq)
+    run = {
+        "parts": lambda: conv_hip._fwd(*A, sc, sf, None, True, cin=Cin, out_parts=True, want_y=False, yslot=slot, xq=xq),
+        "res16": lambda: conv_hip._fwd(*A, sc, sf, None, True, cin=Cin, out_parts=True, want_y=False, yslot=slot, xq=xq,
+                                       res_parts=(rp, rq)),
+        "res32": lambda: conv_hip._fwd(*A, sc, sf, res, True, cin=Cin, out_parts=True, yslot=slot, xq=xq),
+        "res32+mask16": lambda: conv_hip._fwd(*A, None, None, res, False, cin=Cin, out_parts=True, want_y=True,
+                                              want_colsum=True, post_scale=sc, yslot=slot, xq=xq, mask_parts=rp),
+        "mask16+colsum": lambda: conv_hip._fwd(*A, sc, None, None, False, cin=Cin, out_parts=True, want_y=False,
+                                               want_colsum=True, yslot=slot, xq=xq, mask_parts=rp),
+    }[kind]
+
+    def outputs():
+        r = run()
+        r = r if isinstance(r, tuple) else (r, getattr(r, "_sln_parts", (None, None))[1], None)
+        return [t.clone() for t in r if t is not None]
+
+    saved = os.environ.get("SLN_CONV_TILE128H")
+    try:
+        os.environ["SLN_CONV_TILE128H"] = "0"
+        want = outputs()
+        assert conv_hip._lib.lib().sln_conv_fwd_last_kernel() == 2
+        os.environ["SLN_CONV_TILE128H"] = "2"
+        got = outputs()
+        assert conv_hip._lib.lib().sln_conv_fwd_last_kernel() == 3      # the launch went to the new kernel
+        assert len(got) == len(want)
+
+        def same(a, b):
+            # the per-channel column sums are added tile by tile (LDS, then one global atomic per tile and column):
+            # another tile height is another summation order -- fp32 rounding apart, not bit-equal
+            if a.dim() == 1:
+                return bool(torch.allclose(a, b, rtol=2e-5, atol=2e-5 * float(b.abs().max())))
+            return torch.equal(a, b)
+        for a, b in zip(got, want):
+            assert same(a, b)
+        for _ in range(30):
+            again = outputs()
+            assert all(same(a, b) for a, b in zip(again, got))
+    finally:
+        if saved is None:
+            os.environ.pop("SLN_CONV_TILE128H", None)
+        else:
+            os.environ["SLN_CONV_TILE128H"] = saved
