@@ -68,6 +68,9 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 #define SLN_F16_MAX 65504.0f
 #ifndef SLN_W8_DEPTH
 #define SLN_W8_DEPTH 2      // half slabs of residual / mask rows in flight ahead, single-epilogue instances of the 256^2 kernel
+#ifndef SLN_W8_DOUBLE_STAGE
+#define SLN_W8_DOUBLE_STAGE 1   // two staging slabs in the epilogues of the kernels that own the CU's LDS (0: one, A/B builds)
+#endif
 #endif
 
 struct SplitScale {
@@ -1267,8 +1270,12 @@ __device__ __forceinline__ void w8_compute(const ConvParams &p, const float *sta
 // 128 accumulator registers of the wave group whose slabs come last do not fit the 256-register budget.
 // (SR: rows per slab, 64 everywhere but in conv_fwd128x256h_kernel, whose 256 threads take 32-row slabs so that a
 // half slab's look-ahead set stays two rows per thread)
+// (DBOFF > 0: a SECOND staging slab DBOFF floats behind the first -- the kernels that own their CU's LDS in the
+// epilogue.  Slab h + 1 is staged (stage_slab(h + 1, buffer)) at the head of slab h's work, into the buffer slab
+// h - 1 was read from: one barrier per slab instead of two, and the staging -- which only the waves that hold the
+// slab's accumulators do -- runs beside the other waves' arithmetic.)
 template <int NCOL8, int LD, int NTHREADS, int NSLAB, int RES, int MASK, bool FULL, typename StageFn, int DEPTH = 1,
-          int SR = 64>
+          int SR = 64, int DBOFF = 0>
 __device__ __forceinline__ void epilogue_tile_w8(const ConvParams &p, const float *stage, int m0, int n0, int t,
                                                  float *s_colsum, float alpha, float yqs, float &amx,
                                                  StageFn stage_slab) {
@@ -1285,18 +1292,26 @@ __device__ __forceinline__ void epilogue_tile_w8(const ConvParams &p, const floa
 #pragma unroll
     for (int i = 0; i < D && i < NSTEP; ++i)
         w8_load<NCOL8, NTHREADS, NQH, RES, MASK, FULL>(p, m0 + (i / NH) * SR, n0, t, (i % NH) * NQH, pre[i % (D + 1)]);
+    if constexpr (DBOFF > 0) {
+        stage_slab(0, 0);
+        __syncthreads();
+    }
 #pragma unroll
     for (int i = 0; i < NSTEP; ++i) {
         const int h = i / NH, u = i % NH;
-        if (u == 0) {
-            stage_slab(h);
-            __syncthreads();
+        if constexpr (DBOFF > 0) {
+            if (u == 0 && h + 1 < NSLAB) stage_slab(h + 1, (h + 1) & 1);
+        } else {
+            if (u == 0) {
+                stage_slab(h);
+                __syncthreads();
+            }
         }
         if (i + D < NSTEP || D == 0)
             w8_load<NCOL8, NTHREADS, NQH, RES, MASK, FULL>(p, m0 + ((i + D) / NH) * SR, n0, t, ((i + D) % NH) * NQH,
                                                            pre[(i + D) % (D + 1)]);
-        w8_compute<NCOL8, LD, NTHREADS, NQH, RES, MASK, FULL>(p, stage, m0 + h * SR, n0, t, u * NQH, yqs, amx, k,
-                                                              pre[i % (D + 1)]);
+        w8_compute<NCOL8, LD, NTHREADS, NQH, RES, MASK, FULL>(p, stage + (DBOFF > 0 ? (h & 1) * DBOFF : 0), m0 + h * SR,
+                                                              n0, t, u * NQH, yqs, amx, k, pre[i % (D + 1)]);
         if (u == NH - 1) __syncthreads();
     }
     if (p.colsum && n0 + 8 * (t & (NCOL8 - 1)) < p.Cout) {   // the row groups share a column: combine in LDS
@@ -1819,8 +1834,11 @@ __global__ __launch_bounds__(512) void conv_fwd256h_kernel(const ConvParams p) {
     // live in the (by then idle) weight ring during the epilogue.  dbg 4096: one stage ahead, as before (A/B).
     constexpr int BBASE = 3 * OBUF;
     __shared__ __attribute__((aligned(16))) unsigned char smem[5 * OBUF];   // ONE LDS object: 163 840 B
-    float *s_colsum = (float *)(smem + BBASE);
-    unsigned *s_word = (unsigned *)(smem + BBASE + T2 * 4);
+    // epilogue: two staging slabs of [64][260] floats (133 120 B), then the column sums and the amax word
+    constexpr int SLAB_FLOATS = 64 * 260;
+    static_assert(2 * SLAB_FLOATS * 4 + T2 * 4 + 16 <= 5 * OBUF, "two staging slabs + column sums must fit");
+    float *s_colsum = (float *)(smem + 2 * SLAB_FLOATS * 4);
+    unsigned *s_word = (unsigned *)(smem + 2 * SLAB_FLOATS * 4 + T2 * 4);
     const float alpha = operand_unscale(p.x_scale, p.w_scale);
     const float yqs = p.yq.scale ? *p.yq.scale : 1.f;
     float amx = 0.f;
@@ -2120,7 +2138,7 @@ __global__ __launch_bounds__(512) void conv_fwd256h_kernel(const ConvParams p) {
     SLN_STAMP(ts_loop1);
     if (wr == 0 && stagger) __builtin_amdgcn_s_barrier();      // re-align the two groups
     __syncthreads();
-    if (t < T2) s_colsum[t] = 0.f;      // (in the idle weight ring; ordered by the epilogue's first barrier)
+    if (t < T2) s_colsum[t] = 0.f;      // (behind the staging slabs; ordered by the epilogue's first barrier)
     if (p.dbg & 32768) {                 // ablation: prologue + k-loop only (one word per lane keeps the MFMAs alive)
         if (MS == 16) { if (acc16[0][0][0] == 12345.678f && acc16[7][3][3] == 1.f) p.y[t] = 0.f; }
         else if (acc[0][0][0] == 12345.678f) p.y[t] = 0.f;
@@ -2129,10 +2147,10 @@ __global__ __launch_bounds__(512) void conv_fwd256h_kernel(const ConvParams p) {
 
     // ---- epilogue: four 64-row slabs through LDS ([64][260] floats), as in conv_fwd256_kernel ----
     float *stage = (float *)smem;
-    static_assert(64 * 260 * 4 <= BBASE, "staging slab must fit below the column sums");
     const bool plain = epilogue_is_plain(p) && !(p.dbg & 16);      // (dbg 16: A/B against epilogue_slab)
     SLN_STAMP(t0);
-    auto stage_slab = [&](int h) {
+    auto stage_slab = [&](int h, int buf = 0) {       // buf: which of the two staging slabs (eight-channel tiles)
+        float *dst = stage + buf * SLAB_FLOATS;
         if (wr == (h >> 1)) {
             if (MS == 16) {      // C layout of 16x16: column lane % 16, rows 4 * (lane / 16) + r
 #pragma unroll
@@ -2141,7 +2159,7 @@ __global__ __launch_bounds__(512) void conv_fwd256h_kernel(const ConvParams p) {
                     for (int j = 0; j < 4; ++j)
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
-                            stage[(ii * 16 + 4 * (lane >> 4) + r) * 260 + wc * 64 + j * 16 + (lane & 15)] =
+                            dst[(ii * 16 + 4 * (lane >> 4) + r) * 260 + wc * 64 + j * 16 + (lane & 15)] =
                                 acc16[4 * (h & 1) + ii][j][r];
             } else {
 #pragma unroll
@@ -2150,14 +2168,14 @@ __global__ __launch_bounds__(512) void conv_fwd256h_kernel(const ConvParams p) {
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        stage[(ii * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 260 + wc * 64 + j * 32 +
+                        dst[(ii * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 260 + wc * 64 + j * 32 +
                               (lane & 31)] = acc[2 * (h & 1) + ii][j][r];
             }
         }
     };
     if (EPI > 0) {
         const bool full = m0 + T2 <= p.M && n0 + T2 <= p.Cout;          // block-uniform
-#define SLN_W8E(R, K, F) epilogue_tile_w8<32, 260, 512, 4, R, K, F, decltype(stage_slab), SLN_W8_DEPTH>(p, stage, m0, n0, t, s_colsum, alpha, yqs, amx, stage_slab)
+#define SLN_W8E(R, K, F) epilogue_tile_w8<32, 260, 512, 4, R, K, F, decltype(stage_slab), SLN_W8_DEPTH, 64, SLN_W8_DOUBLE_STAGE * SLAB_FLOATS>(p, stage, m0, n0, t, s_colsum, alpha, yqs, amx, stage_slab)
         if (full) {
             if (EPI == 2) SLN_W8E(2, 0, true); else if (EPI == 3) SLN_W8E(0, 2, true);
             else if (EPI == 4) SLN_W8E(1, 2, true); else if (EPI == 5) SLN_W8E(1, 0, true); else SLN_W8E(0, 0, true);
@@ -2235,9 +2253,10 @@ __global__ __launch_bounds__(256, 2) void conv_fwd128x256h_kernel(const ConvPara
     __shared__ __attribute__((aligned(16))) unsigned char smem[BBASE + P * REGB];   // 81 920 B: two blocks per CU
     constexpr int SLD = 260;
     constexpr int SRH = SLN_128H_SLAB_ROWS;    // rows per epilogue slab
-    static_assert(SRH * SLD * 4 + T2 * 4 + 16 <= BBASE + P * REGB, "staging slab + column sums must fit");
-    float *s_colsum = (float *)(smem + SRH * SLD * 4);
-    unsigned *s_word = (unsigned *)(smem + SRH * SLD * 4 + T2 * 4);
+    constexpr int SLABF = SRH * SLD;           // floats of one staging slab; two of them, then the column sums
+    static_assert(2 * SLABF * 4 + T2 * 4 + 16 <= BBASE + P * REGB, "staging slabs + column sums must fit");
+    float *s_colsum = (float *)(smem + 2 * SLABF * 4);
+    unsigned *s_word = (unsigned *)(smem + 2 * SLABF * 4 + T2 * 4);
     const float alpha = operand_unscale(p.x_scale, p.w_scale);
     const float yqs = p.yq.scale ? *p.yq.scale : 1.f;
     float amx = 0.f;
@@ -2435,18 +2454,19 @@ __global__ __launch_bounds__(256, 2) void conv_fwd128x256h_kernel(const ConvPara
     // ---- epilogue: four 32-row slabs through LDS ([32][260] floats), eight channels per thread ----
     float *stage = (float *)smem;
     if (t < T2) s_colsum[t] = 0.f;            // (ordered by the first slab's barrier)
-    auto stage_slab = [&](int h) {            // rows SRH h .. SRH (h + 1) - 1 = SRH / 16 row tiles of every wave
+    auto stage_slab = [&](int h, int buf = 0) {     // rows SRH h .. SRH (h + 1) - 1 = SRH / 16 row tiles of every wave
+        float *dst = stage + buf * SLABF;
 #pragma unroll
         for (int ii = 0; ii < SRH / 16; ++ii)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    stage[(ii * 16 + 4 * (lane >> 4) + r) * SLD + wave * 64 + j * 16 + (lane & 15)] =
+                    dst[(ii * 16 + 4 * (lane >> 4) + r) * SLD + wave * 64 + j * 16 + (lane & 15)] =
                         acc16[(SRH / 16) * h + ii][j][r];
     };
     const bool full = m0 + TM <= p.M && n0 + T2 <= p.Cout;          // block-uniform
-#define SLN_W8H(R, K, F) epilogue_tile_w8<32, SLD, 256, TM / SRH, R, K, F, decltype(stage_slab), SLN_128H_DEPTH, SRH>(p, stage, m0, n0, t, s_colsum, alpha, yqs, amx, stage_slab)
+#define SLN_W8H(R, K, F) epilogue_tile_w8<32, SLD, 256, TM / SRH, R, K, F, decltype(stage_slab), SLN_128H_DEPTH, SRH, SLN_W8_DOUBLE_STAGE * SLABF>(p, stage, m0, n0, t, s_colsum, alpha, yqs, amx, stage_slab)
     if (full) {
         if (EPI == 2) SLN_W8H(2, 0, true); else if (EPI == 3) SLN_W8H(0, 2, true);
         else if (EPI == 4) SLN_W8H(1, 2, true); else if (EPI == 5) SLN_W8H(1, 0, true); else SLN_W8H(0, 0, true);
