@@ -41,6 +41,11 @@ FUSE_CROP_GRADS = os.environ.get("SLN_FUSE_CROP_GRADS", "1") != "0"
 # "1" enables it (measured in DESIGN.md section 13); off by default: every kernel's own duration stretches when it
 # shares the chip, which the per-kernel roofline of bench.py would read as a slower kernel.
 GLM_STREAM = os.environ.get("SLN_GLM_STREAM", "0") == "1"
+# "2": the other way round -- the GLM stays on the main stream, BEHIND the backbone / FPN / RPN forward, and the
+# proposal front end (top-k, decode, NMS) + target generation + the dead-end image crop -- ~150 small, latency-bound
+# launches that leave the chip idle -- run on a second stream beside it.  The convolution launches then share the
+# chip with kernels that occupy a few CUs for a few microseconds: their own durations hardly move.
+TARGETS_STREAM = os.environ.get("SLN_GLM_STREAM", "0") == "2"
 
 LAYER_REGEX = {
     "new": r"(fpn.C1.*)|(classifier.*)|(mask.*)|(layer_decoder.*)|(rpn.*)",
@@ -276,6 +281,9 @@ class MaskRCNN(nn.Module):
             # lockstep: a detect() / validation pass may run on one rank alone)
             conv_hip.update_scales(sync=(mode == "training" and torch.is_grad_enabled()))
         B, _, H, W = molded_images.shape
+        if TARGETS_STREAM and molded_images.is_cuda and mode == "training" and \
+                not (priorities and "rpn_rois" in priorities):
+            return self._predict_training_forked(input, priorities)
         glm_side = None
         if GLM_STREAM and molded_images.is_cuda:
             main = torch.cuda.current_stream(molded_images.device)
@@ -307,6 +315,15 @@ class MaskRCNN(nn.Module):
             return self._predict_inference(rpn_rois, num_rois, mrcnn_feature_maps, probs,
                                            image_metas, scale)
 
+        tgt, rois, roi_valid, box_ind, image_path = self._training_targets(
+            rpn_rois, num_rois, input, scale, molded_images, priorities)
+        return self._training_heads(molded_images, probs, gloable_lab, maps, rpn_class_logits, rpn_bbox, rpn_rois,
+                                    num_rois, tgt, rois, roi_valid, box_ind, image_path)
+
+    def _training_targets(self, rpn_rois, num_rois, input, scale, molded_images, priorities):
+        """Detection targets of the sampled rois + the dead-end image crop (model.py:630-663)."""
+        cfg = self.config
+        B = molded_images.shape[0]
         gt_class_ids, gt_boxes, gt_layer = input[2], input[3], input[4]
         gt_boxes = gt_boxes / scale
         labels = gt_layer if gt_layer.dim() == 3 else None
@@ -323,6 +340,14 @@ class MaskRCNN(nn.Module):
         # dead-end crop the reference computes for its (absent) refine net (model.py:651-663)
         image_path = pyramid_roi_align_image([rois, molded_images.contiguous()], 32, cfg.IMAGE_SHAPE,
                                              istrain=True, box_ind=box_ind).detach() / 140.0
+        return tgt, rois, roi_valid, box_ind, image_path
+
+    def _training_heads(self, molded_images, probs, gloable_lab, maps, rpn_class_logits, rpn_bbox, rpn_rois, num_rois,
+                        tgt, rois, roi_valid, box_ind, image_path):
+        """GLM crop, classifier and mask heads on the sampled rois -> the training outputs (model.py:664-700)."""
+        cfg = self.config
+        mrcnn_feature_maps = maps[:4]
+        B, R = rois.shape[0], rois.shape[1]
         # cropped into the head of the mask head's 439-channel input buffer (no torch.cat later)
         GLM_feature = pyramid_roi_align_image([rois, probs], cfg.MASK_POOL_SIZE, (65, 65), istrain=True,
                                               box_ind=box_ind, cat_extra=256)
@@ -351,6 +376,35 @@ class MaskRCNN(nn.Module):
             "image_path": image_path, "gloable_lab": gloable_lab, "num_rois": num_rois,
             "rpn_rois": rpn_rois,
         }
+
+    def _predict_training_forked(self, input, priorities):
+        """predict(mode='training') with the proposal front end and the target generation on a second stream beside
+        the GLM's forward (SLN_GLM_STREAM=2, see TARGETS_STREAM)."""
+        cfg = self.config
+        molded_images = input[0]
+        B, _, H, W = molded_images.shape
+        main = torch.cuda.current_stream(molded_images.device)
+        side = getattr(self, "_glm_stream", None)
+        if side is None:
+            side = self._glm_stream = torch.cuda.Stream(device=molded_images.device)
+        maps, rpn_class_logits, rpn_class, rpn_bbox = self.rpn_forward(molded_images)
+        side.wait_stream(main)                       # the RPN outputs are complete
+        with torch.cuda.stream(side):
+            rpn_rois, num_rois = proposal_layer([rpn_class, rpn_bbox], proposal_count=cfg.POST_NMS_ROIS_TRAINING,
+                                                nms_threshold=cfg.RPN_NMS_THRESHOLD,
+                                                anchors=self.anchors, config=cfg, return_counts=True)
+            scale = utils.const_tensor([H, W, H, W], torch.float32, molded_images.device)
+            tgt, rois, roi_valid, box_ind, image_path = self._training_targets(
+                rpn_rois, num_rois, input, scale, molded_images, priorities)
+        for t_ in (rpn_class, rpn_bbox, molded_images):
+            t_.record_stream(side)
+        probs, gloable_lab = self.glm_probs(molded_images)
+        main.wait_stream(side)
+        for t_ in [rpn_rois, num_rois, rois, roi_valid, box_ind, image_path] + \
+                [v for v in tgt.values() if torch.is_tensor(v)]:
+            t_.record_stream(main)                   # allocated on the side stream, read on the main one from here on
+        return self._training_heads(molded_images, probs, gloable_lab, maps, rpn_class_logits, rpn_bbox, rpn_rois,
+                                    num_rois, tgt, rois, roi_valid, box_ind, image_path)
 
     def _predict_inference(self, rpn_rois, num_rois, maps, probs, image_metas, scale):
         """Inference tail (model.py:576-628) for B images at once, fixed capacity, no device -> host copy:
