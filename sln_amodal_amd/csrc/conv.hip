@@ -2378,6 +2378,17 @@ __global__ __launch_bounds__(256, 2) void conv_fwd128x256h_kernel(const ConvPara
         const int n = (p.dbg >> 20) & 15;
         for (int i = 0; i <= n; ++i) __builtin_amdgcn_s_sleep(8);      // 8 x 64 = 512 cycles each
     }
+    // (experiment, dbg bits 24..26: the two blocks of a CU get DIFFERENT priorities for their MFMA clusters, so that
+    // when both want the matrix pipe one of them takes it whole and the other reads its fragments meanwhile -- the
+    // half-phase offset conv_fwd256h_kernel enforces with a barrier.  Which blocks share a CU is the dispatcher's
+    // business: the bit of blockIdx used as "parity" is selectable, 0 = off)
+    const int psel = (p.dbg >> 24) & 7;
+    // (psel 6: by the block's LDS base -- HW_REG_LDS_ALLOC bits 0..11 -- the two blocks of a CU differ in it by
+    // construction, whatever the dispatcher did; psel 7: by the wave's hardware slot on its SIMD, HW_REG_HW_ID bits 0..3)
+    const bool prio_hi = psel == 0 ? false
+                       : psel == 6 ? (__builtin_amdgcn_s_getreg((11 << 11) | 6) != 0)
+                       : psel == 7 ? ((__builtin_amdgcn_s_getreg((3 << 11) | 4) & 1) != 0)
+                       : (((blockIdx.x >> (psel == 1 ? 0 : psel == 2 ? 3 : psel == 3 ? 8 : psel == 4 ? 9 : 4)) & 1) != 0);
     // ---- prologue: weight stage 0, activation stages 0 and 1 ----
     stage_offsets();
     issue_a();
@@ -2428,7 +2439,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd128x256h_kernel(const ConvPara
                 if (moreA) issue_a();
             }
             __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_setprio(1);
+            if (prio_hi) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
