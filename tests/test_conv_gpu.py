@@ -1085,3 +1085,56 @@ def test_tile128x256_kernel_equals_the_256_kernel_bit_for_bit(shape, kind, tile_
             os.environ.pop("SLN_CONV_TILE128H", None)
         else:
             os.environ["SLN_CONV_TILE128H"] = saved
+
+
+def test_tile128x256_kernel_equals_the_256_kernel_on_random_shapes(tile_mode):
+    """Twenty seeded random problems (batch, map size, channels, kernel size, dilation; rows and columns mostly NOT
+    multiples of the tile) through both kernels with a parts shortcut and a parts-only output: bit-identical."""
+    import os
+    import random
+    from sln_amodal_amd import conv_hip
+    rnd = random.Random(20261003)
+    tile_mode(2)
+    saved = os.environ.get("SLN_CONV_TILE128H")
+    compared = 0
+    try:
+        for trial in range(20):
+            N = rnd.randint(1, 5)
+            H, W = rnd.randint(9, 50), rnd.randint(9, 50)
+            k = rnd.choice([1, 1, 3])
+            dil = rnd.choice([1, 2]) if k == 3 else 1
+            Cin = 8 * rnd.randint(4, 80)
+            Cout = 8 * rnd.randint(22, 90)                    # 176 .. 720
+            if Cout % 256 and Cout % 256 < 160:                   # (the launcher's own rule for the 256-wide kernels)
+                Cout = (Cout // 256 + 1) * 256
+            g = torch.Generator(device="cuda").manual_seed(trial)
+            x = torch.randn(N, Cin, H, W, device="cuda", generator=g).contiguous(memory_format=torch.channels_last)
+            w = torch.randn(Cout, Cin, k, k, device="cuda", generator=g) / (Cin * k * k) ** 0.5
+            res = torch.randn(N, Cout, H, W, device="cuda", generator=g).contiguous(memory_format=torch.channels_last)
+            sc = torch.rand(Cout, device="cuda", generator=g) + 0.5
+            sf = torch.randn(Cout, device="cuda", generator=g)
+            pad = dil * (k - 1) // 2
+            xp, xq = conv_hip.act_parts(x, 2)
+            rp, rq = conv_hip.act_parts(res, 2)
+            slot = conv_hip._slot(w, ("yrand", trial))
+            A = (xp, N, H, W, conv_hip.wsrc(w, 2), Cout, k, k, (1, 1), (dil, dil), pad, pad, H, W)
+            os.environ["SLN_CONV_TILE128H"] = "0"
+            for _ in range(2):
+                conv_hip._fwd(*A, sc, sf, None, True, cin=Cin, out_parts=True, yslot=slot, xq=xq)
+            run = lambda: conv_hip._fwd(*A, sc, sf, None, True, cin=Cin, out_parts=True, want_y=False, yslot=slot,
+                                        xq=xq, res_parts=(rp, rq))
+            want = [t.clone() for t in run() if t is not None]
+            if conv_hip._lib.lib().sln_conv_fwd_last_kernel() != 2:
+                continue                                          # (the shape went to another kernel family)
+            os.environ["SLN_CONV_TILE128H"] = "2"
+            got = [t.clone() for t in run() if t is not None]
+            assert conv_hip._lib.lib().sln_conv_fwd_last_kernel() == 3
+            assert len(got) == len(want) and all(torch.equal(a, b) for a, b in zip(got, want)), \
+                (trial, N, H, W, Cin, Cout, k, dil)
+            compared += 1
+        assert compared >= 15, compared
+    finally:
+        if saved is None:
+            os.environ.pop("SLN_CONV_TILE128H", None)
+        else:
+            os.environ["SLN_CONV_TILE128H"] = saved
