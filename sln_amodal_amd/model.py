@@ -530,7 +530,9 @@ class MaskRCNN(nn.Module):
             if rank0:
                 log("Epoch {}/{}.".format(epoch, epochs))
             self.current_epoch += 1
-            self.train_epoch(train_dataset, optimizer, steps, grad_sync)
+            mean = self.train_epoch(train_dataset, optimizer, steps, grad_sync)
+            if rank0:       # (the reference prints the running loss in its progress bar, model.py:447-449)
+                log("\t{}/{} Complete - mean loss: {:.5f}".format(steps, steps, mean))
             self.save_checkpoint(self.checkpoint_path.format(self.epoch))
             self.epoch += 1
 
