@@ -753,7 +753,7 @@ struct ConvParams {
     int Cin, Cout, KH, KW, sh, sw, dh, dw, pt, pl, relu;
     int M, Ktot, cin_chunks, gm, gn;
     int w_tiled;   // weights in conv_fwd256_kernel's LDS-image order (split_weights_tiled_kernel)
-    int dbg;   // ablation bits, debug sessions only (SLN_CONV_DBG): 1 no DMA in the k-loop, 2 no MFMA, 4 no fragment reads, 8 no wave-group stagger, 16 general epilogue, 4096 activation stages one ahead instead of two (conv_fwd256h_kernel), 8192 eight-channel epilogue without its part stores, 16384 ... without its split arithmetic, 32768 no epilogue at all (conv_fwd256h_kernel), 131072 eight-channel epilogue without its column constants' loads
+    int dbg;   // ablation bits, debug sessions only (SLN_CONV_DBG): 1 no DMA in the k-loop, 2 no MFMA, 4 no fragment reads, 8 no wave-group stagger, 16 general epilogue, 4096 activation stages one ahead instead of two (conv_fwd256h_kernel), 8192 eight-channel epilogue without its part stores, 16384 ... without its split arithmetic, 32768 no epilogue at all (conv_fwd256h_kernel), bits 28 / 29 no weight / no activation pieces in the k-loop (conv_fwd256h_kernel), 131072 eight-channel epilogue without its column constants' loads
     // Up to SLN_MAX_SEG image groups of different sizes share one launch (the GLM's three
     // scales): group s holds segN[s] images of segH x segW, its output rows start at
     // seg_m0[s] and its input pixels at seg_x0[s] of the flat [pixels][C] buffers.
@@ -2069,11 +2069,11 @@ __global__ __launch_bounds__(512) void conv_fwd256h_kernel(const ConvParams p) {
                     if (ph == 1 && moreA) { issue_piece(0, 0); issue_piece(1, 0); }
                     if (ph == 2 && moreA) { issue_piece(2, 0); issue_piece(3, 0); }
                 } else if (ph == 0) {
-                    if (moreB) {
+                    if (moreB && !(p.dbg & 268435456)) {          // (dbg bit 28: no weight pieces in the loop)
 #pragma unroll
                         for (int g = 4; g < 8; ++g) issue_piece(g, s + 1);
                     }
-                    if (moreA) {
+                    if (moreA && !(p.dbg & 536870912)) {          // (dbg bit 29: no activation pieces in the loop)
 #pragma unroll
                         for (int g = 0; g < 4; ++g) issue_piece(g, 0);
                     }
@@ -2084,7 +2084,7 @@ __global__ __launch_bounds__(512) void conv_fwd256h_kernel(const ConvParams p) {
                 // first reads of the next stage lie behind for both groups (the activation stage after it may
                 // still be on its way); then the offsets of the activation stage to issue next (cheap VALU in the
                 // shortest read segment)
-                if (AD == 2 && moreA && !(p.dbg & 1)) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+                if (AD == 2 && moreA && !(p.dbg & (1 | 268435456 | 536870912))) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                 if (moreA) {
                     stage_advance();
