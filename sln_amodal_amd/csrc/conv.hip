@@ -753,7 +753,7 @@ struct ConvParams {
     int Cin, Cout, KH, KW, sh, sw, dh, dw, pt, pl, relu;
     int M, Ktot, cin_chunks, gm, gn;
     int w_tiled;   // weights in conv_fwd256_kernel's LDS-image order (split_weights_tiled_kernel)
-    int dbg;   // ablation bits, debug sessions only (SLN_CONV_DBG): 1 no DMA in the k-loop, 2 no MFMA, 4 no fragment reads, 8 no wave-group stagger, 16 general epilogue, 4096 activation stages one ahead instead of two (conv_fwd256h_kernel), 8192 eight-channel epilogue without its part stores, 16384 ... without its split arithmetic, 32768 no epilogue at all (conv_fwd256h_kernel), bits 28 / 29 no weight / no activation pieces in the k-loop (conv_fwd256h_kernel), 131072 eight-channel epilogue without its column constants' loads
+    int dbg;   // ablation bits, debug sessions only (SLN_CONV_DBG): 1 no DMA in the k-loop, 2 no MFMA, 4 no fragment reads, 8 no wave-group stagger, 16 general epilogue, 4096 activation stages one ahead instead of two (conv_fwd256h_kernel), 8192 eight-channel epilogue without its part stores, 16384 ... without its split arithmetic, 32768 no epilogue at all (conv_fwd256h_kernel), bits 28 / 29 no weight / no activation pieces in the k-loop (conv_fwd256h_kernel), bit 30 activation pieces issued in phase 0 next to the weight pieces (the placement before round 4's last change), 131072 eight-channel epilogue without its column constants' loads
     // Up to SLN_MAX_SEG image groups of different sizes share one launch (the GLM's three
     // scales): group s holds segN[s] images of segH x segW, its output rows start at
     // seg_m0[s] and its input pixels at seg_x0[s] of the flat [pixels][C] buffers.
@@ -2073,7 +2073,18 @@ __global__ __launch_bounds__(512) void conv_fwd256h_kernel(const ConvParams p) {
 #pragma unroll
                         for (int g = 4; g < 8; ++g) issue_piece(g, s + 1);
                     }
-                    if (moreA && !(p.dbg & 536870912)) {          // (dbg bit 29: no activation pieces in the loop)
+                    if (moreA && (p.dbg & 1073741824)) {          // (dbg bit 30: the activation pieces here too, as before)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) issue_piece(g, 0);
+                    }
+                } else if (ph == 1 && !(p.dbg & (536870912 | 1073741824))) {
+                    // The activation pieces of stage s + 2 go out in PHASE 1, half a stage behind the weight pieces
+                    // (round 4: with all eight pieces issued back to back in phase 0 the K = 1024 pointwise launch
+                    // took 0.122 ms, with the activation pieces here 0.099; the 3x3 launch 0.176 -> 0.173; the train
+                    // step +0.7 %, profiles/r4_y_bench_ab_phase1.json).  They are still the four youngest pieces at
+                    // the wait below, and their buffer -- stage s - 1's -- has been idle for longer.  (dbg bit 29:
+                    // no activation pieces in the loop)
+                    if (moreA) {
 #pragma unroll
                         for (int g = 0; g < 4; ++g) issue_piece(g, 0);
                     }
@@ -2436,7 +2447,9 @@ __global__ __launch_bounds__(256, 2) void conv_fwd128x256h_kernel(const ConvPara
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
                 if (moreB) issue_b(s + 1);
-                if (moreA) issue_a();
+                if (moreA && (p.dbg & 1073741824)) issue_a();      // (dbg bit 30: here, as first built)
+            } else if (moreA && !(p.dbg & 1073741824)) {
+                issue_a();          // the activation pieces two stages ahead: in phase 1, as in conv_fwd256h_kernel
             }
             __builtin_amdgcn_sched_barrier(0);
             if (prio_hi) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(1);
