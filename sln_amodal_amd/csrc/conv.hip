@@ -2079,9 +2079,11 @@ __global__ __launch_bounds__(512) void conv_fwd256h_kernel(const ConvParams p) {
                     }
                 } else if (ph == 1 && !(p.dbg & (536870912 | 1073741824))) {
                     // The activation pieces of stage s + 2 go out in PHASE 1, half a stage behind the weight pieces
-                    // (round 4: with all eight pieces issued back to back in phase 0 the K = 1024 pointwise launch
-                    // took 0.122 ms, with the activation pieces here 0.099; the 3x3 launch 0.176 -> 0.173; the train
-                    // step +0.7 %, profiles/r4_y_bench_ab_phase1.json).  They are still the four youngest pieces at
+                    // (round 4, same-box per-shape tables of the train step, profiles/r4_aa_shapes_*: 3x3 256 -> 256 at
+                    // 64^2 452 -> 466 TFLOP/s, 512 -> 256 at 256^2 595 -> 627, the K = 1024 pointwise layers 298 -> 314
+                    // and 321 -> 337; the step +0.7 ... +1.1 % in two A/B sessions, profiles/r4_y_bench_ab_phase1.json.
+                    // Isolated launches of the K = 1024 layer are bimodal, 0.100 / 0.120 ms, whatever the placement:
+                    // not a measure of this.)  They are still the four youngest pieces at
                     // the wait below, and their buffer -- stage s - 1's -- has been idle for longer.  (dbg bit 29:
                     // no activation pieces in the loop)
                     if (moreA) {

@@ -28,7 +28,7 @@ for (name, N, Cin, H, Cout, k) in [("C4 conv1 1x1 1024->256 @64", 16, 1024, 64, 
     f = lambda: conv_hip._fwd(*A, sc, sf, None, True, out_parts=True, want_y=False, yslot=slot, xq=xq)
     row = []
     for label, dbg in (("full", 0), ("no weight pieces", 1 << 28), ("no activation pieces", 1 << 29), ("neither", 3 << 28), ("no MFMA", 2),
-                       ("activation pieces in phase 1", 1 << 30), ("no epilogue", 32768), ("no epilogue, no weight pieces", 32768 | (1 << 28)), ("no epilogue, no act pieces", 32768 | (1 << 29))):
+                       ("activation pieces in phase 0 (round-3 placement)", 1 << 30), ("no epilogue", 32768), ("no epilogue, no weight pieces", 32768 | (1 << 28)), ("no epilogue, no act pieces", 32768 | (1 << 29))):
         os.environ["SLN_CONV_DBG"] = str(dbg)
         row.append("%s %.3f" % (label, timeit(f)))
     os.environ["SLN_CONV_DBG"] = "0"
