@@ -16,7 +16,8 @@ def timeit(fn, iters=30):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters
 for (name, N, Cin, H, Cout, k) in [("C4 conv1 1x1 1024->256 @64", 16, 1024, 64, 256, 1), ("C4 conv3 1x1 256->1024 @64", 16, 256, 64, 1024, 1),
-                                   ("C4 conv2 3x3 256->256 @64", 16, 256, 64, 256, 3)]:
+                                   ("C4 conv2 3x3 256->256 @64", 16, 256, 64, 256, 3), ("FPN 3x3 256->256 @256", 4, 256, 256, 256, 3),
+                                   ("mask head 3x3 256->256 @16", 1600, 256, 16, 256, 3)]:
     x = torch.randn(N, Cin, H, H, device="cuda").contiguous(memory_format=torch.channels_last)
     w = torch.randn(Cout, Cin, k, k, device="cuda") * 0.03
     sc, sf = torch.rand(Cout, device="cuda") + 0.5, torch.randn(Cout, device="cuda")
@@ -27,7 +28,7 @@ for (name, N, Cin, H, Cout, k) in [("C4 conv1 1x1 1024->256 @64", 16, 1024, 64, 
         conv_hip._fwd(*A, sc, sf, None, True, out_parts=True, yslot=slot, xq=xq)
     f = lambda: conv_hip._fwd(*A, sc, sf, None, True, out_parts=True, want_y=False, yslot=slot, xq=xq)
     row = []
-    for label, dbg in (("full", 0), ("no weight pieces", 1 << 28), ("no activation pieces", 1 << 29), ("neither", 3 << 28), ("no MFMA", 2),
+    for label, dbg in (("full", 0), ("no weight pieces", 1 << 28), ("no activation pieces", 1 << 29), ("neither", 3 << 28), ("activation pieces of the first tap column only", 1 << 20), ("no MFMA", 2),
                        ("activation pieces in phase 0 (round-3 placement)", 1 << 30), ("no epilogue", 32768), ("no epilogue, no weight pieces", 32768 | (1 << 28)), ("no epilogue, no act pieces", 32768 | (1 << 29))):
         os.environ["SLN_CONV_DBG"] = str(dbg)
         row.append("%s %.3f" % (label, timeit(f)))
