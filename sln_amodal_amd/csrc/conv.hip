@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void im2col_split_kernel(const float *__restri
                                                            int C, int KH, int KW, int sh, int sw, int pt, int pl,
                                                            int OH, int OW, int Kp, long pstride, long row0,
                                                            __bf16 *__restrict__ parts, SplitScale q) {
-    extern __shared__ int s_tab[];            // [Kp] input offset, [Kp] kh | kw << 8 | valid << 16
+    extern __shared__ __attribute__((aligned(16))) int s_tab[];   // [Kp] input offset, [Kp] kh | kw << 8 | valid << 16
     __shared__ unsigned s_word[2];
     int *s_off = s_tab, *s_pos = s_tab + Kp;
     const int K = KH * KW * C;
@@ -249,12 +249,16 @@ __global__ __launch_bounds__(256) void im2col_split_kernel(const float *__restri
         const int ih0 = oh * sh - pt, iw0 = ow * sw - pl;
         const float *px = x + (((long)n * H + ih0) * W + iw0) * C;
         float v[4];
+        // one 16-B read per table (Kp % 8 == 0): four dword reads at a stride of four dwords per lane were 4-way bank
+        // conflicts (SQ_LDS_BANK_CONFLICT 74 % of this kernel's LDS cycles, profiles/r4_ah_head_pmc_lds.json)
+        const int4 pos4 = *(const int4 *)(s_pos + kq), off4 = *(const int4 *)(s_off + kq);
+        const int posv[4] = {pos4.x, pos4.y, pos4.z, pos4.w}, offv[4] = {off4.x, off4.y, off4.z, off4.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int pos = s_pos[kq + j];
+            const int pos = posv[j];
             const int ih = ih0 + (pos & 255), iw = iw0 + ((pos >> 8) & 255);
             const bool ok = (pos >> 16) && ih >= 0 && ih < H && iw >= 0 && iw < W;
-            v[j] = ok ? px[s_off[kq + j]] : 0.f;
+            v[j] = ok ? px[offv[j]] : 0.f;
         }
         if (P == 2) amx = amax4(amx, v);
         if (!parts) continue;
