@@ -1830,10 +1830,24 @@ __device__ __forceinline__ void mfma16_products(const bf16x8 (&a)[2], const bf16
 // 1 / 2 / 3 / 4 / 5 = ONLY the eight-channel tile epilogue without operands / with the shortcut from its parts / with
 // the ReLU pattern from part 0 / fp32 residual + that pattern / fp32 residual -- the launcher knows which a launch needs.  One variant per instance instead of
 // seven: the all-in-one instance spills 1600 scalar registers into vector lanes (26 VGPRs, a v_readlane per use).
-template <bool STAMP, int NPH, int MS = 32, int EPI = 0>
+// ROW (round 4, "tap-row stages"): 3-wide kernels with stride 1 on maps of 32 / 64 / 128 / 256 columns.  The plain k-loop
+// DMAs a tile's 256 activation rows once per TAP; the three taps of one kernel ROW read the same input rows shifted by
+// 0 / d / 2d pixels.  Here an activation stage is (32-channel chunk, kernel row kh) and serves THREE weight stages.
+// Its LDS image is the tile's 256 / W whole image rows with EIGHT ZERO ROWS in front of each and behind the last
+// (the DMA's range check writes them): output pixel (k, ow) of the tile sits at LDS row k (W + 8) + 8 + ow, tap kw
+// reads row + (kw - 1) d, and a tap that leaves its image row lands in a gap -- no mask, no address select (the
+// three earlier builds of this idea lost to exactly that arithmetic).  Gaps of 8 rows keep every
+// row congruent to its pixel column modulo 8, so the chunk swizzle of a fragment read depends on (lane, kw) only:
+// address = [lane and kw part, one register per stage] + [tile part, a scalar], one add per read like the plain loop.
+// Two activation buffers of 336 rows (the next stage has three weight stages to land), the weight ring unchanged.
+// Stage order (64-channel group, kh, half, kw) instead of (group, tap, half): same products, another fp32 summation
+// order.  Launcher: one image group, KW == 3, stride 1, pad_left == dil_w <= 8, OW == W in {32, 64, 128, 256},
+// M % 256 == 0.
+template <bool STAMP, int NPH, int MS = 32, int EPI = 0, bool ROW = false>
 __global__ __launch_bounds__(512) void conv_fwd256h_kernel(const ConvParams p) {
     constexpr int P = 2;
     static_assert(MS == 32 || (MS == 16 && NPH == 2), "the 16x16x32 body is written for two phases per stage");
+    static_assert(!ROW || (MS == 16 && !STAMP), "tap-row stages: the 16x16x32 body, no stamps");
     unsigned long long sums[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
     constexpr int REGION = T2 * T2H * 2;      // one part of one operand: 256 rows x 64 B = 16 KB
@@ -2005,6 +2019,185 @@ __global__ __launch_bounds__(512) void conv_fwd256h_kernel(const ConvParams p) {
     // its stores.  Same box A/B: the train step 88.0 -> 86.0 img/s, the K = 256 expand layer with a parts shortcut
     // 0.188 -> 0.221 ms: the extra reads compete with the k-loop's stages and much of what they fetch is gone
     // again before the epilogue asks for it.  profiles/r4_g_prefetch_epilogue_inputs.txt)
+    if constexpr (ROW) {
+        constexpr int RROWS = 336;                  // LDS rows of an activation stage: 256 + 8 (256 / W + 1) <= 328, in whole pieces
+        constexpr int RREG = RROWS * 64;            // one part of it: 21 504 B
+        constexpr int RBUF = P * RREG;              // 43 008 B
+        constexpr int RB = 2 * RBUF;                // the weight ring behind the two activation buffers
+        static_assert(RB + 2 * OBUF <= 5 * OBUF && RB % 16 == 0, "tap-row stages: LDS budget");
+        const int d = p.dw;
+        const int Wm = p.segW[0], Hm = p.segH[0], OHW = p.segOH[0] * p.segOW[0];
+        const int W8 = Wm + 8, R = T2 / Wm;
+        const int NPC = (T2 + 8 * R + 8 + 15) >> 4;                 // 16-row pieces per part: 17 ... 21
+        const bool has3 = wave + 16 < NPC;                         // this wave DMAs a third piece (wave-uniform)
+        // ---- DMA slots: piece wave + 8 q (q = 0, 1, 2), LDS row j = 16 piece + lane / 4 ----
+        int r_ih0[3], r_iw[3];
+        unsigned r_base[3], r_c0[3], r_voff[3];
+        bool r_ok[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int j = 16 * (wave + 8 * q) + (lane >> 2);
+            r_c0[q] = (unsigned)(((lane & 3) ^ SLN_SWZH(j)) * 8);
+            const int k = j / W8, pos = j - k * W8 - 8;
+            const int m = m0 + k * Wm + pos;
+            r_ok[q] = pos >= 0 && k < R && (q < 2 || has3);
+            const int mm = r_ok[q] ? m : 0;
+            const int n = mm / OHW;
+            const int oh = (mm - n * OHW) / Wm;
+            r_ih0[q] = oh - p.pt;
+            r_iw[q] = pos;
+            r_base[q] = (unsigned)(n * Hm * Wm);
+            r_voff[q] = 0xFFFFFFFFu;
+        }
+        // ---- fragment addresses: [lane, kw] part c_kw (bytes inside a part's region) + the tile's scalar s_off[i] ----
+        const int r16 = lane & 15, c16 = lane >> 4;
+        const int wru = __builtin_amdgcn_readfirstlane(wr);
+        int c_kw[3];
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int jl = r16 + 8 + (kw - 1) * d;                 // the row modulo 8 is that of jl
+            c_kw[kw] = jl * 64 + ((c16 ^ SLN_SWZH(jl)) * 16);
+        }
+        int s_off[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r0 = 128 * wru + 16 * i;
+            s_off[i] = (r0 + 8 * (r0 / Wm)) * 64;
+        }
+        // ---- walkers: the activation stage to issue next (group, kh, half); the weight stage to issue next ----
+        int ag = 0, akh = 0, ahalf = 0;
+        auto a_offsets = [&]() {
+            const int cc = 2 * ag + ahalf;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int ih = r_ih0[q] + akh * p.dh;
+                const unsigned ci = (unsigned)(cc * T2H) + r_c0[q];
+                const bool ok = r_ok[q] && (unsigned)ih < (unsigned)Hm && ci < (unsigned)p.Cin;
+                const unsigned off = ((r_base[q] + (unsigned)(ih * Wm + r_iw[q])) * (unsigned)p.Cin + ci) * 2u;
+                r_voff[q] = ok ? off : 0xFFFFFFFFu;
+            }
+        };
+        auto a_advance = [&]() {
+            if (++ahalf == (ag < gfull ? 2 : 1)) {
+                ahalf = 0;
+                if (++akh == p.KH) { akh = 0; ++ag; }
+            }
+        };
+        auto issue_a = [&](int buf) {
+            unsigned char *base = smem + buf * RBUF + wave * 1024;
+#pragma unroll
+            for (int pp = 0; pp < P; ++pp)
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(pp ? rsrc_a1 : rsrc_a0,
+                                                             (lds_void *)(base + pp * RREG + q * 8192), 16, r_voff[q],
+                                                             0, 0, 0);
+            if (has3) {
+#pragma unroll
+                for (int pp = 0; pp < P; ++pp)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(pp ? rsrc_a1 : rsrc_a0,
+                                                             (lds_void *)(base + pp * RREG + 16384), 16, r_voff[2], 0,
+                                                             0, 0);
+            }
+        };
+        int wg = 0, wkh = 0, whalf = 0, wkw = 0;
+        auto issue_w = [&](int wbuf) {        // the weight stage the walker points at, in the image's (group, tap, half) order
+            const int nh = wg < gfull ? 2 : 1;
+            const int bs = wg * ntap * 2 + (wkh * 3 + wkw) * nh + whalf;
+            unsigned char *base = smem + RB + wbuf * OBUF + wave * 2048;
+#pragma unroll
+            for (int pp = 0; pp < P; ++pp)
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_void *)(base + pp * REGION + q * 1024), 16,
+                                                             b_voff, (unsigned)(bs * P + pp) * (T2 * T2H * 2) + q * 1024,
+                                                             0, 0);
+            if (++wkw == 3) {
+                wkw = 0;
+                if (++whalf == nh) {
+                    whalf = 0;
+                    if (++wkh == p.KH) { wkh = 0; ++wg; }
+                }
+            }
+        };
+        const int nA = ncc * p.KH;            // activation stages of the tile
+        int a_issued = 1;
+        a_offsets();
+        issue_a(0);
+        issue_w(0);
+        a_advance();
+        if (nA > 1) {
+            a_offsets();
+            issue_a(1);                       // stage 1 stays in flight behind stage 0
+            a_advance();
+            a_issued = 2;
+            if (nA > 2) a_offsets();
+            if (has3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        const bool stagger = !(p.dbg & 8);
+        if (wr == 1 && stagger) __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+
+        bf16x8 b16[4][P];
+        int kw = 0, a_rd = 0;
+        for (int s = 0; s < nk; ++s) {
+            const unsigned char *stB = smem + RB + (s & 1) * OBUF;
+            const bool moreB = s + 1 < nk;
+            // the first weight stage of an activation stage refills the OTHER buffer (read until a stage ago)
+            const bool fillA = kw == 0 && s > 0 && a_issued < nA;
+            const int vb = (kw == 0 ? c_kw[0] : kw == 1 ? c_kw[1] : c_kw[2]) + a_rd * RBUF;
+#pragma unroll
+            for (int ph = 0; ph < 2; ++ph) {
+                bf16x8 a[4][P];
+                if (ph == 0) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int pp = 0; pp < P; ++pp)
+                            b16[j][pp] = *(const bf16x8 *)(stB + pp * REGION + b_off16[j]);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int pp = 0; pp < P; ++pp)
+                        a[i][pp] = *(const bf16x8 *)(smem + pp * RREG + (vb + s_off[4 * ph + i]));
+                __builtin_amdgcn_sched_barrier(0);
+                if (ph == 0 && moreB) issue_w((s + 1) & 1);
+                if (ph == 1 && fillA) issue_a(a_rd ^ 1);
+                if (ph == 1) {
+                    // in order: the weight pieces of stage s + 1 are older than this stage's activation pieces
+                    if (fillA) {
+                        if (has3) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+                        else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+                        a_advance();
+                        if (++a_issued < nA) a_offsets();
+                    } else {
+                        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    }
+                    if (++kw == 3) { kw = 0; a_rd ^= 1; }
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) mfma16_products(a[i], b16[j], acc16[4 * ph + i][j]);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+            }
+        }
+        if (wr == 0 && stagger) __builtin_amdgcn_s_barrier();      // re-align the two groups
+    } else {
     stage_offsets();
 #pragma unroll
     for (int g = 0; g < 8; ++g) issue_piece(g, 0);          // activation and weight stage 0
@@ -2162,6 +2355,7 @@ __global__ __launch_bounds__(512) void conv_fwd256h_kernel(const ConvParams p) {
     }
     SLN_STAMP(ts_loop1);
     if (wr == 0 && stagger) __builtin_amdgcn_s_barrier();      // re-align the two groups
+    }
     __syncthreads();
     if (t < T2) s_colsum[t] = 0.f;      // (behind the staging slabs; ordered by the epilogue's first barrier)
     if (p.dbg & 32768) {                 // ablation: prologue + k-loop only (one word per lane keeps the MFMAs alive)
@@ -3585,6 +3779,22 @@ extern "C" int sln_conv2d_fwd_ms_f32(const uint16_t *x_parts, int nseg, const in
                     else if (p.residual) hipLaunchKernelGGL((conv_fwd128x256h_kernel<5>), g1, b1, 0, (hipStream_t)stream, p);
                     else if (p.mask_part0) hipLaunchKernelGGL((conv_fwd128x256h_kernel<3>), g1, b1, 0, (hipStream_t)stream, p);
                     else hipLaunchKernelGGL((conv_fwd128x256h_kernel<1>), g1, b1, 0, (hipStream_t)stream, p);
+                    return sln_launch_status();
+                }
+                // 3-wide kernels, stride 1, on maps of 32 ... 256 columns in whole tiles: activation stages per kernel ROW
+                const int Wr = p.segW[0];
+                const bool row = nseg == 1 && KW == 3 && stride_h == 1 && stride_w == 1 && pad_left == dil_w && dil_w <= 8 &&
+                                 p.segOW[0] == Wr && (Wr == 32 || Wr == 64 || Wr == 128 || Wr == 256) && M % T2 == 0 &&
+                                 !(p.dbg & ~(8 | 16 | 256 | 8192 | 16384 | 32768 | 131072)) &&
+                                 sln_knob("SLN_CONV_TAPROW", 1) != 0;
+                if (row) {
+                    sln_last_fwd_kernel = 4;
+                    if (!w8) hipLaunchKernelGGL((conv_fwd256h_kernel<false, 2, 16, 0, true>), g2, b2, 0, (hipStream_t)stream, p);
+                    else if (p.res_parts) hipLaunchKernelGGL((conv_fwd256h_kernel<false, 2, 16, 2, true>), g2, b2, 0, (hipStream_t)stream, p);
+                    else if (p.residual && p.mask_part0) hipLaunchKernelGGL((conv_fwd256h_kernel<false, 2, 16, 4, true>), g2, b2, 0, (hipStream_t)stream, p);
+                    else if (p.residual) hipLaunchKernelGGL((conv_fwd256h_kernel<false, 2, 16, 5, true>), g2, b2, 0, (hipStream_t)stream, p);
+                    else if (p.mask_part0) hipLaunchKernelGGL((conv_fwd256h_kernel<false, 2, 16, 3, true>), g2, b2, 0, (hipStream_t)stream, p);
+                    else hipLaunchKernelGGL((conv_fwd256h_kernel<false, 2, 16, 1, true>), g2, b2, 0, (hipStream_t)stream, p);
                     return sln_launch_status();
                 }
                 if (!w8) hipLaunchKernelGGL((conv_fwd256h_kernel<false, 2, 16>), g2, b2, 0, (hipStream_t)stream, p);

@@ -1061,6 +1061,7 @@ def test_tile128x256_kernel_equals_the_256_kernel_bit_for_bit(shape, kind, tile_
 
     saved = os.environ.get("SLN_CONV_TILE128H")
     try:
+        os.environ["SLN_CONV_TAPROW"] = "0"      # (3x3 shapes: the plain k-loop, whose stage order the sibling shares)
         os.environ["SLN_CONV_TILE128H"] = "0"
         want = outputs()
         assert conv_hip._lib.lib().sln_conv_fwd_last_kernel() == 2
@@ -1081,6 +1082,7 @@ def test_tile128x256_kernel_equals_the_256_kernel_bit_for_bit(shape, kind, tile_
             again = outputs()
             assert all(same(a, b) for a, b in zip(again, got))
     finally:
+        os.environ.pop("SLN_CONV_TAPROW", None)
         if saved is None:
             os.environ.pop("SLN_CONV_TILE128H", None)
         else:
@@ -1098,6 +1100,7 @@ def test_tile128x256_kernel_equals_the_256_kernel_on_random_shapes(tile_mode):
     saved = os.environ.get("SLN_CONV_TILE128H")
     compared = 0
     try:
+        os.environ["SLN_CONV_TAPROW"] = "0"
         for trial in range(20):
             N = rnd.randint(1, 5)
             H, W = rnd.randint(9, 50), rnd.randint(9, 50)
@@ -1134,7 +1137,100 @@ def test_tile128x256_kernel_equals_the_256_kernel_on_random_shapes(tile_mode):
             compared += 1
         assert compared >= 15, compared
     finally:
+        os.environ.pop("SLN_CONV_TAPROW", None)
         if saved is None:
             os.environ.pop("SLN_CONV_TILE128H", None)
         else:
             os.environ["SLN_CONV_TILE128H"] = saved
+
+
+# ------------------------------------------------- tap-row stages (conv_fwd256h_kernel<..., ROW = true>)
+def _taprow_env(v):
+    import os
+    if v is None:
+        os.environ.pop("SLN_CONV_TAPROW", None)
+    else:
+        os.environ["SLN_CONV_TAPROW"] = v
+
+
+@pytest.mark.parametrize("shape", [
+    # N, H, W, Cin, Cout, dil.  The ROW instances take maps of 32 / 64 / 128 / 256 columns in whole tiles: dilations 1 ... 8
+    # (8 = the whole zero gap), ragged channel counts, K of one chunk, images smaller than a tile (two images per tile);
+    # the last three shapes are NOT admitted (16 columns; ragged rows; 41 columns) and must fall back to the plain loop
+    (4, 64, 64, 256, 256, 1), (8, 32, 32, 136, 439, 2), (2, 16, 128, 72, 200, 4), (1, 256, 256, 8, 256, 8),
+    (1, 64, 32, 40, 256, 8), (16, 8, 32, 32, 256, 1), (32, 4, 32, 32, 256, 3), (1, 128, 128, 64, 512, 1),
+    (16, 16, 16, 256, 256, 1), (3, 20, 32, 64, 256, 1), (3, 37, 41, 64, 256, 1)])
+@pytest.mark.parametrize("kind", ["plain", "parts", "res16", "res32", "res32+mask16", "mask16+colsum"])
+def test_tap_row_stages_equal_the_plain_k_loop(shape, kind, tile_mode):
+    """conv_fwd256h_kernel's ROW instances stage the activations once per kernel ROW (image rows with zero gaps between
+    them in LDS) and read the three taps of the row from shifted LDS rows.  Same products as the plain loop, summed in
+    another order: every output within 4e-6 of the output scale of the plain loop's (fp32; the parts decode to the
+    same values), the fp64 reference within the file's 5e-6, and 30 launches reproduce themselves bit for bit (a race in
+    the rings or a stale gap row shows up as a difference)."""
+    from sln_amodal_amd import conv_hip
+    N, H, W, Cin, Cout, dil = shape
+    k = 3
+    g = torch.Generator(device="cuda").manual_seed(H * 19 + Cin + len(kind))
+    x = torch.randn(N, Cin, H, W, device="cuda", generator=g).contiguous(memory_format=torch.channels_last)
+    w = torch.randn(Cout, Cin, k, k, device="cuda", generator=g) / (Cin * k * k) ** 0.5
+    res = torch.randn(N, Cout, H, W, device="cuda", generator=g).contiguous(memory_format=torch.channels_last)
+    sc = torch.rand(Cout, device="cuda", generator=g) + 0.5
+    sf = torch.randn(Cout, device="cuda", generator=g)
+    xp, xq = conv_hip.act_parts(x, 2)
+    rp, rq = conv_hip.act_parts(res, 2)
+    slot = conv_hip._slot(w, ("yrow", H, W, kind))
+    A = (xp, N, H, W, conv_hip.wsrc(w, 2), Cout, k, k, (1, 1), (dil, dil), dil, dil, H, W)
+    tile_mode(2)
+    _taprow_env("0")
+    try:
+        for _ in range(2):       # bootstrap the output's scale slot with a plain launch
+            conv_hip._fwd(*A, sc, sf, None, True, cin=Cin, out_parts=True, yslot=slot, xq=xq)
+        run = {
+            "plain": lambda: conv_hip._fwd(*A, sc, sf, None, True, cin=Cin, out_parts=True, yslot=slot, xq=xq),
+            "parts": lambda: conv_hip._fwd(*A, sc, sf, None, True, cin=Cin, out_parts=True, want_y=False, yslot=slot, xq=xq),
+            "res16": lambda: conv_hip._fwd(*A, sc, sf, None, True, cin=Cin, out_parts=True, want_y=False, yslot=slot, xq=xq,
+                                           res_parts=(rp, rq)),
+            "res32": lambda: conv_hip._fwd(*A, sc, sf, res, True, cin=Cin, out_parts=True, yslot=slot, xq=xq),
+            "res32+mask16": lambda: conv_hip._fwd(*A, None, None, res, False, cin=Cin, out_parts=True, want_y=True,
+                                                  want_colsum=True, post_scale=sc, yslot=slot, xq=xq, mask_parts=rp),
+            "mask16+colsum": lambda: conv_hip._fwd(*A, sc, None, None, False, cin=Cin, out_parts=True, want_y=False,
+                                                   want_colsum=True, yslot=slot, xq=xq, mask_parts=rp),
+        }[kind]
+
+        def outputs():
+            r = run()
+            r = r if isinstance(r, tuple) else (r, getattr(r, "_sln_parts", (None, None))[1], None)
+            return [None if t is None else t.clone() for t in r]
+
+        want = outputs()
+        if conv_hip._lib.lib().sln_conv_fwd_last_kernel() != 2:
+            pytest.skip("the shape does not run on conv_fwd256h_kernel")
+        _taprow_env("1")
+        got = outputs()
+        admitted = W in (32, 64, 128, 256) and (N * H * W) % 256 == 0
+        assert conv_hip._lib.lib().sln_conv_fwd_last_kernel() == (4 if admitted else 2)
+
+        def decode(t):
+            if t is None:
+                return None
+            if t.dtype == torch.bfloat16:                                # the two fp16 parts (scale: the slot's)
+                return t.view(torch.float16).double().sum(dim=0)
+            return t.double()
+        for a, b in zip(got, want):
+            assert (a is None) == (b is None)
+            if a is None:
+                continue
+            da, db = decode(a), decode(b)
+            tol = (2e-5 if a.dim() == 1 else 4e-6) * float(db.abs().max()) + 1e-30
+            assert float((da - db).abs().max()) <= tol, (kind, float((da - db).abs().max()), tol)
+        if kind == "plain":
+            ref = F.relu(F.conv2d(x.double(), w.double(), None, 1, dil, dil) * sc.double().view(1, -1, 1, 1)
+                         + sf.double().view(1, -1, 1, 1))
+            assert float((got[0].double() - ref).abs().max()) / float(ref.abs().max()) < 5e-6
+        for _ in range(30):
+            again = outputs()
+            for a, b in zip(again, got):
+                if a is not None and a.dim() != 1:       # (the column sums are atomics: order-dependent rounding)
+                    assert torch.equal(a, b)
+    finally:
+        _taprow_env(None)
