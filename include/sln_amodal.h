@@ -476,7 +476,8 @@ int sln_conv2d_fwd_ms_f32(const uint16_t *x_parts, int nseg, const int32_t *seg_
  * Cout channels, K = KH*KW*Cin and `parts`: host-side rule, no GPU work (csrc/conv.hip). */
 int sln_conv_fwd_tile(int64_t M, int Cout, int64_t K, int parts);
 /* Which forward kernel the calling thread's last sln_conv2d_fwd*_f32 call launched: 0 conv_fwd_kernel (128 x 128),
- * 1 conv_fwd256_kernel, 2 conv_fwd256h_kernel, 3 conv_fwd128x256h_kernel (pointwise layers: two blocks per CU).
+ * 1 conv_fwd256_kernel, 2 conv_fwd256h_kernel, 3 conv_fwd128x256h_kernel (pointwise layers: two blocks per CU),
+ * 4 conv_fwd256h_kernel's tap-row instances (3-wide kernels, stride 1, maps of 32 ... 256 columns).
  * Profiling labels only. */
 int sln_conv_fwd_last_kernel(void);
 /* Tile edge (128 or 256) of the weight-gradient kernel sln_conv2d_wgrad_f32 uses (host-side rule). */

@@ -3656,7 +3656,7 @@ extern "C" int sln_scale_update_f32(float *amax, float *scale, float *history, i
 // and K is long enough to amortise the pipeline; else 128.  SLN_CONV_TILE256 = 0 never,
 // 1 (default) by this rule, 2 always (tests); read on every call.
 // Which forward kernel the last sln_conv2d_fwd*_f32 call of this thread launched (profiling labels): 0 the 128^2
-// kernel, 1 conv_fwd256_kernel, 2 conv_fwd256h_kernel, 3 conv_fwd128x256h_kernel.
+// kernel, 1 conv_fwd256_kernel, 2 conv_fwd256h_kernel, 3 conv_fwd128x256h_kernel, 4 conv_fwd256h_kernel's tap-row instances.
 static thread_local int sln_last_fwd_kernel = 0;
 extern "C" int sln_conv_fwd_last_kernel(void) { return sln_last_fwd_kernel; }
 
