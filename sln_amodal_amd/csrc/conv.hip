@@ -765,6 +765,7 @@ struct ConvParams {
     int Cin, Cout, KH, KW, sh, sw, dh, dw, pt, pl, relu;
     int M, Ktot, cin_chunks, gm, gn;
     int w_tiled;   // weights in conv_fwd256_kernel's LDS-image order (split_weights_tiled_kernel)
+    int tapmode;   // conv_fwd256h_kernel's ROW instances: 1 = a stage per kernel row (taps kw by row shifts), 2 = per kernel column (taps kh)
     int dbg;   // ablation bits, debug sessions only (SLN_CONV_DBG): 1 no DMA in the k-loop, 2 no MFMA, 4 no fragment reads, 8 no wave-group stagger, 16 general epilogue, 4096 activation stages one ahead instead of two (conv_fwd256h_kernel), 8192 eight-channel epilogue without its part stores, 16384 ... without its split arithmetic, 32768 no epilogue at all (conv_fwd256h_kernel), bits 28 / 29 no weight / no activation pieces in the k-loop (conv_fwd256h_kernel), bit 30 activation pieces issued in phase 0 next to the weight pieces (the placement before round 4's last change), bit 20 activation pieces only for the stages of the first tap column (what a per-kernel-row activation stage would save), 131072 eight-channel epilogue without its column constants' loads
     // Up to SLN_MAX_SEG image groups of different sizes share one launch (the GLM's three
     // scales): group s holds segN[s] images of segH x segW, its output rows start at
@@ -2025,10 +2026,15 @@ __global__ __launch_bounds__(512) void conv_fwd256h_kernel(const ConvParams p) {
         constexpr int RBUF = P * RREG;              // 43 008 B
         constexpr int RB = 2 * RBUF;                // the weight ring behind the two activation buffers
         static_assert(RB + 2 * OBUF <= 5 * OBUF && RB % 16 == 0, "tap-row stages: LDS budget");
-        const int d = p.dw;
+        // (tapmode 2, maps of exactly one tile -- the mask head's 16 x 16 rois: the stage is a kernel COLUMN, its three
+        // taps kh read rows shifted by dh * W = one image row; the image has dh * W zero rows above and below it in
+        // LDS and no gaps inside, the horizontal tap is the DMA's bounds check as in the plain loop)
+        const bool col = p.tapmode == 2;
         const int Wm = p.segW[0], Hm = p.segH[0], OHW = p.segOH[0] * p.segOW[0];
+        const int sft = col ? p.dh * Wm : p.dw;                     // LDS rows between consecutive taps of a stage
+        const int lead = col ? sft : 8;                             // zero rows in front of the first pixel row
         const int W8 = Wm + 8, R = T2 / Wm;
-        const int NPC = (T2 + 8 * R + 8 + 15) >> 4;                 // 16-row pieces per part: 17 ... 21
+        const int NPC = ((col ? T2 + 2 * sft : T2 + 8 * R + 8) + 15) >> 4;      // 16-row pieces per part: 17 ... 21
         const bool has3 = wave + 16 < NPC;                         // this wave DMAs a third piece (wave-uniform)
         // ---- DMA slots: piece wave + 8 q (q = 0, 1, 2), LDS row j = 16 piece + lane / 4 ----
         int r_ih0[3], r_iw[3];
@@ -2038,14 +2044,15 @@ __global__ __launch_bounds__(512) void conv_fwd256h_kernel(const ConvParams p) {
         for (int q = 0; q < 3; ++q) {
             const int j = 16 * (wave + 8 * q) + (lane >> 2);
             r_c0[q] = (unsigned)(((lane & 3) ^ SLN_SWZH(j)) * 8);
-            const int k = j / W8, pos = j - k * W8 - 8;
+            const int k = col ? 0 : j / W8, pos = col ? j - lead : j - k * W8 - 8;
             const int m = m0 + k * Wm + pos;
-            r_ok[q] = pos >= 0 && k < R && (q < 2 || has3);
+            r_ok[q] = pos >= 0 && (col ? pos < T2 : k < R) && (q < 2 || has3);
             const int mm = r_ok[q] ? m : 0;
             const int n = mm / OHW;
-            const int oh = (mm - n * OHW) / Wm;
+            const int rem = mm - n * OHW;
+            const int oh = rem / Wm;
             r_ih0[q] = oh - p.pt;
-            r_iw[q] = pos;
+            r_iw[q] = rem - oh * Wm - p.pl;
             r_base[q] = (unsigned)(n * Hm * Wm);
             r_voff[q] = 0xFFFFFFFFu;
         }
@@ -2055,32 +2062,35 @@ __global__ __launch_bounds__(512) void conv_fwd256h_kernel(const ConvParams p) {
         int c_kw[3];
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) {
-            const int jl = r16 + 8 + (kw - 1) * d;                 // the row modulo 8 is that of jl
+            const int jl = r16 + lead + (kw - 1) * sft;            // the row modulo 8 is that of jl
             c_kw[kw] = jl * 64 + ((c16 ^ SLN_SWZH(jl)) * 16);
         }
         int s_off[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int r0 = 128 * wru + 16 * i;
-            s_off[i] = (r0 + 8 * (r0 / Wm)) * 64;
+            s_off[i] = (col ? r0 : r0 + 8 * (r0 / Wm)) * 64;
         }
-        // ---- walkers: the activation stage to issue next (group, kh, half); the weight stage to issue next ----
+        // ---- walkers: the activation stage to issue next (group, outer tap index, half) -- the outer index is kh in row
+        //      mode, kw in column mode; the stage holds the CENTRE tap of the other direction -- and the weight stage ----
+        const int nouter = col ? p.KW : p.KH;
         int ag = 0, akh = 0, ahalf = 0;
         auto a_offsets = [&]() {
             const int cc = 2 * ag + ahalf;
+            const int dih = (col ? 1 : akh) * p.dh, diw = (col ? akh : 1) * p.dw;
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
-                const int ih = r_ih0[q] + akh * p.dh;
+                const int ih = r_ih0[q] + dih, iw = r_iw[q] + diw;
                 const unsigned ci = (unsigned)(cc * T2H) + r_c0[q];
-                const bool ok = r_ok[q] && (unsigned)ih < (unsigned)Hm && ci < (unsigned)p.Cin;
-                const unsigned off = ((r_base[q] + (unsigned)(ih * Wm + r_iw[q])) * (unsigned)p.Cin + ci) * 2u;
+                const bool ok = r_ok[q] && (unsigned)ih < (unsigned)Hm && (unsigned)iw < (unsigned)Wm && ci < (unsigned)p.Cin;
+                const unsigned off = ((r_base[q] + (unsigned)(ih * Wm + iw)) * (unsigned)p.Cin + ci) * 2u;
                 r_voff[q] = ok ? off : 0xFFFFFFFFu;
             }
         };
         auto a_advance = [&]() {
             if (++ahalf == (ag < gfull ? 2 : 1)) {
                 ahalf = 0;
-                if (++akh == p.KH) { akh = 0; ++ag; }
+                if (++akh == nouter) { akh = 0; ++ag; }
             }
         };
         auto issue_a = [&](int buf) {
@@ -2103,7 +2113,7 @@ __global__ __launch_bounds__(512) void conv_fwd256h_kernel(const ConvParams p) {
         int wg = 0, wkh = 0, whalf = 0, wkw = 0;
         auto issue_w = [&](int wbuf) {        // the weight stage the walker points at, in the image's (group, tap, half) order
             const int nh = wg < gfull ? 2 : 1;
-            const int bs = wg * ntap * 2 + (wkh * 3 + wkw) * nh + whalf;
+            const int bs = wg * ntap * 2 + (col ? wkw * p.KW + wkh : wkh * 3 + wkw) * nh + whalf;
             unsigned char *base = smem + RB + wbuf * OBUF + wave * 2048;
 #pragma unroll
             for (int pp = 0; pp < P; ++pp)
@@ -2116,11 +2126,11 @@ __global__ __launch_bounds__(512) void conv_fwd256h_kernel(const ConvParams p) {
                 wkw = 0;
                 if (++whalf == nh) {
                     whalf = 0;
-                    if (++wkh == p.KH) { wkh = 0; ++wg; }
+                    if (++wkh == nouter) { wkh = 0; ++wg; }
                 }
             }
         };
-        const int nA = ncc * p.KH;            // activation stages of the tile
+        const int nA = ncc * nouter;          // activation stages of the tile
         int a_issued = 1;
         a_offsets();
         issue_a(0);
@@ -3739,6 +3749,7 @@ extern "C" int sln_conv2d_fwd_ms_f32(const uint16_t *x_parts, int nseg, const in
     // the 256x256 kernel DMAs the weights in its own LDS-image order, the 128x128 kernel reads rows
     if (w_layout != sln_conv_fwd_weights_layout(M, Cout, Cin, KH * KW, parts, Min)) return SLN_ERR_INVALID_ARG;
     p.w_tiled = w_layout;
+    p.tapmode = 0;
     if (residual_parts || mask_part0) {
         // parts-only operands of the epilogue exist in the fixed-feature slab only: fp16 x 2, whole 16-B row
         // groups, and not the round-1 256^2 kernel (operands beyond the 4-GiB buffer range)
@@ -3787,7 +3798,13 @@ extern "C" int sln_conv2d_fwd_ms_f32(const uint16_t *x_parts, int nseg, const in
                                  p.segOW[0] == Wr && (Wr == 32 || Wr == 64 || Wr == 128 || Wr == 256) && M % T2 == 0 &&
                                  !(p.dbg & ~(8 | 16 | 256 | 8192 | 16384 | 32768 | 131072)) &&
                                  sln_knob("SLN_CONV_TAPROW", 1) != 0;
-                if (row) {
+                // ... and on maps of exactly one tile with at most 40 columns x dilation (the mask head's 16 x 16 rois): per kernel COLUMN
+                const bool colm = !row && nseg == 1 && KH == 3 && stride_h == 1 && stride_w == 1 && pad_top == dil_h &&
+                                  p.segOH[0] == p.segH[0] && p.segOW[0] == Wr && (long)p.segH[0] * Wr == T2 && dil_h * Wr <= 40 &&
+                                  !(p.dbg & ~(8 | 16 | 256 | 8192 | 16384 | 32768 | 131072)) &&
+                                  sln_knob("SLN_CONV_TAPROW", 1) != 0;
+                p.tapmode = row ? 1 : colm ? 2 : 0;
+                if (row || colm) {
                     sln_last_fwd_kernel = 4;
                     if (!w8) hipLaunchKernelGGL((conv_fwd256h_kernel<false, 2, 16, 0, true>), g2, b2, 0, (hipStream_t)stream, p);
                     else if (p.res_parts) hipLaunchKernelGGL((conv_fwd256h_kernel<false, 2, 16, 2, true>), g2, b2, 0, (hipStream_t)stream, p);

@@ -1156,10 +1156,12 @@ def _taprow_env(v):
 @pytest.mark.parametrize("shape", [
     # N, H, W, Cin, Cout, dil.  The ROW instances take maps of 32 / 64 / 128 / 256 columns in whole tiles: dilations 1 ... 8
     # (8 = the whole zero gap), ragged channel counts, K of one chunk, images smaller than a tile (two images per tile);
-    # the last three shapes are NOT admitted (16 columns; ragged rows; 41 columns) and must fall back to the plain loop
+    # maps of exactly one tile (16 x 16 rois, 32 x 8) go per kernel COLUMN; the last two shapes are NOT admitted (ragged
+    # rows; 41 columns) and must fall back to the plain loop
     (4, 64, 64, 256, 256, 1), (8, 32, 32, 136, 439, 2), (2, 16, 128, 72, 200, 4), (1, 256, 256, 8, 256, 8),
     (1, 64, 32, 40, 256, 8), (16, 8, 32, 32, 256, 1), (32, 4, 32, 32, 256, 3), (1, 128, 128, 64, 512, 1),
-    (16, 16, 16, 256, 256, 1), (3, 20, 32, 64, 256, 1), (3, 37, 41, 64, 256, 1)])
+    (16, 16, 16, 256, 256, 1), (5, 16, 16, 136, 439, 2), (7, 32, 8, 72, 200, 1),        # one image per tile: a stage per kernel COLUMN
+    (3, 20, 32, 64, 256, 1), (3, 37, 41, 64, 256, 1)])
 @pytest.mark.parametrize("kind", ["plain", "parts", "res16", "res32", "res32+mask16", "mask16+colsum"])
 def test_tap_row_stages_equal_the_plain_k_loop(shape, kind, tile_mode):
     """conv_fwd256h_kernel's ROW instances stage the activations once per kernel ROW (image rows with zero gaps between
@@ -1207,7 +1209,7 @@ def test_tap_row_stages_equal_the_plain_k_loop(shape, kind, tile_mode):
             pytest.skip("the shape does not run on conv_fwd256h_kernel")
         _taprow_env("1")
         got = outputs()
-        admitted = W in (32, 64, 128, 256) and (N * H * W) % 256 == 0
+        admitted = (W in (32, 64, 128, 256) and (N * H * W) % 256 == 0) or (H * W == 256 and dil * W <= 40)
         assert conv_hip._lib.lib().sln_conv_fwd_last_kernel() == (4 if admitted else 2)
 
         def decode(t):

@@ -15,7 +15,7 @@ def timeit(fn, iters=30):
     return e0.elapsed_time(e1) / iters
 for (name, N, Cin, H, Cout, dil) in [("C4 3x3 256->256 @64", 16, 256, 64, 256, 1), ("FPN 3x3 256->256 @256", 16, 256, 256, 256, 1),
                                      ("RPN 3x3 256->512 @256", 16, 256, 256, 512, 1), ("FPN 3x3 256->256 @128", 16, 256, 128, 256, 1),
-                                     ("3x3 512->256 @256", 16, 512, 256, 256, 1), ("mask head 3x3 256->256 @16 (not admitted)", 1600, 256, 16, 256, 1)]:
+                                     ("3x3 512->256 @256", 16, 512, 256, 256, 1), ("mask head 3x3 256->256 @16", 1600, 256, 16, 256, 1), ("mask head 3x3 256->439 @16", 1600, 256, 16, 439, 1)]:
     x = torch.randn(N, Cin, H, H, device="cuda").contiguous(memory_format=torch.channels_last)
     w = torch.randn(Cout, Cin, 3, 3, device="cuda") * 0.03
     sc, sf = torch.rand(Cout, device="cuda") + 0.5, torch.randn(Cout, device="cuda")
