@@ -219,8 +219,8 @@ def main_resnext(args, rank, world, dev):
     import torch.nn.functional as F
     from sln_amodal_amd import conv_hip, nn_ops, parallel
     from sln_amodal_amd.modal.resnext import DeepLabV2_ResNeXt101_MSC
-    batch = args.batch if args.batch != 16 else 32
-    dim = args.dim if args.dim != 1024 else 321
+    batch = args.batch if args.batch is not None else 32
+    dim = args.dim if args.dim is not None else 321
     classes = 21
     torch.manual_seed(0)
     net = DeepLabV2_ResNeXt101_MSC(classes).to(dev)
@@ -332,10 +332,19 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=16, help="images per GPU")
-    ap.add_argument("--dim", type=int, default=1024)
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU (default: 16 for sln, 32 for resnext)")
+    ap.add_argument("--dim", type=int, default=None, help="image edge (default: 1024 for sln, 321 for resnext)")
     ap.add_argument("--arch", default="resnet101")
     ap.add_argument("--stage", default="all", choices=["all", "heads"])
+    ap.add_argument("--settle", type=int, default=8,
+                    help="untimed set-up train steps that seed the operand-scale window (see conv_saturated_blocks)")
+    ap.add_argument("--data", default="synthetic", choices=["synthetic", "files"],
+                    help="synthetic: two device-resident batches (BASELINE.json's metric).  files: --files generated jpg + "
+                         "npz pairs read through the training input pipeline (worker processes, pinned staging, copy "
+                         "stream; sln_amodal_amd/loader.py) INSIDE the timed region -- what `amodal_train.py train "
+                         "--dataset DIR` sustains")
+    ap.add_argument("--files", type=int, default=256, help="--data files: pairs to generate per job")
+    ap.add_argument("--workers", type=int, default=None, help="--data files: loader worker processes per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-strict", action="store_true", help="skip the 5 extra steps in the 3 x bf16 format")
     ap.add_argument("--conv-backend", default="auto", choices=["auto", "hip", "torch"])
@@ -353,6 +362,29 @@ def main():
     from sln_amodal_amd.config import Config
     from sln_amodal_amd.model import LAYER_REGEX, MaskRCNN
 
+    file_data = None
+    if args.data == "files" and args.config == "sln":
+        # before this process touches the GPU: write the file set (once per job) and spawn the loader's workers
+        from sln_amodal_amd import amodal_train, loader
+        b_, d_ = (16 if args.batch is None else args.batch), (1024 if args.dim is None else args.dim)
+        env_rank, env_world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+        parallel.set_cpu_affinity(int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("LOCAL_WORLD_SIZE", env_world)))
+        root = os.path.join(os.environ.get("TMPDIR", "/tmp"), "sln_bench_files_%d_%d" % (d_, args.files))
+        t_gen = time.perf_counter()
+        loader.write_synthetic_dataset(root, args.files, d_, procs=min(32, os.cpu_count() or 8))
+        t_gen = time.perf_counter() - t_gen
+
+        class FileConfig(Config):
+            NAME = "bench"
+            IMAGE_MAX_DIM = d_
+            IMAGE_MIN_DIM = d_
+            ARCHITECTURE = args.arch
+            BATCH_SIZE = b_
+
+        file_data = amodal_train.AmodalDataset(FileConfig(), None, root, limit=-1, seed=1234 + env_rank, device="cpu",
+                                               rank=env_rank, world=env_world, workers=args.workers, max_objects=8,
+                                               seed_order=0).start_workers()
+        file_data.gen_seconds = round(t_gen, 1)
     rank, local, world = parallel.init_distributed()
     if world != args.gpus:   # never print a line whose n_gpus differs from what was asked for
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
@@ -361,6 +393,8 @@ def main():
     nn_ops.BACKEND = args.conv_backend
     if args.config == "resnext":
         return main_resnext(args, rank, world, dev)
+    args.batch = 16 if args.batch is None else args.batch
+    args.dim = 1024 if args.dim is None else args.dim
     if args.parts:
         from sln_amodal_amd import conv_hip as _ch
         _ch.PARTS = args.parts
@@ -389,6 +423,12 @@ def main():
     synthetic.warm_start_rpn(model, [dict(b, images=b["images"]) for b in batches], iters=40)
     parallel.broadcast_parameters(model)
 
+    if file_data is not None:
+        file_data.bind(model, dev)
+        file_iter = iter(file_data)
+        next_batch = lambda i: next(file_iter)       # the loader is INSIDE the timed region
+    else:
+        next_batch = lambda i: batches[i % 2]
     opt = model.make_optimizer(cfg.LEARNING_RATE)
     reducer = parallel.GradientAllReducer([p for p in model.parameters() if p.requires_grad]).attach()
     sync = (lambda params: reducer.finish()) if world > 1 else None
@@ -400,19 +440,51 @@ def main():
 
     losses = []
     from sln_amodal_amd import conv_hip
+    # Set-up, untimed: the delayed-scaling window of the fp16 x 2 operand format (conv_hip.SCALE_WINDOW productions
+    # per tensor role) is seeded with real train steps on both batches, so that the timed region starts from settled
+    # scales like a run that has been training for a while (the reference always starts from checkpoints).  These
+    # steps are ordinary optimiser steps; `config.setup_scale_settle_steps` reports them.
+    for i in range(args.settle):
+        model.train_step(next_batch(i), opt, sync)
     sat_setup = conv_hip.saturation_count()        # (host syncs outside the timed region)
     for i in range(args.warmup):
-        loss, _ = model.train_step(batches[i % 2], opt, sync)
+        loss, _ = model.train_step(next_batch(i), opt, sync)
     sat_warmup = conv_hip.saturation_count()
+    sat_snaps = [conv_hip.saturation_snapshot()]   # device-side copies, one per timed step: no host sync
     if rank == 0:
         conv_hip.PROFILE = []          # HIP-event pairs around every conv launch (launch stream)
     barrier()
     t0 = time.perf_counter()
+    step_marks = [torch.cuda.Event(enable_timing=True)]
+    step_marks[0].record()
+    depth_seen = []
     for i in range(args.steps):
-        loss, _ = model.train_step(batches[i % 2], opt, sync)
+        if file_data is not None:
+            depth_seen.append(file_data.queue_depth())
+        loss, _ = model.train_step(next_batch(i), opt, sync)
         losses.append(loss)
+        sat_snaps.append(conv_hip.saturation_snapshot())
+        step_marks.append(torch.cuda.Event(enable_timing=True))
+        step_marks[-1].record()                    # (an event record: no sync)
     barrier()
     elapsed = time.perf_counter() - t0
+    # this rank's own step times (GPU clock between the marks): a scaling run shows a straggler rank here
+    step_ms = [a.elapsed_time(b) for a, b in zip(step_marks[:-1], step_marks[1:])]
+    rank_diag = {"rank": rank, "step_ms_min": round(min(step_ms), 3), "step_ms_max": round(max(step_ms), 3),
+                 "step_ms_mean": round(sum(step_ms) / len(step_ms), 3)} if step_ms else {"rank": rank}
+    if world > 1:
+        rank_diag.update(reducer.diagnostics(last=args.steps))
+        rank_diag["cpu_affinity"] = dict(parallel.AFFINITY)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, rank_diag)
+    else:
+        gathered = [rank_diag]
+    # which tensor role clamped an operand block to +-65504, and in which timed step (empty = none did)
+    sat_events = []
+    for k_ in range(args.steps):
+        for role, shape, blocks in conv_hip.saturation_report(sat_snaps[k_], sat_snaps[k_ + 1]):
+            sat_events.append({"step": k_, "role": role, "layer_weight_shape": shape, "blocks": blocks})
+    sat_timed = conv_hip.saturation_count() - sat_warmup
     prof, conv_hip.PROFILE = conv_hip.PROFILE, None
     max_mem_gb = round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)      # (of the fp16 x 2 steps: before the strict leg)
     # the same step in the strict operand format (3 x bf16, 6 MFMA products per multiply-add: >= fp32 per
@@ -456,7 +528,9 @@ def main():
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / max(args.steps, 1), 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32",
+            "data": "synthetic" if file_data is None else
+                    "synthetic files (%d generated jpg + npz pairs, read through the input pipeline inside the timed region)" % args.files,
             "config": {"workload": "ResNet-101 + DeepLab-v2 SLN train step, stage=%s, %d x %dx%d images/GPU, "
                                    "R=100 roi slots/image, 8 GT objects/image" %
                                    (args.stage, args.batch, args.dim, args.dim),
@@ -470,8 +544,9 @@ def main():
                        "max_mem_gb": max_mem_gb,
                        # fp16 x 2 operands: blocks that had to clamp a value to +-65504 since start-up
                        # (set-up, warm-up steps, timed steps)
-                       "conv_saturated_blocks": [sat_setup, sat_warmup - sat_setup,
-                                                 conv_hip.saturation_count() - sat_warmup]},
+                       "conv_saturated_blocks": [sat_setup, sat_warmup - sat_setup, sat_timed],
+                       "conv_saturated_events_timed": sat_events,
+                       "setup_scale_settle_steps": args.settle},
             "step_roofline": {"bound": "mfma", "kernel": "whole train step (all kernels)",
                               "achieved": round(achieved, 3), "peak": round(split_peak(conv_hip.PARTS), 1),
                               "unit": "TFLOP/s", "frac": round(achieved / split_peak(conv_hip.PARTS), 4),
@@ -489,16 +564,40 @@ def main():
                                         "rccl_version": ver, "buckets": len(reducer.buckets),
                                         "bucket_launch_order": reducer.last_trace,
                                         "in_place_bytes": st_["in_place_bytes"],
-                                        "copied_bytes": st_["copied_bytes"], "copied_tensors": st_["copied_tensors"]}
+                                        "copied_bytes": st_["copied_bytes"], "copied_tensors": st_["copied_tensors"],
+                                        # self-diagnosis (round 5): per rank its own step times, the all-reduce wait
+                                        # that backward did not hide, the host cores it is pinned to
+                                        "per_rank": gathered,
+                                        "step_ms_min_over_ranks": min(g_["step_ms_min"] for g_ in gathered),
+                                        "step_ms_max_over_ranks": max(g_["step_ms_max"] for g_ in gathered),
+                                        "exposed_allreduce_wait_ms_max_over_ranks":
+                                            max(g_.get("exposed_wait_ms_mean", g_.get("host_wait_ms_mean", 0.0))
+                                                for g_ in gathered),
+                                        # batches ready when a step starts (None: synthetic resident batches)
+                                        "loader_queue_depth": (min(depth_seen) if depth_seen else None)}
             out["config"].update({"world_size_seen": dist.get_world_size(), "dist_backend": backend,
                                   "rccl_version": ver})
+        if file_data is not None:
+            rep = file_data.loader_report()
+            rep.update(queue_depth_at_step_start=depth_seen, files=args.files, generated_in_s=file_data.gen_seconds,
+                       host_cores=os.cpu_count())
+            out["loader"] = rep
+            out["config"]["loader"] = {k_: rep[k_] for k_ in ("workers", "prefetch_batches", "queue_depth_mean",
+                                                               "queue_depth_min", "consumer_wait_ms_per_batch")}
+        out["step_ms"] = {"min": rank_diag.get("step_ms_min"), "max": rank_diag.get("step_ms_max"),
+                          "mean": rank_diag.get("step_ms_mean")}
         out["launches"] = {"wgrad_reduce_batches": conv_hip.REDUCE_STATS[0], "wgrad_layers_reduced": conv_hip.REDUCE_STATS[1],
                            "crop_gradients_fused": conv_hip.GradInbox.STATS[1]}
         if strict is not None:
             st = torch.tensor([strict], dtype=torch.float64, device=dev)
             out["strict_bf16x3_images_per_sec"] = round(float(st.item()), 4)
             out["config"]["strict_bf16x3_images_per_sec"] = out["strict_bf16x3_images_per_sec"]
-        out["roofline"] = dominant_kernel_roofline(prof, elapsed, conv_hip.PARTS)
+        # the committed counter passes were collected on the headline workload: any other problem gets traffic = null
+        headline = (args.batch, args.dim, args.arch, args.stage) == (16, 1024, "resnet101", "all") and \
+            conv_hip.PARTS == 2 and nn_ops.BACKEND != "torch" and file_data is None
+        out["roofline"] = dominant_kernel_roofline(prof, elapsed, conv_hip.PARTS, replay_traffic=headline)
+        if not headline:
+            out["roofline"]["traffic_note"] = "null: the committed PMC passes belong to 16 x 1024^2 resnet101 stage=all parts=2"
         if os.environ.get("SLN_PROFILE_SHAPES"):
             agg = {}
             for e0, e1, fl, name, shape, rd, wr in prof:
@@ -511,7 +610,7 @@ def main():
                     v[3] / v[0] / 1e9, name, shape), file=sys.stderr)
         try:
             from tools import kernel_roofline
-            out["roofline_kernels"] = kernel_roofline.measure(dev)
+            out["roofline_kernels"] = kernel_roofline.measure(dev, replay_traffic=headline)
             rk = out["roofline_kernels"]
             # RoIAlign next to the dominant kernel, as scalars: the fraction of the 20 / 36 B-per-element MODEL the
             # survey defines, and the bandwidth the op really moved (measured FETCH_SIZE + WRITE_SIZE of the
@@ -539,6 +638,8 @@ def main():
         ordered = {k_: out[k_] for k_ in front if k_ in out}
         ordered.update({k_: v_ for k_, v_ in out.items() if k_ not in ordered})
         print(json.dumps(ordered))
+    if file_data is not None:
+        file_data.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

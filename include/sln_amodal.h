@@ -111,6 +111,19 @@ int sln_crop_and_resize_bwd_f32(const float *grads, const float *boxes,
  * ------------------------------------------------------------------------- */
 int sln_label_num_objects_u64(const uint64_t *label, int B, int64_t npix, int32_t *n_obj,
                               sln_stream_t stream);
+/* Loader front end (ABI 11): the nearest-neighbour zoom of the uint64 labels to the network size and the object
+ * count of the ORIGINAL labels, on the device.
+ * Replaces: utils.resize_layer (utils.py:358-362: scipy.ndimage.zoom(order=0) of the decoded planes, on a
+ *           DataLoader worker) + the flip of Functions.py:713-716 for the label, and max_objectID over the
+ *           un-resized label (Functions.py:1074-1079 as called by amodal_train.py:236-271).
+ * src       image b's label at src + b * src_stride, src_hw[2b] rows of src_hw[2b+1] pixels (device int32 [B,2]).
+ * ys, xs    [B,OH] / [B,OW] int32 device: source row / column of every output row / column (scipy's index map,
+ *           host-computed once per image size; -1 = the constant fill 0; a flipped image passes xs reversed).
+ * out       [B,OH,OW] uint64, fully written. */
+int sln_label_zoom_u64(const uint64_t *src, int64_t src_stride, const int32_t *src_hw, const int32_t *ys,
+                       const int32_t *xs, int B, int OH, int OW, uint64_t *out, sln_stream_t stream);
+int sln_label_num_objects_ragged_u64(const uint64_t *label, int B, int64_t stride, const int32_t *src_hw,
+                                     int32_t *n_obj, sln_stream_t stream);
 int sln_label_decode_u64(const uint64_t *label, int B, int H, int W, int L, int N,
                          uint8_t *planes, sln_stream_t stream);
 

@@ -24,6 +24,8 @@ SIGNATURES = {
     "sln_crop_and_resize_fwd_f32": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _i, _i, _i, _f, _p, _p, _p]),
     "sln_crop_and_resize_bwd_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
     "sln_label_num_objects_u64": (_i, [_p, _i, C.c_int64, _p, _p]),
+    "sln_label_zoom_u64": (_i, [_p, C.c_int64, _p, _p, _p, _i, _i, _i, _p, _p]),
+    "sln_label_num_objects_ragged_u64": (_i, [_p, _i, C.c_int64, _p, _p, _p]),
     "sln_label_decode_u64": (_i, [_p, _i, _i, _i, _i, _i, _p, _p]),
     "sln_mask_targets_u64": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _i, _i, _i, _p, _p]),
     "sln_proposal_decode_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, C.POINTER(_f), _f, _f, _p, _p]),

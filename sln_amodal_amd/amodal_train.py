@@ -46,7 +46,9 @@ class AmodalDataset(object):
       * the reference's per-image methods (`image_ids`, `image_info`, `load_image`, `load_layer2`) that
         model.Dataset / Functions.load_image_gt call -- host side, numpy;
       * an iterable of device-resident training BATCHES (dicts, see MaskRCNN.train_step) -- what the
-        train loop consumes.  Per image it follows load_image_gt (Functions.py:675-736) step by step:
+        train loop consumes, fed by worker processes through pinned staging buffers in a per-epoch shuffled,
+        rank-sharded order (loader.py; the reference: DataLoader(shuffle=True, num_workers=4), model.py:340-342).
+        Per image it follows load_image_gt (Functions.py:675-736) step by step:
         uint8 squash to IMAGE_MAX_DIM^2 (Pillow BILINEAR = scipy.misc.imresize), nearest zoom of the label
         with scipy.ndimage.zoom's index map (the label, not its planes, is resized: the decode is per
         pixel), `random.randint` flip, boxes jittered by `np.random.rand(4)` per instance, class id 1 for
@@ -54,10 +56,17 @@ class AmodalDataset(object):
         boxes and RPN targets are computed there."""
 
     def __init__(self, config, model, root=None, limit=-1, seed=1234, device="cuda", max_objects=None,
-                 rank=0, world=1, augment=True):
+                 rank=0, world=1, augment=True, workers=None, prefetch=3, shuffle=True, seed_order=0):
         self.config, self.model, self.device, self.seed = config, model, device, seed
         self.rank, self.world = rank, world   # data-parallel shard of the file list
         self.augment = augment
+        # input pipeline (loader.py): worker processes (0 = load on the training thread), batches in flight,
+        # per-epoch shuffle seeded by seed_order -- the SAME on every rank (the ranks cut one permutation)
+        self.workers = int(os.environ.get("SLN_LOADER_WORKERS", "8")) if workers is None else int(workers)
+        self.prefetch, self.shuffle, self.seed_order = int(prefetch), bool(shuffle), int(seed_order)
+        self._pipe, self._zoom_maps, self._mean = None, {}, None
+        self._overflow = 0
+        self._jitter_rng = np.random.RandomState((seed * 7919 + 13) % (2 ** 32))
         self.files = []
         if root:
             self.files = sorted(glob.glob(os.path.join(root, "**", "*.npz"), recursive=True))
@@ -90,68 +99,164 @@ class AmodalDataset(object):
         return label_planes_host(self._layer(image_id), config.NUM_CLASSES - 1)
 
     # ---------------------------------------------------------------- device-resident batches
-    def _load_real(self, image_ids, draws=None):
-        """Batch dict of the given images.  draws (parity tests): per image {"flip", "jitter" [n,4],
-        "rpn_priority" [A]} replaying the reference's RNG; default: `random` / `np.random` like the
-        reference's worker."""
-        import random
-        from . import utils
-        dim, N = self.config.IMAGE_MAX_DIM, self.max_objects
-        imgs, labs, jit, flips = [], [], [], []
-        for k, iid in enumerate(image_ids):
-            d = draws[k] if draws is not None else None
-            layer = self._layer(iid)
-            u8, _window, scale, _pad = utils.resize_image(self.load_image(iid), self.config.IMAGE_MIN_DIM, dim,
-                                                          self.config.IMAGE_PADDING)
-            lab = utils.resize_layer(layer, scale)
-            flip = 0
-            if self.augment:
-                flip = random.randint(0, 1) if d is None else int(d["flip"])
-            if flip:
-                u8, lab = u8[:, ::-1], lab[:, ::-1]
-            imgs.append(torch.from_numpy(np.array(u8)))          # (a writable, contiguous copy)
-            labs.append(torch.from_numpy(np.ascontiguousarray(lab).view(np.int64)))
-            # object count of the ORIGINAL label (load_layer2 runs before the resize): one draw of
-            # np.random.rand(4) per object, in order, like utils.extract_bboxes
-            lo = np.unique(layer & np.uint64(0xFFFFFFFF))
-            tops = set(int(v).bit_length() - 1 for v in lo if v)
-            n = 0
-            while n in tops:
-                n += 1
-            if n > N:
-                raise ValueError("image %s has %d objects, the batch holds %d slots" % (iid, n, N))
-            u = np.zeros((N, 4), np.float64)
-            u[:n] = np.random.rand(n, 4) if d is None else np.asarray(d["jitter"], np.float64).reshape(n, 4)
-            jit.append((n, u))
-            flips.append(flip)
-        dev = self.device
+    def _assemble(self, u8, labels, src_hw, src_hw_host, flips, jitter, host_zoomed=None, rpn_priority=None):
+        """The device half of load_image_gt (Functions.py:675-736) for a whole batch, no host sync:
+        u8 [B,dim,dim,3] uint8 (already flipped), labels [B, stride] int64 -- the ORIGINAL labels, image b with
+        src_hw[b] = (H0, W0) -- flips (host list), jitter [B,N,4] float64 uniform draws (row i = object i).
+        Nearest zoom of the label on the device with scipy's index maps (a flip = the reversed column map), object
+        count of the original label, molding, tight boxes + jitter, class ids, RPN targets."""
+        from . import ops, utils
+        dev, dim, N = self.device, self.config.IMAGE_MAX_DIM, self.max_objects
+        B = u8.shape[0]
+        ys = np.empty((B, dim), np.int32)
+        xs = np.empty((B, dim), np.int32)
+        for b in range(B):
+            h0, w0 = int(src_hw_host[b][0]), int(src_hw_host[b][1])
+            key = (h0, w0, dim)
+            maps = self._zoom_maps.get(key)
+            if maps is None:
+                # utils.resize_layer: output size round(n * scale), scale = dim / n -- dim for every n.  (A label the
+                # worker already zoomed -- one that did not fit a loader slot -- arrives at dim x dim: identity maps.)
+                oh = utils.zoom_output_size(h0, dim / h0)
+                ow = utils.zoom_output_size(w0, dim / w0)
+                if (oh, ow) != (dim, dim):
+                    raise ValueError("label %dx%d does not zoom to %d^2 (%dx%d)" % (h0, w0, dim, oh, ow))
+                maps = (utils.zoom_nearest_index(h0, dim).astype(np.int32),
+                        utils.zoom_nearest_index(w0, dim).astype(np.int32))
+                if len(self._zoom_maps) < 4096:
+                    self._zoom_maps[key] = maps
+            ys[b] = maps[0]
+            xs[b] = maps[1][::-1] if flips[b] else maps[1]       # the label in the slot is never flipped
+        idx = torch.from_numpy(np.concatenate([ys, xs], axis=1))
+        idx = (idx.pin_memory() if torch.device(dev).type == "cuda" else idx).to(dev, non_blocking=True)
+        labels_z = ops.label_zoom(labels, src_hw, idx[:, :dim].contiguous(), idx[:, dim:].contiguous())
+        counts = ops.label_num_objects_ragged(labels, src_hw).to(torch.int64)
+        # more objects than slots: counted on the device, read where the loop syncs anyway (health())
+        self._overflow = self._overflow + (counts > N).sum()
+        counts = counts.clamp(max=N)
         # mold_image (Functions.py:654-660): uint8 -> float32, minus the float64 mean pixel (the difference is
         # formed in float64 and rounded to float32 once, by the later .float())
-        mean = torch.tensor(np.asarray(self.config.MEAN_PIXEL, np.float64), dtype=torch.float64, device=dev)
-        images = (torch.stack(imgs).to(dev).double() - mean).float().permute(0, 3, 1, 2).contiguous(
-            memory_format=torch.channels_last)
-        labels = torch.stack(labs).to(dev)
-        tight = extract_bboxes_from_labels(labels, N)
-        u = torch.from_numpy(np.stack([j[1] for j in jit])).to(dev)
+        mean = self._mean
+        if mean is None:
+            mean = self._mean = torch.tensor(np.asarray(self.config.MEAN_PIXEL, np.float64), dtype=torch.float64,
+                                             device=dev)
+        images = (u8.double() - mean).float().permute(0, 3, 1, 2).contiguous(memory_format=torch.channels_last)
+        tight = extract_bboxes_from_labels(labels_z, N)
+        u = torch.from_numpy(np.ascontiguousarray(jitter, np.float64))
+        u = (u.pin_memory() if torch.device(dev).type == "cuda" else u).to(dev, non_blocking=True)
         boxes = utils.jitter_boxes(tight, u)
-        counts = torch.tensor([j[0] for j in jit], device=dev)
         ids = (torch.arange(N, device=dev)[None, :] < counts[:, None]).to(torch.int32)
         boxes = torch.where(ids[..., None] > 0, boxes, torch.zeros_like(boxes)).float()
+        match, bbox = build_rpn_targets((dim, dim, 3), self.model.anchors_f64, ids, boxes, self.config,
+                                        priority=rpn_priority)
+        return {"images": images, "image_metas": None, "gt_class_ids": ids, "gt_boxes": boxes,
+                "gt_layer": labels_z, "rpn_match": match.unsqueeze(2), "rpn_bbox": bbox, "flipped": list(flips)}
+
+    def _load_real(self, image_ids, draws=None, flips=None):
+        """Batch dict of the given images, loaded on THIS thread (parity tests, calibration, tiny runs; the train loop
+        goes through the worker pipeline, see __iter__).  draws (parity tests): per image {"flip", "jitter" [n,4],
+        "rpn_priority" [A]} replaying the reference's RNG; default: `random` / `np.random` like the reference's
+        worker."""
+        import random
+        from . import loader
+        dim, N = self.config.IMAGE_MAX_DIM, self.max_objects
+        B = len(image_ids)
+        imgs, labs, fl = [], [], []
+        jitter = np.zeros((B, N, 4), np.float64)
+        for k, iid in enumerate(image_ids):
+            d = draws[k] if draws is not None else None
+            u8, layer = loader.load_item(self.image_info[iid], dim)
+            flip = 0
+            if self.augment:
+                flip = (random.randint(0, 1) if flips is None else int(flips[k])) if d is None else int(d["flip"])
+            imgs.append(np.ascontiguousarray(u8[:, ::-1] if flip else u8))
+            labs.append(layer)
+            fl.append(flip)
+            if d is None:
+                jitter[k] = np.random.rand(N, 4)
+            else:       # one draw of np.random.rand(4) per object of the ORIGINAL label, in order (utils.extract_bboxes)
+                jd = np.asarray(d["jitter"], np.float64).reshape(-1, 4)
+                if jd.shape[0] > N:
+                    raise ValueError("image %s has %d objects, the batch holds %d slots" % (iid, jd.shape[0], N))
+                jitter[k, :jd.shape[0]] = jd
+        dev = self.device
+        hw = np.array([l.shape for l in labs], np.int32)
+        stride = int((max(int(h) * int(w) for h, w in hw) + 7) // 8 * 8)
+        flat = np.zeros((B, stride), np.int64)
+        for k, l in enumerate(labs):
+            flat[k, :l.size] = l.reshape(-1).view(np.int64)
         pr = None
         if draws is not None and all("rpn_priority" in d for d in draws):
             pr = torch.stack([torch.as_tensor(d["rpn_priority"]) for d in draws]).to(dev)
-        match, bbox = build_rpn_targets((dim, dim, 3), self.model.anchors_f64, ids, boxes, self.config,
-                                        priority=pr)
-        return {"images": images, "image_metas": None, "gt_class_ids": ids, "gt_boxes": boxes,
-                "gt_layer": labels, "rpn_match": match.unsqueeze(2), "rpn_bbox": bbox, "flipped": flips}
+        return self._assemble(torch.from_numpy(np.stack(imgs)).to(dev), torch.from_numpy(flat).to(dev),
+                              torch.from_numpy(hw).to(dev), hw, fl, jitter, rpn_priority=pr)
+
+    # ---------------------------------------------------------------- the worker pipeline
+    def start_workers(self):
+        """Spawn the loader's worker processes now -- call before the process touches the GPU when possible
+        (amodal_train.main and bench.py do); __iter__ starts them otherwise."""
+        if self.files and self.workers > 0 and self._pipe is None:
+            from . import loader
+            sampler = loader.EpochSampler(len(self.files), self.config.BATCH_SIZE, self.rank, self.world,
+                                          seed=self.seed_order, shuffle=self.shuffle, flip=self.augment)
+            self._pipe = loader.PrefetchLoader(self.image_info, self.config.IMAGE_MAX_DIM, self.config.BATCH_SIZE,
+                                               sampler, workers=self.workers, depth=self.prefetch,
+                                               device=self.device).start()
+        return self
+
+    def bind(self, model, device):
+        """Late binding for a dataset whose workers were started before the process touched the GPU (the model --
+        its anchors -- and the device did not exist yet)."""
+        self.model, self.device = model, device
+        if self._pipe is not None:
+            self._pipe.device = device
+        return self
+
+    def close(self):
+        if self._pipe is not None:
+            self._pipe.close()
+            self._pipe = None
+
+    def loader_report(self):
+        """Queue depth / consumer wait of the worker pipeline (None without one) + images with more objects than
+        slots (host sync)."""
+        rep = self._pipe.report() if self._pipe is not None else None
+        if rep is not None:
+            rep["images_over_object_slots"] = int(self._overflow)
+        return rep
+
+    def queue_depth(self):
+        return self._pipe.queue_depth() if self._pipe is not None else None
 
     def __iter__(self):
         B, dim, step = self.config.BATCH_SIZE, self.config.IMAGE_MAX_DIM, 0
+        if self.files and self.workers > 0:
+            # worker processes -> shared-memory slots -> pinned staging -> copy stream; this thread waits on an
+            # event and runs the device half (loader.py)
+            self.start_workers()
+            N = self.max_objects
+            for item in self._pipe:
+                if item["ready"] is not None:
+                    torch.cuda.current_stream(self.device).wait_event(item["ready"])
+                    for t in (item["u8"], item["labels"], item["src_hw"]):
+                        t.record_stream(torch.cuda.current_stream(self.device))
+                jitter = self._jitter_rng.rand(B, N, 4)
+                yield self._assemble(item["u8"], item["labels"], item["src_hw"], item["src_hw_host"], item["flips"],
+                                     jitter, host_zoomed=item["host_zoomed"])
+            return
+        sampler = None
+        if self.files:
+            from . import loader
+            sampler = loader.EpochSampler(len(self.files), B, self.rank, self.world, seed=self.seed_order,
+                                          shuffle=self.shuffle, flip=self.augment)
+        epoch, plan = 0, []
         while True:
             if self.files:
-                # disjoint shards: global step `step` covers files [step*world*B, (step+1)*world*B)
-                idx = [((step * self.world + self.rank) * B + i) % len(self.files) for i in range(B)]
-                yield self._load_real(idx)
+                if not plan:
+                    plan = sampler.epoch(epoch)
+                    epoch += 1
+                ids, flips = plan.pop(0)
+                yield self._load_real([int(i) for i in ids], flips=flips)
             else:
                 yield synthetic.make_batch(self.config, B, dim, dim, n_obj=self.max_objects,
                                            seed=self.seed + step, device=self.device,
@@ -199,6 +304,9 @@ def parse_args(argv=None):
     ap.add_argument("--image-dim", default=1024, type=int)
     ap.add_argument("--batch", default=None, type=int, help="images per GPU")
     ap.add_argument("--steps-per-epoch", default=None, type=int)
+    ap.add_argument("--workers", default=None, type=int,
+                    help="loader worker processes per rank (default 8, SLN_LOADER_WORKERS; 0 = load on the training "
+                         "thread; the reference: DataLoader(num_workers=4), model.py:340-342)")
     return ap.parse_args(argv)
 
 
@@ -244,7 +352,18 @@ def build_run(args):
 def main(argv=None):
     args = parse_args(argv)
     config, model, model_path = build_run(args)
+    # the input pipeline's worker processes start BEFORE this process touches the GPU (rank / world from the
+    # launcher's environment; parallel.init_distributed reads the same variables)
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    data = AmodalDataset(config, model, None if args.synthetic else args.dataset, args.limit,
+                         seed=1234 + rank, device="cpu", rank=rank, world=world, workers=args.workers,
+                         shuffle=args.command == "train", augment=args.command == "train")
+    if args.command == "train":
+        parallel.set_cpu_affinity(int(os.environ.get("LOCAL_RANK", "0")),
+                                  int(os.environ.get("LOCAL_WORLD_SIZE", world)))   # the workers inherit the share
+        data.start_workers()
     if not torch.cuda.is_available():
+        data.close()
         raise RuntimeError("amodal_train %s: the run itself needs an MI355X -- sln_amodal_amd has no CPU path "
                            "(NMS, RoIAlign, the conv stacks and the inference tail live in "
                            "libsln_amodal_hip.so); the plumbing up to here (config, model, checkpoints) ran" %
@@ -253,8 +372,7 @@ def main(argv=None):
     device = torch.device("cuda", local)
     torch.cuda.set_device(local)
     model.to(device)
-    data = AmodalDataset(config, model, None if args.synthetic else args.dataset, args.limit,
-                         seed=1234 + rank, device=device, rank=rank, world=world)
+    data.bind(model, device)
 
     if args.command == "train" and not os.path.exists(str(model_path)):
         # no checkpoint: emulate pretrained statistics.  Calibrate FIRST (the batch is rank-specific),

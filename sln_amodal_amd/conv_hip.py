@@ -149,7 +149,7 @@ SCALE_WINDOW = 16           # the scale follows the maximum over this many recen
 class _Slot(object):
     """One tensor role of one layer: views of its device-side scale / running amax.  The table entry goes
     back to the book when the slot dies (with its layer)."""
-    __slots__ = ("scale", "amax", "hist", "cursor", "fresh", "book", "idx")
+    __slots__ = ("scale", "amax", "hist", "cursor", "fresh", "book", "idx", "sat")
 
     def __del__(self):
         try:
@@ -164,6 +164,7 @@ class _Slot(object):
         self.amax = book.amax[idx:idx + 1]
         self.hist = book.hist[0, idx:idx + 1]      # column idx of the ring (row stride = capacity)
         self.cursor = book.cursor[idx:idx + 1]
+        self.sat = book.saturated[idx:idx + 1]     # this role's own clamp counter (blocks that clamped to +-65504)
         self.fresh = True            # no scale yet: the first producer bootstraps it from an amax pass
 
 
@@ -174,7 +175,8 @@ class ScaleBook(object):
         self.scale = torch.ones(capacity, dtype=torch.float32, device=device)
         self.hist = torch.zeros((SCALE_WINDOW, capacity), dtype=torch.float32, device=device)   # ring of maxima
         self.cursor = torch.zeros(capacity, dtype=torch.int32, device=device)
-        self.saturated = torch.zeros(1, dtype=torch.int32, device=device)
+        # one clamp counter PER SLOT (round 5: the bench line says which tensor role clamped, and in which step)
+        self.saturated = torch.zeros(capacity, dtype=torch.int32, device=device)
         self.n = 0
         self._n_written, self._n_reduced = None, False
         self.free = []               # indices of dead slots (a heap: the lowest index is reused first, so
@@ -273,7 +275,27 @@ def check_ranks():
 
 def saturation_count():
     """Blocks that clamped a value to +-65504 since the start (host sync; tests / monitoring)."""
-    return sum(int(b.saturated.item()) for b in _books.values())
+    return sum(int(b.saturated.sum().item()) for b in _books.values())
+
+
+def saturation_snapshot():
+    """Device-side copy of every book's per-slot clamp counters (no host sync): take one per step, diff them with
+    saturation_report() afterwards to learn which tensor role clamped in which step."""
+    return {i: b.saturated.clone() for i, b in _books.items()}
+
+
+def saturation_report(before=None, after=None):
+    """[(role key, owner shape, blocks)] of the slots whose clamp counter moved between two snapshots (host sync).
+    before=None: since start-up; after=None: now."""
+    out = []
+    for i, b in _books.items():
+        cur = (after[i] if after is not None else b.saturated).cpu()
+        if before is not None and i in before:
+            cur = cur - before[i].cpu()
+        for idx in torch.nonzero(cur).flatten().tolist():
+            key, shape = b.names.get(idx, (("?",), ()))
+            out.append(("/".join(str(k) for k in key), list(shape), int(cur[idx])))
+    return out
 
 
 def _slot(owner, key):
@@ -294,7 +316,7 @@ def _q3(slot):
     """(q_scale, q_amax, q_saturated) pointer triple of a slot (NULLs without one)."""
     if slot is None:
         return None, None, None
-    return ops._ptr(slot.scale), ops._ptr(slot.amax), ops._ptr(slot.book.saturated)
+    return ops._ptr(slot.scale), ops._ptr(slot.amax), ops._ptr(slot.sat)
 
 
 def supports(conv, x):
@@ -387,7 +409,7 @@ def _register_weight_split(weight, flip, layout, out, slot, geom):
     total = out.numel() // 2
     _WSPLIT[(id(weight), flip, layout)] = dict(ref=weakref.ref(weight), flip=flip, layout=layout, out=out, slot=slot,
                                                desc=(weight.data_ptr(), out.data_ptr(), slot.scale.data_ptr(),
-                                                     slot.amax.data_ptr(), slot.book.saturated.data_ptr(), so, si, skh,
+                                                     slot.amax.data_ptr(), slot.sat.data_ptr(), so, si, skh,
                                                      skw, total, O, I, Ip, KH, KW, 1 if flip else 0, layout, 0))
     _WSPLIT_STATE["order"] = None        # the device table is rebuilt at the next refresh
 
@@ -1147,9 +1169,10 @@ class _ConvFn(torch.autograd.Function):
             # queued on this stream by now and is complete when the side stream passes the event
             rst = _reduce_state(weight.device)
             sink_used = False
+            # a SECOND gradient of this weight inside the pass (decided before this gradient leaves its own mark)
+            second = id(own) in rst[1] or id(own) in _side_state(weight.device)[1]
             if DETERMINISTIC_WGRAD and GRAD_SINK is not None and own.is_leaf and \
-                    own.data_ptr() == weight.data_ptr() and tuple(own.shape) == (Co, Ci, KH, KW) and \
-                    id(own) not in rst[1] and id(own) not in _side_state(weight.device)[1]:
+                    own.data_ptr() == weight.data_ptr() and tuple(own.shape) == (Co, Ci, KH, KW) and not second:
                 # the parameter's slot of its all-reduce bucket: autograd adopts the view as .grad (no pack /
                 # unpack copies around the collective).  Only the weight's FIRST gradient of a pass goes there:
                 # a weight used several times per pass (the RPN convs: five pyramid levels) gets private memory
@@ -1300,7 +1323,7 @@ class _ConvFn(torch.autograd.Function):
             else:
                 if id(own) in _side_state(weight.device)[1]:
                     main.wait_stream(_side_state(weight.device)[0])    # autograd adds this one to the first on this stream
-                if not defer and id(own) in rst[1]:
+                if not defer and second:
                     flush_wgrad_reduces()                              # ... and the first must be complete by then
                 SIDE_STATS[1] += 1
             with torch.cuda.stream(side[0] if side is not None else main):

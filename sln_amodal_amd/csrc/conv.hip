@@ -76,9 +76,9 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 #define SLN_SWZH(r) (((r) >> 1) & 3)
 #ifndef SLN_W8_DEPTH
 #define SLN_W8_DEPTH 2      // half slabs of residual / mask rows in flight ahead, single-epilogue instances of the 256^2 kernel
+#endif
 #ifndef SLN_W8_DOUBLE_STAGE
 #define SLN_W8_DOUBLE_STAGE 1   // two staging slabs in the epilogues of the kernels that own the CU's LDS (0: one, A/B builds)
-#endif
 #endif
 
 struct SplitScale {

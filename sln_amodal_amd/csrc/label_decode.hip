@@ -154,6 +154,84 @@ extern "C" int sln_label_num_objects_u64(const uint64_t *label, int B, int64_t n
     return sln_launch_status();
 }
 
+// ---------------------------------------------------------------- loader front end (round 5)
+// Nearest-neighbour zoom of the uint64 labels of a batch to the network size, on the device: the reference's
+// utils.resize_layer (utils.py:358-362) is scipy.ndimage.zoom(order=0) of the decoded planes on a DataLoader worker
+// (12 ms per 1024^2 image on a host core); the label itself is zoomed here instead (the decode is per pixel, so
+// decoding the zoomed label equals zooming the decoded planes) with scipy's index maps, which the host computes
+// once per image size (utils.zoom_nearest_index: OH + OW integers, -1 = the constant fill 0).  A horizontal flip
+// (Functions.py:713) is the reversed xs map.  Image b's label lies at src + b * src_stride with row pitch
+// src_hw[2b+1]; 16 B written per lane (two output pixels), gathered 8-B reads.
+__global__ __launch_bounds__(256) void label_zoom_kernel(const u64 *__restrict__ src, long src_stride,
+                                                         const int32_t *__restrict__ src_hw,
+                                                         const int32_t *__restrict__ ys,
+                                                         const int32_t *__restrict__ xs, int OH, int OW,
+                                                         u64 *__restrict__ out) {
+    const int b = blockIdx.z, oy = blockIdx.y;
+    const int W0 = src_hw[2 * b + 1];
+    const int sy = ys[(long)b * OH + oy];
+    const u64 *row = src + (long)b * src_stride + (long)(sy < 0 ? 0 : sy) * W0;
+    u64 *dst = out + ((long)b * OH + oy) * OW;
+    const int32_t *xb = xs + (long)b * OW;
+    for (int ox = (blockIdx.x * 256 + threadIdx.x) * 2; ox < OW; ox += gridDim.x * 512) {
+        const int x0 = xb[ox], x1 = ox + 1 < OW ? xb[ox + 1] : -1;
+        const u64 v0 = (sy >= 0 && x0 >= 0) ? row[x0] : 0ull;
+        const u64 v1 = (sy >= 0 && x1 >= 0) ? row[x1] : 0ull;
+        if (ox + 1 < OW && (OW & 1) == 0) {
+            *(ulonglong2 *)(dst + ox) = make_ulonglong2(v0, v1);
+        } else {
+            dst[ox] = v0;
+            if (ox + 1 < OW) dst[ox + 1] = v1;
+        }
+    }
+}
+
+extern "C" int sln_label_zoom_u64(const uint64_t *src, int64_t src_stride, const int32_t *src_hw, const int32_t *ys,
+                                  const int32_t *xs, int B, int OH, int OW, uint64_t *out, sln_stream_t stream) {
+    sln_enter();
+    if (B < 0 || OH < 0 || OW < 0 || src_stride < 0) return SLN_ERR_INVALID_ARG;
+    if (B == 0 || OH == 0 || OW == 0) return SLN_OK;
+    if (!src || !src_hw || !ys || !xs || !out || B > 65535 || OH > 65535) return SLN_ERR_INVALID_ARG;
+    int gx = sln_div_up(OW, 512);
+    hipLaunchKernelGGL(label_zoom_kernel, dim3(gx, OH, B), dim3(256), 0, (hipStream_t)stream, (const u64 *)src,
+                       (long)src_stride, src_hw, ys, xs, OH, OW, (u64 *)out);
+    return sln_launch_status();
+}
+
+// Object counts of labels of DIFFERENT sizes packed at a fixed stride (the original, un-zoomed labels of a batch:
+// load_layer2 counts before the resize): image b holds src_hw[2b] * src_hw[2b+1] valid pixels.
+__global__ __launch_bounds__(256) void label_tops_ragged_kernel(const u64 *__restrict__ label, long stride,
+                                                                const int32_t *__restrict__ src_hw,
+                                                                unsigned *__restrict__ tops) {
+    const int b = blockIdx.y;
+    const u64 *lab = label + (size_t)b * stride;
+    const long npix = (long)src_hw[2 * b] * src_hw[2 * b + 1];
+    unsigned acc = 0;
+    for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < npix; p += (long)gridDim.x * 256) {
+        const unsigned vis = (unsigned)lab[p];
+        if (vis) acc |= 1u << (31 - __clz(vis));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc |= __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0 && acc) atomicOr(tops + b, acc);
+}
+
+extern "C" int sln_label_num_objects_ragged_u64(const uint64_t *label, int B, int64_t stride, const int32_t *src_hw,
+                                                int32_t *n_obj, sln_stream_t stream) {
+    sln_enter();
+    if (B < 0 || stride < 0) return SLN_ERR_INVALID_ARG;
+    if (B == 0) return SLN_OK;
+    if (!n_obj || !label || !src_hw || B > 65535) return SLN_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(n_obj, 0, sizeof(int32_t) * (size_t)B, st) != hipSuccess) return SLN_ERR_LAUNCH;
+    int gx = sln_div_up(stride > 0 ? stride : 1, 256 * 8);
+    if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL(label_tops_ragged_kernel, dim3(gx, B), dim3(256), 0, st, (const u64 *)label, (long)stride,
+                       src_hw, (unsigned *)n_obj);
+    hipLaunchKernelGGL(label_count_kernel, dim3(sln_div_up(B, 64)), dim3(64), 0, st, (const unsigned *)n_obj, B, n_obj);
+    return sln_launch_status();
+}
+
 extern "C" int sln_label_decode_u64(const uint64_t *label, int B, int H, int W, int L, int N,
                                     uint8_t *planes, sln_stream_t stream) {
     sln_enter();

@@ -126,6 +126,36 @@ def label_num_objects(label):
     return n
 
 
+def label_zoom(src, src_hw, ys, xs):
+    """src [B, stride] int64/uint64 (image b: src_hw[b] = (H0, W0) valid rows x columns, row pitch W0), ys [B,OH] /
+    xs [B,OW] int32 index maps (-1 = fill 0) -> [B,OH,OW] int64: scipy.ndimage.zoom(order=0) of every label
+    (utils.resize_layer, utils.py:358-362) on the device; a flipped image passes xs reversed."""
+    if not src.is_cuda:
+        raise RuntimeError("label must live on the GPU")
+    if src.dtype not in (torch.int64, torch.uint64) or src.dim() != 2 or not src.is_contiguous():
+        raise TypeError("src must be a contiguous [B, stride] tensor of 64-bit patterns")
+    B, OH, OW = src.shape[0], ys.shape[1], xs.shape[1]
+    for t, nm in ((src_hw, "src_hw"), (ys, "ys"), (xs, "xs")):
+        _need(t, torch.int32, nm)
+        if not t.is_contiguous() or t.shape[0] != B:
+            raise ValueError("%s must be contiguous with one row per image" % nm)
+    out = torch.empty((B, OH, OW), dtype=torch.int64, device=src.device)
+    _lib.check(_lib.lib().sln_label_zoom_u64(_ptr(src), src.shape[1], _ptr(src_hw), _ptr(ys), _ptr(xs), B, OH, OW,
+                                             _ptr(out), _stream()), "sln_label_zoom_u64")
+    return out
+
+
+def label_num_objects_ragged(src, src_hw):
+    """Object counts [B] int32 of labels of different sizes packed as src [B, stride] (see label_zoom)."""
+    if not src.is_cuda or src.dtype not in (torch.int64, torch.uint64) or src.dim() != 2 or not src.is_contiguous():
+        raise TypeError("src must be a contiguous [B, stride] device tensor of 64-bit patterns")
+    _need(src_hw, torch.int32, "src_hw")
+    n = torch.empty((src.shape[0],), dtype=torch.int32, device=src.device)
+    _lib.check(_lib.lib().sln_label_num_objects_ragged_u64(_ptr(src), src.shape[0], src.shape[1], _ptr(src_hw),
+                                                           _ptr(n), _stream()), "sln_label_num_objects_ragged_u64")
+    return n
+
+
 def _as_u64(label):
     if not label.is_cuda:
         raise RuntimeError("label must live on the GPU")

@@ -24,6 +24,7 @@ def init_distributed(backend=None, timeout_s=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    set_cpu_affinity(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)))   # before anything touches the GPU
     if torch.cuda.is_available() and torch.cuda.device_count() > 0:
         local = local % torch.cuda.device_count()     # (several ranks may share a GPU in gloo test runs)
     if world > 1 and not dist.is_initialized():
@@ -38,6 +39,30 @@ def init_distributed(backend=None, timeout_s=None):
         dist.init_process_group(backend=backend, rank=rank, world_size=world,
                                 timeout=datetime.timedelta(seconds=tmo))
     return rank, local, world
+
+
+AFFINITY = {}
+
+
+def set_cpu_affinity(local_rank, local_world):
+    """One process per GPU: pin this rank (and the loader workers it will start) to its own contiguous share of the
+    host cores, so that eight ranks' Python threads and input workers do not migrate over each other
+    (SLN_CPU_AFFINITY=0 leaves the scheduler alone).  Called before any GPU call; a no-op for a single rank.
+    The result is kept in AFFINITY for the bench line (`gradient_exchange.cpu_affinity`)."""
+    AFFINITY.clear()
+    if local_world <= 1 or os.environ.get("SLN_CPU_AFFINITY", "1") == "0" or not hasattr(os, "sched_setaffinity"):
+        return None
+    try:
+        cores = sorted(os.sched_getaffinity(0))
+        per = len(cores) // local_world
+        if per < 1:
+            return None
+        mine = cores[local_rank * per:(local_rank + 1) * per]
+        os.sched_setaffinity(0, mine)
+        AFFINITY.update(cores=len(mine), first=mine[0], last=mine[-1])
+        return mine
+    except OSError:
+        return None
 
 
 def broadcast_parameters(module, src=0):
@@ -98,6 +123,9 @@ class GradientAllReducer(object):
         # the order in which this pass's collectives were issued, and (kept until the next finish()) the previous
         # pass's: must be the same sequence on every rank -- 0, 1, 2, ... -- whatever order the gradients arrived in
         self.trace, self.last_trace = [], []
+        # self-diagnosis of a scaling run (round 5): per finish() the time the main stream (nccl) / the host (gloo)
+        # stood waiting for the collectives -- the part of the exchange that backward did NOT hide
+        self._wait_events, self._wait_host_s, self._finishes = [], [], 0
 
     # ------------------------------------------------------------------ slots
     def _storage(self, bi):
@@ -196,8 +224,23 @@ class GradientAllReducer(object):
         while self._next < len(self.buckets):   # grads that never arrived (unused params): reduce now, in order
             self._launch(self._next)
             self._next += 1
+        cuda = bool(self.params) and self.params[0].is_cuda
+        if cuda:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+        import time
+        h0 = time.perf_counter()
         for bi, bucket in enumerate(self.buckets):
             self._work[bi].wait()
+        self._wait_host_s.append(time.perf_counter() - h0)
+        if cuda:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()                              # (nothing but the waits lies between the two events)
+            self._wait_events.append((e0, e1))
+            del self._wait_events[:-256]
+        del self._wait_host_s[:-256]
+        self._finishes += 1
+        for bi, bucket in enumerate(self.buckets):
             self._flat[bi].div_(self.world)
             for p in bucket:
                 view = self.slot_view(p)
@@ -207,6 +250,22 @@ class GradientAllReducer(object):
         self._pending = [len(b) for b in self.buckets]
         self._next = 0
         self.last_trace, self.trace = self.trace, []
+
+    def diagnostics(self, last=None):
+        """Exposed all-reduce wait of the last `last` finish() calls (host sync: call it after the timed region):
+        `exposed_wait_ms_*` is GPU time the main stream stood behind the collectives (backend nccl: work.wait() is a
+        stream wait), `host_wait_ms_*` what the host thread spent in work.wait() (the whole wait under gloo)."""
+        ev = self._wait_events[-last:] if last else self._wait_events
+        hs = self._wait_host_s[-last:] if last else self._wait_host_s
+        out = {"finishes": self._finishes, "buckets": len(self.buckets),
+               "bucket_mib": [round(n * 4 / 2 ** 20, 1) for n in self._size]}
+        if ev:
+            torch.cuda.synchronize()
+            ms = [a.elapsed_time(b) for a, b in ev]
+            out.update(exposed_wait_ms_mean=round(sum(ms) / len(ms), 3), exposed_wait_ms_max=round(max(ms), 3))
+        if hs:
+            out.update(host_wait_ms_mean=round(1e3 * sum(hs) / len(hs), 3), host_wait_ms_max=round(1e3 * max(hs), 3))
+        return out
 
     def __call__(self, params=None):
         self.finish()

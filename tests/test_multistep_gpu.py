@@ -52,63 +52,92 @@ def _step_inputs(g, k):
 DEEP = ("fpn.C1", "fpn.C2", "fpn.C3", "fpn.C4")
 
 
-def test_five_optimiser_steps_follow_the_reference_loop():
-    """Measured (profiles/r4_*_gpu_suite.log): the six losses stay within 4e-4 of the reference's over all five
-    steps (6e-8 at step 0), the clip norm within 1e-3.  The 256-element slices of the backbone weights deep under
-    many ReLUs (fpn.C1..C4) accumulate ReLU-switch differences of their updates (0.08 at step 1, 0.16 at step 2 on
-    fpn.C2.2.conv2) exactly like two fp32 convolution implementations do among themselves (the control run of the
-    next test); the heads, FPN and RPN slices stay tight."""
+def _replay_reference_loop(g, backend):
+    """K optimiser steps of the recorded reference loop on one conv backend -> per step (|dloss| max, relative clip
+    norm error, worst cumulative-update error of the backbone slices (value, name), of the other slices), plus the
+    optimiser (skip counter)."""
+    from sln_amodal_amd import nn_ops
+    K = int(g["steps"])
+    nn_ops.BACKEND = backend
+    try:
+        m, cfg = e2e_model("cuda")
+        assert tuple(float(v) for v in cfg.MEAN_PIXEL) == (123.7, 116.8, 103.9)
+        params = dict(m.named_parameters())
+        names = [str(n) for n in g["names"]]
+        for n in names:
+            assert np.array_equal(params[n].detach().reshape(-1)[:256].cpu().numpy(), g["before/" + n]), n
+        opt = m.make_optimizer(float(g["lr"]))
+        rows = []
+        for k in range(K):
+            batch, pr = _step_inputs(g, k)
+            loss, parts = m.train_step(batch, opt, priorities=pr)
+            want = g["s%d/losses" % k]
+            got = np.array([float(parts[LOSS_KEYS[str(n)]].detach()) for n in g["loss_names"]])
+            norm, want_norm = float(m.last_grad_norm), float(g["s%d/total_norm" % k])
+            errs = {}
+            for n in names:
+                # the model CONTINUES from its own weights (never re-seated on the reference's): the error of the
+                # cumulative change since step 0's start, relative to the reference's cumulative change
+                after = g["s%d/after/%s" % (k, n)].astype(np.float64)
+                base = g["before/" + n].astype(np.float64)
+                d_got = params[n].detach().reshape(-1)[:256].double().cpu().numpy() - base
+                errs[n] = np.linalg.norm(d_got - (after - base)) / max(np.linalg.norm(after - base), 1e-30)
+            rows.append({"dl": float(np.abs(got - want).max()), "total": float(got.sum()), "want_total": float(want.sum()),
+                         "norm": norm, "want_norm": want_norm, "dnorm": abs(norm - want_norm) / want_norm,
+                         "deep": max((e, n) for n, e in errs.items() if n.startswith(DEEP)),
+                         "rest": max((e, n) for n, e in errs.items() if not n.startswith(DEEP))})
+        return rows, opt
+    finally:
+        nn_ops.BACKEND = "hip"
+
+
+# Absolute ceilings per step (measured on scene 0, profiles/r4_*_gpu_suite.log: losses 6e-8, 3e-4, 2e-4, 1.8e-2, 2.0e-2;
+# backbone slices 1.3e-3, 5.7e-2, 0.10, 0.26, 0.33 -- one 256-element slice of C2 under ~90 ReLU layers; heads / FPN /
+# RPN slices 1e-6, 1.8e-2, 2.2e-2, 3.5e-2, 3.9e-2).  Steps 1 and 2 are held to ~2.5 x their measured values instead of
+# the one bound every later step used to share (ADVICE r4); the reference's own step 3 is an excursion (mrcnn_class
+# 1.05 -> 3.48, total 6.13) behind which the run-to-run spread of ONE build is as large as its distance from the
+# reference, so steps 3 and 4 share a bound.
+LOSS_TOL = [1e-4, 1e-3, 1e-3, 5e-2, 5e-2]
+DEEP_TOL = [2e-2, 0.15, 0.25, 0.6, 0.6]
+REST_TOL = [2e-3, 0.05, 0.06, 0.1, 0.1]
+# ... and RELATIVE to the control: aten fp32 convolutions replaying the same fixture in the same test.  Both are fp32
+# implementations other than the reference's (CPU) one; the product path may be as far from the reference as aten is,
+# times a small factor (the two differ from each other run to run by up to ~2 x), plus a floor where aten's own
+# error is at rounding level.
+CONTROL_FACTOR = 3.0
+
+
+@pytest.mark.parametrize("scene", [0, 1])
+def test_five_optimiser_steps_follow_the_reference_loop(scene):
+    """The product path replays the reference's own five optimiser steps (recorded inputs, draws, proposals) and is
+    held (i) to per-step absolute ceilings and (ii) to CONTROL_FACTOR x the distance ATEN's convolutions keep from
+    the same fixture in the same run: the six losses, the clip norm, and the cumulative update
+    of watched 256-element parameter slices.  Deep backbone slices (fpn.C1..C4) accumulate ReLU-switch differences
+    exactly like two fp32 convolution implementations do among themselves; heads, FPN and RPN slices stay tight."""
     from sln_amodal_amd import conv_hip
     sat0 = conv_hip.saturation_count()          # (a counter of the whole process)
-    g = golden("e2e_multistep_0")
-    K = int(g["steps"])
-    m, cfg = e2e_model("cuda")
-    assert tuple(float(v) for v in cfg.MEAN_PIXEL) == (123.7, 116.8, 103.9)
-    params = dict(m.named_parameters())
-    names = [str(n) for n in g["names"]]
-    for n in names:
-        assert np.array_equal(params[n].detach().reshape(-1)[:256].cpu().numpy(), g["before/" + n]), n
-    opt = m.make_optimizer(float(g["lr"]))
-    prev = {n: g["before/" + n].astype(np.float64) for n in names}
+    g = golden("e2e_multistep_%d" % scene)
+    hip, opt = _replay_reference_loop(g, "hip")
+    saturated = conv_hip.saturation_count() - sat0
+    ctl, _ = _replay_reference_loop(g, "torch")
     report, bad = [], []
-    # step 0 is the e2e_train_0 fixture (1e-4); later steps inherit the earlier steps' update differences, and the
-    # reference's own step 3 is an excursion (mrcnn_class 1.05 -> 3.48, total 6.13) where they show most: measured
-    # 3.2e-4, 2.3e-4, 1.5e-2 (0.24 % of the total), 3.0e-3 in the first recorded run and 3.2e-4, 1.3e-4, 1.8e-2, 2.0e-2
-    # in profiles/r4_v6_gpu_suite.log: behind the excursion the run-to-run spread of THIS build (fp32 atomics of the
-    # RoIAlign scatter and of the per-channel sums land in another order every run) is as large as its distance from
-    # the reference, so steps 3 and 4 share one bound (0.8 % of the totals)
-    loss_tol = [1e-4, 1e-3, 1e-3, 5e-2, 5e-2]
-    for k in range(K):
-        batch, pr = _step_inputs(g, k)
-        loss, parts = m.train_step(batch, opt, priorities=pr)
-        want = g["s%d/losses" % k]
-        got = np.array([float(parts[LOSS_KEYS[str(n)]].detach()) for n in g["loss_names"]])
-        dl = float(np.abs(got - want).max())
-        norm, want_norm = float(m.last_grad_norm), float(g["s%d/total_norm" % k])
-        errs = {}
-        for n in names:
-            # the model CONTINUES from its own weights (never re-seated on the reference's): the error of the
-            # cumulative change since step 0's start, relative to the reference's cumulative change
-            after = g["s%d/after/%s" % (k, n)].astype(np.float64)
-            base = g["before/" + n].astype(np.float64)
-            d_got = params[n].detach().reshape(-1)[:256].double().cpu().numpy() - base
-            errs[n] = np.linalg.norm(d_got - (after - base)) / max(np.linalg.norm(after - base), 1e-30)
-        deep = max((e, n) for n, e in errs.items() if n.startswith(DEEP))
-        rest = max((e, n) for n, e in errs.items() if not n.startswith(DEEP))
-        report.append("step %d: |dloss| %.2e (total %.5f vs %.5f) norm %.4f vs %.4f  cumulative update err: "
-                      "backbone %.2e (%s), other %.2e (%s)" % (k, dl, got.sum(), want.sum(), norm, want_norm,
-                                                               deep[0], deep[1], rest[0], rest[1]))
+    for k, (h, c) in enumerate(zip(hip, ctl)):
+        report.append("step %d: |dloss| hip %.2e aten %.2e (total %.5f / ref %.5f)  norm err hip %.2e aten %.2e  "
+                      "cumulative update err: backbone hip %.2e (%s) aten %.2e, other hip %.2e (%s) aten %.2e" % (
+                          k, h["dl"], c["dl"], h["total"], h["want_total"], h["dnorm"], c["dnorm"],
+                          h["deep"][0], h["deep"][1], c["deep"][0], h["rest"][0], h["rest"][1], c["rest"][0]))
         print(report[-1])
-        if dl > loss_tol[k]:
+        kk = min(k, len(LOSS_TOL) - 1)
+        if h["dl"] > LOSS_TOL[kk] or h["dl"] > max(CONTROL_FACTOR * c["dl"], 1e-4):
             bad.append("step %d loss" % k)
-        if abs(norm - want_norm) > (2e-3 if k == 0 else 1e-2) * want_norm:
+        if h["dnorm"] > (2e-3 if k == 0 else 1e-2) or h["dnorm"] > max(CONTROL_FACTOR * c["dnorm"], 2e-3):
             bad.append("step %d norm" % k)
-        # measured: backbone 1.3e-3, 5.7e-2, 0.10, 0.26, 0.33 (one 256-element slice of C2 under ~90 ReLU layers);
-        # heads / FPN / RPN 1e-6, 1.8e-2, 2.2e-2, 3.5e-2, 3.9e-2
-        if deep[0] > (2e-2 if k == 0 else 0.6) or rest[0] > (2e-3 if k == 0 else 0.1):
-            bad.append("step %d update" % k)
+        if h["deep"][0] > DEEP_TOL[kk] or h["deep"][0] > max(CONTROL_FACTOR * c["deep"][0], 2e-2):
+            bad.append("step %d backbone update" % k)
+        if h["rest"][0] > REST_TOL[kk] or h["rest"][0] > max(CONTROL_FACTOR * c["rest"][0], 2e-3):
+            bad.append("step %d heads update" % k)
     assert not bad, "%s\n%s" % (bad, "\n".join(report))
-    assert opt.skipped_steps() == 0 and conv_hip.saturation_count() == sat0
+    assert opt.skipped_steps() == 0 and saturated == 0
 
 
 def _cos(a, b):

@@ -189,7 +189,7 @@ def test_bench_launches_its_own_ranks():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
     env["SLN_DIST_BACKEND"] = "gloo"
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
-                        "--warmup", "1", "--batch", "2", "--dim", "256", "--arch", "resnet50",
+                        "--warmup", "1", "--settle", "1", "--batch", "2", "--dim", "256", "--arch", "resnet50",
                         "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=420)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -197,3 +197,17 @@ def test_bench_launches_its_own_ranks():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "dp2"
     assert out["value"] > 0 and out["scaling"] == "weak"
+    # the self-diagnosis of a scaling run: every rank reports its own step times, the all-reduce
+    # wait backward did not hide, and the host cores it was pinned to before its first GPU call
+    gx = out["gradient_exchange"]
+    assert gx["world_size_seen"] == 2 and gx["backend"] == "gloo"
+    assert "loader_queue_depth" in gx and gx["step_ms_max_over_ranks"] >= gx["step_ms_min_over_ranks"] > 0
+    assert [g["rank"] for g in gx["per_rank"]] == [0, 1]
+    for g in gx["per_rank"]:
+        assert g["step_ms_min"] > 0 and g["finishes"] >= 2 and g["buckets"] == gx["buckets"]
+        assert "exposed_wait_ms_mean" in g and "host_wait_ms_mean" in g
+        assert g["cpu_affinity"].get("cores", 0) >= 1
+    a0, a1 = (g["cpu_affinity"] for g in gx["per_rank"])
+    assert a0["last"] < a1["first"]              # disjoint shares of the host cores
+    # another problem than the headline's: no replayed counter file next to this run's numbers
+    assert out["roofline"]["traffic"] is None

@@ -13,7 +13,7 @@ used) and turns the checkpoint write into a no-op.  Weights are the name-keyed d
 initialisation of tests/_util.e2e_init_ (regenerated from the keys on the test side, not stored).
 
     python tools/gen_golden_e2e.py --masks   # writes tests/golden/e2e_relu_masks_0.npz only
-    python tools/gen_golden_e2e.py --steps   # writes tests/golden/e2e_multistep_0.npz only (run_multistep)
+    python tools/gen_golden_e2e.py --steps [--scene 1]  # writes tests/golden/e2e_multistep_<scene>.npz only (run_multistep)
     python tools/gen_golden_e2e.py --dim 256 # writes tests/golden/e2e_train_256_0.npz only: scene 0's train step at 256^2
                                              # (six objects) -- maps of 64^2 .. 4^2: whole 256-row tiles of the conv kernels
 
@@ -195,7 +195,7 @@ def main(only_masks=False, multistep=False, dim=None):
         return
     if multistep:
         del model
-        run_multistep(locals())
+        run_multistep(locals(), scene=int(sys.argv[sys.argv.index("--scene") + 1]) if "--scene" in sys.argv else 0)
         return
     rec_opt = {}
     if big:
@@ -485,7 +485,7 @@ def run_mask_scene(env):
             setattr(ref_model, n, real["real_losses"][n])
         for h in hooks:
             h.remove()
-    base = np.load(os.path.join(ROOT, "tests", "golden", "e2e_train_0.npz"))
+    base = np.load(os.path.join(ROOT, "tests", "golden", "e2e_train_%d.npz" % scene))
     got = np.array([rec["losses"][n] for n in loss_names], dtype=np.float64)
     assert np.array_equal(got, base["losses"]), (got, base["losses"])
     for n in WATCH:      # the same step as the e2e_train_0 fixture, bit for bit
@@ -506,7 +506,7 @@ def run_mask_scene(env):
          **{"grad/" + n: v for n, v in rec["grad"].items()}, **arrs)
 
 
-def run_multistep(env, steps=5):
+def run_multistep(env, steps=5, scene=0):
     """Scene 0 through `steps` consecutive optimiser steps of the reference's own loop (train_model with
     epochs = steps, STEPS_PER_EPOCH = 1: one optimiser, momentum carried over; model.py:356-366, 383-444).  Per
     step the observers record what the loop consumed (the augmented image / boxes / RPN targets the DataLoader
@@ -517,7 +517,7 @@ def run_multistep(env, steps=5):
     ref_train, scenes, tmp, loss_names = env["ref_train"], env["scenes"], env["tmp"], env["loss_names"]
     real = {k: env[k] for k in ("real_loader", "real_randperm", "real_clip", "real_step", "real_save",
                                 "real_predict", "real_losses")}
-    image, label = scenes[0]
+    image, label = scenes[scene]
     model, cfg = build_reference_model(ref_model, ref_config, ref_dl, nn)
     params = dict(model.named_parameters())
     ds = StubDataset(ref_train, [image], [label], tmp)
@@ -564,7 +564,7 @@ def run_multistep(env, steps=5):
         return f
 
     before = grab(params, "data")
-    seed = 1000
+    seed = 1000 + scene
     random.seed(seed); np.random.seed(seed); torch.manual_seed(seed)
     torch.randperm = rec_randperm
     ref_model.proposal_layer = rec_proposal
@@ -606,11 +606,11 @@ def run_multistep(env, steps=5):
                      "s%d/perm_neg" % k: st["perms"][2], "s%d/rpn_rois" % k: st["rpn_rois"],
                      "s%d/losses" % k: losses, "s%d/total_norm" % k: np.array(st["total_norm"])})
         arrs.update({"s%d/after/%s" % (k, n): v for n, v in st["after"].items()})
-    base = np.load(os.path.join(ROOT, "tests", "golden", "e2e_train_0.npz"))
+    base = np.load(os.path.join(ROOT, "tests", "golden", "e2e_train_%d.npz" % scene))
     assert np.array_equal(arrs["s0/losses"], base["losses"]), (arrs["s0/losses"], base["losses"])
     for n in WATCH:
         assert np.array_equal(arrs["s0/after/" + n], base["after/" + n]), n
-    save("e2e_multistep_0", native=np.array("oracle"), dim=np.array(DIM), lr=np.array(0.01), steps=np.array(steps),
+    save("e2e_multistep_%d" % scene, native=np.array("oracle"), dim=np.array(DIM), lr=np.array(0.01), steps=np.array(steps),
          image_u8=image, label=label, loss_names=np.array(loss_names), names=np.array(WATCH),
          **{"before/" + n: v for n, v in before.items()}, **arrs)
 

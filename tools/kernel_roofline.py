@@ -19,7 +19,7 @@ def _time(fn, iters=10, warmup=3):
     return e0.elapsed_time(e1) * 1e-3 / iters  # seconds per launch
 
 
-def measure(dev, B=16):
+def measure(dev, B=16, replay_traffic=True):
     from sln_amodal_amd import ops
     from sln_amodal_amd.modal.modals import _PyramidCrop
     g = torch.Generator(device=dev).manual_seed(7)
@@ -78,7 +78,10 @@ def measure(dev, B=16):
                                                        ops._stream()), "sln_pyramid_crop_bwd_f32")
     tk7 = _time(launch7)
     measured = {}
-    try:      # HBM bytes the scatter kernel really moved (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE, committed pass; mean
+    try:      # (replay_traffic=False: the bench runs another problem than the one the counter pass was collected on)
+        if not replay_traffic:
+            raise KeyError("no replay")
+        # HBM bytes the scatter kernel really moved (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE, committed pass; mean
         # over its pool-16 and pool-7 launches) over the mean live duration of the same two launches
         import json
         import os
