@@ -34,6 +34,8 @@ def split_peak(parts):
     fp32 multiply-add is 3 fp16 MFMA products (2 scaled fp16 parts per operand, the default) or 6 bf16
     products (3 bf16 parts); both run at the dense 16-bit MFMA peak, which therefore bounds the
     algorithmic rate at 2500/3 = 833.3 (2500/6 = 416.7) TFLOP/s."""
+    if parts == 1:          # one scaled fp16 part per operand (configs[4], fp16 storage): the dense 16-bit peak itself
+        return PEAK_BF16_MFMA_TFLOPS
     return PEAK_BF16_MFMA_TFLOPS / (6 if parts == 3 else 3)
 PEAK_HBM_GBS = 8000.0
 # HBM bytes per launch cannot be collected live (PMC needs rocprofv3 around the process): the bench line
@@ -101,7 +103,7 @@ def dominant_kernel_roofline(prof, elapsed, parts, replay_traffic=True):
     name = max(by, key=lambda k: by[k][0])
     secs, flops, n, rd_b, wr_b = by[name]
     ach = flops / secs / 1e12
-    mult = 6 if parts == 3 else 3
+    mult = {1: 1, 2: 3, 3: 6}[parts]
     # the same launches split by which roof bounds them: machine balance = MFMA peak / HBM peak in part-product
     # FLOPs per algorithmic byte (every operand read once, every output written once)
     balance = PEAK_BF16_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
@@ -156,7 +158,7 @@ def dominant_kernel_roofline(prof, elapsed, parts, replay_traffic=True):
             "unit": "TFLOP/s", "frac": round(ach / peak, 4), **flat,
             "peak_note": "algorithmic fp32-equivalent FLOPs against dense 16-bit MFMA peak / %d part products; "
                          "the fp32-input MFMA peak is %.1f (ratio in vs_fp32_mfma_peak, not a roofline "
-                         "fraction: this kernel does not run on that path)" % (6 if parts == 3 else 3,
+                         "fraction: this kernel does not run on that path)" % (mult,
                                                                               PEAK_F32_MFMA_TFLOPS),
             "vs_fp32_mfma_peak": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic_detail": traffic,
             "launches": n, "avg_launch_us": round(secs / n * 1e6, 2),
@@ -222,6 +224,9 @@ def main_resnext(args, rank, world, dev):
     batch = args.batch if args.batch is not None else 32
     dim = args.dim if args.dim is not None else 321
     classes = 21
+    if args.parts:
+        conv_hip.PARTS = args.parts      # 1: single scaled fp16 operands + fp16 storage + MFMA grouped 3x3 ("fp16 MFMA")
+    P = conv_hip.PARTS
     torch.manual_seed(0)
     net = DeepLabV2_ResNeXt101_MSC(classes).to(dev)
     for m in net.modules():
@@ -282,8 +287,21 @@ def main_resnext(args, rank, world, dev):
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
+    for i in range(max(args.warmup, 2)):        # (>= 2: the first step bootstraps every operand scale exactly)
         step(i)
+    # cross-check of the FLOP count: one step under the live profile -- the forward entries of every
+    # convolution launch must add up to what the patched conv_bn_act counted
+    conv_hip.PROFILE = []
+    po0 = conv_hip.PO_STATS[0]
+    step(0)
+    torch.cuda.synchronize()
+    po_per_step = conv_hip.PO_STATS[0] - po0       # activations that exist as their fp16 part alone (fp16 storage)
+    prof_fwd = sum(e[2] for e in conv_hip.PROFILE if e[4].startswith("fwd"))
+    prof_all = sum(e[2] for e in conv_hip.PROFILE)
+    conv_hip.PROFILE = None
+    if abs(prof_fwd - fwd_flops[0]) > 1e-6 * fwd_flops[0]:
+        raise SystemExit("bench.py --config resnext: counted %.6e forward FLOPs, the launches' profile says %.6e" %
+                         (fwd_flops[0], prof_fwd))
     if rank == 0:
         conv_hip.PROFILE = []
     barrier()
@@ -301,21 +319,32 @@ def main_resnext(args, rank, world, dev):
         # forward + data gradient + weight gradient of every convolution (the image needs no data gradient: < 1 %)
         tflop_step = 3.0 * fwd_flops[0] / 1e12
         achieved = tflop_step * args.steps / elapsed
-        peak = split_peak(conv_hip.PARTS)
+        peak = split_peak(P)
+        fmt = {1: "1 x scaled fp16 (fp16 storage, one MFMA product per multiply-add, fp32 accumulate); grouped 3x3: "
+                  "v_mfma_f32_16x16x32_f16 on block-diagonal 16-channel tiles",
+               2: "2 x scaled fp16 (dense convolutions); grouped 3x3: fp32 direct kernels",
+               3: "3 x bf16 (dense convolutions); grouped 3x3: fp32 direct kernels"}[P]
         out = {"metric": "images/sec train-step (ResNeXt-101 32 groups + multi-scale ASPP heads, %d^2, bs%d/GPU)" % (dim, batch),
                "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / max(args.steps, 1), 3),
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "roofline": dominant_kernel_roofline(prof, elapsed, conv_hip.PARTS, replay_traffic=False),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16" if P == 1 else "f32",
+               "data": "synthetic",
+               "roofline": dominant_kernel_roofline(prof, elapsed, P, replay_traffic=False),
                "config": {"workload": "BASELINE.json configs[4]: ResNeXt-101 (3,4,23,3; 32 groups) + ASPP(6,12,18,24) under "
                                       "the multi-scale wrapper (scales 1 / 0.5 / 0.75 + maximum), train step, "
                                       "%d x %dx%d images/GPU, %d classes" % (batch, dim, dim, classes),
                           "images_per_gpu": batch, "image_dim": dim, "parallelism": "dp%d" % world,
-                          "conv_operand_format": "2 x scaled fp16 (dense convolutions); grouped 3x3: fp32 direct kernels",
+                          "conv_operand_format": fmt, "conv_split_parts": P,
+                          "conv_saturated_blocks": conv_hip.saturation_count(),
+                          "parts_only_activations_per_step": po_per_step,
+                          "profiled_tflop_per_step_all_launches": round(prof_all / 1e12, 3),
                           "final_loss": round(float(losses[-1].detach()), 5),
                           "loss_trace": [round(float(l.detach()), 4) for l in losses[:: max(1, len(losses) // 8)]],
                           "max_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
-                          "note": "fp32 storage, not the fp16 storage configs[4] names: a wider format than asked"},
+                          "note": ("fp16 operands and fp16 storage as configs[4] names; tolerance held against the reference-"
+                                   "module fixture: 2e-2 (tests/test_f16_gpu.py), the fp32-class path (--parts 2) 1e-4")
+                          if P == 1 else "fp32-class arithmetic and storage: a wider format than configs[4] names "
+                                         "(--parts 1 is the fp16 form)"},
                "step_roofline": {"bound": "mfma", "kernel": "whole train step (all kernels)",
                                  "achieved": round(achieved, 3), "peak": round(peak, 1), "unit": "TFLOP/s",
                                  "frac": round(achieved / peak, 4),
@@ -351,9 +380,10 @@ def main():
     ap.add_argument("--config", default="sln", choices=["sln", "resnext"],
                     help="sln: BASELINE.json's headline (configs[2] / [3]); resnext: configs[4], ResNeXt-101 + multi-scale "
                          "heads train step (default there: --batch 32 --dim 321)")
-    ap.add_argument("--parts", type=int, default=None, choices=[2, 3],
-                    help="operand format of the conv stack: 2 = two scaled fp16 parts (default), 3 = three bf16 parts; "
-                         "both fp32-class")
+    ap.add_argument("--parts", type=int, default=None, choices=[1, 2, 3],
+                    help="operand format of the conv stack: 2 = two scaled fp16 parts (default), 3 = three bf16 parts "
+                         "(both fp32-class); 1 = one scaled fp16 part, fp16 storage (--config resnext only: configs[4] "
+                         "as BASELINE.json states it, 'fp16 MFMA')")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(launch_ranks(args.gpus))
@@ -395,6 +425,9 @@ def main():
         return main_resnext(args, rank, world, dev)
     args.batch = 16 if args.batch is None else args.batch
     args.dim = 1024 if args.dim is None else args.dim
+    if args.parts == 1:
+        raise SystemExit("bench.py: --parts 1 (single fp16 operands) is the format of --config resnext (BASELINE.json "
+                         "configs[4]); the SLN detector's north-star tolerance is 1e-4 fp32: --parts 2 or 3")
     if args.parts:
         from sln_amodal_amd import conv_hip as _ch
         _ch.PARTS = args.parts
@@ -447,9 +480,12 @@ def main():
     for i in range(args.settle):
         model.train_step(next_batch(i), opt, sync)
     sat_setup = conv_hip.saturation_count()        # (host syncs outside the timed region)
+    snap_w = conv_hip.saturation_snapshot()
     for i in range(args.warmup):
         loss, _ = model.train_step(next_batch(i), opt, sync)
     sat_warmup = conv_hip.saturation_count()
+    sat_events_warmup = [{"role": r_, "layer_weight_shape": s_, "blocks": b_}
+                         for r_, s_, b_ in conv_hip.saturation_report(snap_w, None)]
     sat_snaps = [conv_hip.saturation_snapshot()]   # device-side copies, one per timed step: no host sync
     if rank == 0:
         conv_hip.PROFILE = []          # HIP-event pairs around every conv launch (launch stream)
@@ -546,6 +582,7 @@ def main():
                        # (set-up, warm-up steps, timed steps)
                        "conv_saturated_blocks": [sat_setup, sat_warmup - sat_setup, sat_timed],
                        "conv_saturated_events_timed": sat_events,
+                       "conv_saturated_events_warmup": sat_events_warmup,
                        "setup_scale_settle_steps": args.settle},
             "step_roofline": {"bound": "mfma", "kernel": "whole train step (all kernels)",
                               "achieved": round(achieved, 3), "peak": round(split_peak(conv_hip.PARTS), 1),

@@ -233,6 +233,27 @@ size_t sln_grouped_conv3x3_wgrad_workspace_bytes(int N, int H, int W, int C, int
 int sln_grouped_conv3x3_wgrad_f32(const float *x, const float *gy, const float *y_out, const float *scale, int N,
                                   int H, int W, int C, int groups, int stride, float *gw, void *workspace,
                                   size_t workspace_bytes, sln_stream_t stream);
+/* The same layer on the fp16 matrix cores (ABI 11; BASELINE.json configs[4] "fp16 MFMA"): operands are single scaled
+ * fp16 parts (the parts = 1 format of the conv entry points below: h = fp16(v * s), s a device scalar), fp32
+ * accumulation in v_mfma_f32_16x16x32_f16, C % 64 == 0, C/groups in {4, 8, 16, 32}.
+ * sln_grouped_conv3x3_pack_weights_f16: w fp32 [C][C/groups][3][3] -> the kernels' fragment order
+ *   (sln_grouped_conv3x3_packed_weight_elems() 16-bit words), flip 0 for the forward pass, 1 for the data gradient;
+ *   out NULL: only the tensor's amax is recorded (first use of its scale slot).
+ * sln_grouped_conv3x3_f16: mode 0 forward, x16 [N,H,W,C] -> y fp32 and / or y16 scaled fp16 [N,OH,OW,C] (+ its running
+ *   amax / clamp count); mode 1 data gradient, x16 = the PREPARED gradient [N,OH,OW,C] (ReLU mask and BN scale applied:
+ *   sln_conv_grad_prep_f32 with parts = 1), w_packed packed with flip = 1 -> y = gx [N,H,W,C] fp32.
+ * sln_grouped_conv3x3_wgrad_f16: gw fp32 [C][C/groups][3][3] from the prepared gradient and the layer's input parts;
+ *   workspace as for the fp32 entry point (per-range partial sums + ordered reduce: bit-reproducible). */
+int64_t sln_grouped_conv3x3_packed_weight_elems(int C, int groups);
+int sln_grouped_conv3x3_pack_weights_f16(const float *w, int C, int groups, int flip, uint16_t *out, const float *q_scale,
+                                         float *q_amax, int32_t *q_saturated, sln_stream_t stream);
+int sln_grouped_conv3x3_f16(const uint16_t *x16, int N, int H, int W, int C, int groups, const uint16_t *w_packed,
+                            int stride, int mode, const float *scale, const float *shift, int relu, float *y,
+                            uint16_t *y16, const float *x_scale, const float *w_scale, const float *y_q_scale,
+                            float *y_q_amax, int32_t *y_q_saturated, sln_stream_t stream);
+int sln_grouped_conv3x3_wgrad_f16(const uint16_t *x16, const uint16_t *gz16, int N, int H, int W, int C, int groups,
+                                  int stride, const float *gz_scale, const float *x_scale, float *gw, void *workspace,
+                                  size_t workspace_bytes, sln_stream_t stream);
 /* Tail of the global layer module (reference model.py:537-541, modal/msc_deeplab.py:42-48), one pass: the logits
  * of the coarser scales resized bilinearly (align_corners = False) to the scale-1 grid, element-wise maximum over
  * the scales, softmax over the C classes, argmax.  All maps NHWC fp32 with the given pixel strides (floats).
@@ -389,7 +410,9 @@ int64_t sln_rle_from_string(const char *s, int64_t len, uint32_t *counts, int64_
  * Operand formats.  parts = 3: three bf16 parts per fp32 value, six part products per
  * fp32 product.  parts = 2 ("scaled split-fp16"): two fp16 parts of v*s, s a per-tensor
  * power of two, three part products (22-bit operands: the accuracy of fp32 at half the
- * matrix work).  Every function that WRITES parts takes the tensor's scaling record
+ * matrix work).  parts = 1 (ABI 11; BASELINE.json configs[4] "fp16 MFMA"): ONE scaled fp16 part h = fp16(v*s) --
+ * fp16 storage, one product per multiply-add, fp32 accumulate, fp16-class results; generic 128-wide kernels only,
+ * weights in SLN_WEIGHTS_ROWS.  Every function that WRITES parts takes the tensor's scaling record
  *     q_scale      device scalar s (NULL = 1): the parts encode v*s
  *     q_amax       device scalar (optional): atomic running max |v| of what was split --
  *                  the input of sln_scale_update_f32, which derives the scale the same

@@ -25,6 +25,8 @@ from . import _lib, ops
 
 # 2 = two scaled fp16 parts (3 MFMA products per fp32 product; the default: same fp64-checked accuracy
 # at half the matrix work); 3 = three bf16 parts (6 products, no scales)
+# 1 = ONE scaled fp16 part (fp16 storage, one product: fp16-class results -- BASELINE.json configs[4]'s "fp16 MFMA";
+# chosen per model, e.g. `bench.py --config resnext --parts 1`, never the default)
 PARTS = int(os.environ.get("SLN_CONV_PARTS", "2"))
 # parts used while autograd is disabled (the frozen GLM, inference): None = same as PARTS
 PARTS_NOGRAD = int(os.environ["SLN_CONV_PARTS_NOGRAD"]) if os.environ.get("SLN_CONV_PARTS_NOGRAD") else None
@@ -374,7 +376,7 @@ def _split_weights(weight, flip_swap=False, parts=None, owner=None, layout=ROWS)
                           dtype=torch.bfloat16, device=w.device)
     else:
         out = torch.empty((parts, O, KH, KW, Ip), dtype=torch.bfloat16, device=w.device)
-    slot = _slot(owner if owner is not None else weight, ("w",)) if parts == 2 else None
+    slot = _slot(owner if owner is not None else weight, ("w",)) if parts <= 2 else None
 
     def launch(dst):
         _lib.check(_lib.lib().sln_conv_split_weights_f32(
@@ -531,6 +533,14 @@ def _placeholder(shape, device):
     return n.expand(shape)
 
 
+def _parts_value(parts, q):
+    """fp32 [M, C_pad] value of scaled fp16 parts [P, M, C_pad] (P = 1 or 2): (h0 [+ h1]) / s."""
+    v = parts[0].view(torch.float16).float()
+    if parts.shape[0] == 2:
+        v = v + parts[1].view(torch.float16).float()
+    return v / q
+
+
 def parts_only_of(t):
     """(parts [2, M, C_pad], scale) of a parts-only activation, None for an ordinary tensor."""
     po = getattr(t, "_sln_po", None)
@@ -549,8 +559,7 @@ def materialize(t):
         return t
     parts, q = po
     N, C, H, W = t.shape
-    v = (parts[0].view(torch.float16).float() + parts[1].view(torch.float16).float()) / q
-    return v[:, :C].reshape(N, H, W, C).permute(0, 3, 1, 2)
+    return _parts_value(parts, q)[:, :C].reshape(N, H, W, C).permute(0, 3, 1, 2)
 
 
 def act_parts(x, parts=None, owner=None, key=None):
@@ -568,7 +577,7 @@ def act_parts(x, parts=None, owner=None, key=None):
     xc = _nhwc(x.detach())
     N, C, H, W = xc.shape
     slot = None
-    if parts == 2:
+    if parts <= 2:
         slot = _slot(owner if owner is not None else x, ("x",) + tuple(key or (H, W)))
     out = _act_split(xc, N * H * W, C, parts, slot)
     q = slot.scale if slot is not None else None
@@ -639,22 +648,20 @@ def _fwd(xparts, N, H, W, w, Cout, KH, KW, stride, dil, pt, pl, OH, OW, scale, s
     cin = cin or xparts.shape[2]
     y = torch.empty((N, OH, OW, Cout), dtype=torch.float32, device=dev).permute(0, 3, 1, 2) if want_y else None
     plain = mask is None and mask_parts is None and want_y and not want_colsum and post_scale is None
-    if (res_parts is not None or mask_parts is not None) and (P != 2 or Cout % 8 or layout == TILED256):
+    if (res_parts is not None or mask_parts is not None) and (P > 2 or Cout % 8 or layout == TILED256):
         # (the fixed-feature epilogue only: whole 16-B row groups, not the round-1 256^2 kernel)
         if res_parts is not None:
-            rq = res_parts[1]
-            rv = (res_parts[0][0].view(torch.float16).float() + res_parts[0][1].view(torch.float16).float()) / rq
-            residual, res_parts = rv[:, :Cout].contiguous(), None
+            residual, res_parts = _parts_value(res_parts[0], res_parts[1])[:, :Cout].contiguous(), None
         if mask_parts is not None:
             mask = (mask_parts[0].view(torch.float16)[:, :Cout] > 0).float().contiguous()
             mask_parts = None
-    if out_parts and P == 2:
+    if out_parts and P <= 2:
         if yslot is None:
             raise RuntimeError("two-part output split needs a scale slot")
         if yslot.fresh and not plain:
             raise RuntimeError("chained gradient preparation on a tensor without a scale (the chain "
                                "must stay off until its slot has been bootstrapped)")
-    fresh = out_parts and P == 2 and yslot.fresh
+    fresh = out_parts and P <= 2 and yslot.fresh
     yp = None
     if out_parts and not fresh:   # the epilogue also emits the output's parts (next layer's operand)
         alloc = torch.empty if Cout % 8 == 0 else torch.zeros   # pad channels must be zero
@@ -668,7 +675,7 @@ def _fwd(xparts, N, H, W, w, Cout, KH, KW, stride, dil, pt, pl, OH, OW, scale, s
         ops._ptr(xparts), 1, seg, xparts.shape[2], ops._ptr(wparts), layout, P, Cout, KH, KW,
         stride[0], stride[1], dil[0], dil[1], pt, pl, pb, pr, ops._ptr(scale), ops._ptr(shift),
         ops._ptr(residual), (1 if relu else 0) | cs_flag, ops._ptr(mask), ops._ptr(post_scale), ops._ptr(y),
-        ops._ptr(yp), ops._ptr(cs), ops._ptr(xq), ops._ptr(wq), *_q3(yslot if yp is not None and P == 2 else None),
+        ops._ptr(yp), ops._ptr(cs), ops._ptr(xq), ops._ptr(wq), *_q3(yslot if yp is not None and P <= 2 else None),
         ops._ptr(res_parts[0]) if res_parts is not None else None,
         ops._ptr(res_parts[1]) if res_parts is not None else None,
         ops._ptr(mask_parts) if mask_parts is not None else None,
@@ -685,7 +692,7 @@ def _fwd(xparts, N, H, W, w, Cout, KH, KW, stride, dil, pt, pl, OH, OW, scale, s
     if fresh:   # first use of this output's slot: exact amax pass over y, then the split
         yp = _act_split(_nhwc(y), N * OH * OW, Cout, P, yslot)
     if yp is not None and y is not None and post_scale is None:
-        y._sln_parts = ((y._version, P, SCALE_EPOCH[0]), yp, yslot.scale if P == 2 else None)
+        y._sln_parts = ((y._version, P, SCALE_EPOCH[0]), yp, yslot.scale if P <= 2 else None)
     if mask is not None or mask_parts is not None or not want_y or want_colsum:
         return y, yp, cs
     return y
@@ -722,7 +729,7 @@ class MultiScale(object):
         """-> (parts, scale or None)."""
         if self.parts is None or self.parts.shape[0] != parts:
             M, C = self.y.shape
-            slot = _slot(owner, ("x_ms",) + tuple(self.segs)) if parts == 2 else None
+            slot = _slot(owner, ("x_ms",) + tuple(self.segs)) if parts <= 2 else None
             self.parts = _act_split(self.y, M, C, parts, slot)
             self.q = slot.scale if slot is not None else None
         return self.parts, getattr(self, "q", None)
@@ -760,27 +767,27 @@ def conv_bn_act_ms(x, conv, bn, relu, residual, pads, parts_only=False):
     layout = weights_layout(M, Co, xp.shape[2], KH * KW, parts, xp.shape[1])
     wp, wq = _split_weights(conv.weight, parts=parts, layout=layout)
     dev = xp.device
-    yslot = _slot(conv.weight, ("y_ms",) + tuple(osegs)) if parts == 2 else None
+    yslot = _slot(conv.weight, ("y_ms",) + tuple(osegs)) if parts <= 2 else None
     fresh = yslot is not None and yslot.fresh
     yp = None
     if not fresh:
         alloc = torch.empty if Co % 8 == 0 else torch.zeros
         yp = alloc((parts, M, _pad8(Co)), dtype=torch.bfloat16, device=dev)
     # (a fresh slot bootstraps its scale from the fp32 output: that one time it is written)
-    y = None if (parts_only and yp is not None and parts == 2) else \
+    y = None if (parts_only and yp is not None and parts <= 2) else \
         torch.empty((M, Co), dtype=torch.float32, device=dev)
     seg = (C.c_int32 * (3 * len(x.segs)))(*[v for s_ in x.segs for v in s_])
     res = residual.y if residual is not None else None
     rparts = rq = None
     if residual is not None and res is None:          # a parts-only shortcut: added from its parts
-        if residual.parts is None or residual.parts.shape[0] != 2:
-            raise ValueError("parts-only residual without fp16 x 2 parts")
-        if parts == 2 and Co % 8 == 0 and layout != TILED256 and tuple(residual.parts.shape[1:]) == (M, Co):
+        if residual.parts is None or residual.parts.shape[0] > 2:
+            raise ValueError("parts-only residual without scaled fp16 parts")
+        if parts <= 2 and residual.parts.shape[0] == parts and Co % 8 == 0 and layout != TILED256 and \
+                tuple(residual.parts.shape[1:]) == (M, Co):
             rparts, rq = residual.parts, residual.q
             PO_STATS[1] += 1
         else:
-            res = ((residual.parts[0].view(torch.float16).float() + residual.parts[1].view(torch.float16).float())
-                   / residual.q)[:, :Co].contiguous()
+            res = _parts_value(residual.parts, residual.q)[:, :Co].contiguous()
     if res is not None and tuple(res.shape) != (M, Co):
         raise ValueError("residual does not match the convolution output")
     e0 = _prof_begin()
@@ -809,7 +816,7 @@ def _grad_prep(gy, y, scale, want_gu, want_bias, parts, slot=None):
     gu = gy
     y16 = None
     if y is not None and y.dtype == torch.bfloat16:     # the layer's output exists as parts only: [2, M, Cp]
-        if parts != 2 or tuple(y.shape[1:]) != (M, Cp):
+        if parts > 2 or tuple(y.shape[1:]) != (M, Cp):
             raise RuntimeError("parts-only ReLU pattern does not match the gradient")
         y16, y = y, None
         PO_STATS[2] += 1
@@ -817,15 +824,15 @@ def _grad_prep(gy, y, scale, want_gu, want_bias, parts, slot=None):
     if write_gu:
         gu = torch.empty((N, H, W, C), dtype=torch.float32, device=gy.device).permute(0, 3, 1, 2)
     gb, gb_flag = _zeroed(C, gy.device) if want_bias else (None, 0)
-    if parts == 2 and slot is None:
+    if parts <= 2 and slot is None:
         raise RuntimeError("two-part gradient preparation needs a scale slot")
 
     def launch(dst):
         _lib.check(_lib.lib().sln_conv_grad_prep_f32(
             ops._ptr(gy), ops._ptr(y), ops._ptr(y16), ops._ptr(scale), M, C, Cp, parts | (gb_flag if dst is not None else 0),
-            ops._ptr(gu) if write_gu else None, ops._ptr(dst), ops._ptr(gb), *_q3(slot if parts == 2 else None),
+            ops._ptr(gu) if write_gu else None, ops._ptr(dst), ops._ptr(gb), *_q3(slot if parts <= 2 else None),
             ops._stream()), "sln_conv_grad_prep_f32")
-    if parts == 2 and slot.fresh:
+    if parts <= 2 and slot.fresh:
         launch(None)
         slot.book.settle(slot)
     launch(gz)
@@ -841,15 +848,15 @@ def _grad_prep_pooled(pooled, y, scale, want_bias, parts, slot):
     M = N * H * W
     gz = torch.empty((parts, M, C), dtype=torch.bfloat16, device=g.device)
     gb, gb_flag = _zeroed(C, g.device) if want_bias else (None, 0)
-    if parts == 2 and slot is None:
+    if parts <= 2 and slot is None:
         raise RuntimeError("two-part gradient preparation needs a scale slot")
 
     def launch(dst):
         _lib.check(_lib.lib().sln_conv_grad_prep_pooled_f32(
             ops._ptr(g), ops._ptr(arg), N, H, W, kernel, stride, pt, pl, OH, OW, ops._ptr(y), ops._ptr(scale), C,
             parts | (gb_flag if dst is not None else 0), ops._ptr(dst), ops._ptr(gb),
-            *_q3(slot if parts == 2 else None), ops._stream()), "sln_conv_grad_prep_pooled_f32")
-    if parts == 2 and slot.fresh:
+            *_q3(slot if parts <= 2 else None), ops._stream()), "sln_conv_grad_prep_pooled_f32")
+    if parts <= 2 and slot.fresh:
         launch(None)
         slot.book.settle(slot)
     launch(gz)
@@ -918,11 +925,12 @@ def _force_relu(own, y):
     po = getattr(y, "_sln_po", None)
     if po is not None:       # parts only: the pattern is the sign of part 0
         N, C, H, W = y.shape
-        h = po[0].view(torch.int16).view(2, N, H, W, po[0].shape[2])[..., :C]
+        h = po[0].view(torch.int16).view(po[0].shape[0], N, H, W, po[0].shape[2])[..., :C]
         mm = m.permute(0, 2, 3, 1)
         one, zero = torch.ones((), dtype=torch.int16, device=h.device), torch.zeros((), dtype=torch.int16, device=h.device)
         h[0, :n] = torch.where(mm, torch.where(h[0, :n] > 0, h[0, :n], one), zero)   # (bits 1 = the least fp16)
-        h[1, :n] = torch.where(mm, h[1, :n], zero)
+        if h.shape[0] == 2:
+            h[1, :n] = torch.where(mm, h[1, :n], zero)
         return
     hit = getattr(y, "_sln_parts", None)
     with torch.no_grad():
@@ -936,7 +944,7 @@ def _check_epoch(ctx, parts):
     tensors saved next to them are live views of the ScaleBook.  After another update_scales() (a second
     predict() / detect() between this graph's forward and backward) the two no longer belong together
     and the weight gradient would be off by a power of two, silently."""
-    if parts == 2 and ctx.scale_epoch != SCALE_EPOCH[0]:
+    if parts <= 2 and ctx.scale_epoch != SCALE_EPOCH[0]:
         raise RuntimeError("conv backward after update_scales(): this graph's forward ran in scale epoch %d, "
                            "the ScaleBook is at %d (run backward before the next predict()/detect(), or "
                            "run that forward under conv_hip.hold_scales())" % (ctx.scale_epoch, SCALE_EPOCH[0]))
@@ -990,12 +998,12 @@ class _ConvFn(torch.autograd.Function):
         own = owner if owner is not None else weight
         xp, xq = act_parts(x, parts, owner=own)
         x_po = getattr(x, "_sln_po", None) is not None
-        yslot = _slot(own, ("y", OH, OW)) if (parts == 2 and FUSE_OUTPUT_SPLIT) else None
-        gzslot = _slot(own, ("gz", OH, OW)) if parts == 2 else None
+        yslot = _slot(own, ("y", OH, OW)) if (parts <= 2 and FUSE_OUTPUT_SPLIT) else None
+        gzslot = _slot(own, ("gz", OH, OW)) if parts <= 2 else None
         # parts-only output: this layer's readers are convolutions, a shortcut add and ReLU masks (the caller
         # says so); needs a scale with a history (the first step bootstraps it from the fp32 output) and the
         # fixed-feature epilogue
-        po = bool(parts_only and PARTS_ONLY_TRAIN and parts == 2 and FUSE_OUTPUT_SPLIT and not yslot.fresh and
+        po = bool(parts_only and PARTS_ONLY_TRAIN and parts <= 2 and FUSE_OUTPUT_SPLIT and not yslot.fresh and
                   Co % 8 == 0 and
                   weights_layout(N * OH * OW, Co, xp.shape[2], KH * KW, parts, xp.shape[1]) != TILED256)
         if po:
@@ -1052,7 +1060,7 @@ class _ConvFn(torch.autograd.Function):
         # (PARTS = 2: a reader can only prepare this layer's gradient once that gradient's scale slot
         # has a history, i.e. from the second step on; the first step bootstraps it in _grad_prep)
         if CHAIN_GRAD_PREP and chain_out is not None and (ctx.needs_input_grad[0] or need_w) and \
-                (not with_res or (CHAIN_BLOCK_OUTPUT and relu)) and not (parts == 2 and gzslot.fresh):
+                (not with_res or (CHAIN_BLOCK_OUTPUT and relu)) and not (parts <= 2 and gzslot.fresh):
             chain_out.update(active=True, scale=scale, relu=bool(relu), parts=parts, with_res=with_res,
                              want_bias=bool(bias is not None and ctx.needs_input_grad[2]), gz_slot=gzslot)
             chain_out.setdefault("readers", 1)      # 2: two sibling convs read the output (RPN heads)
@@ -1156,7 +1164,7 @@ class _ConvFn(torch.autograd.Function):
             CHAIN_STATS[1] += 1
         else:
             gz, g_res, g_bias = _grad_prep(gy, y, scale, want_res, want_bias, parts, slot=ctx.gzslot)
-            gzq = ctx.gzslot.scale if parts == 2 else None
+            gzq = ctx.gzslot.scale if parts <= 2 else None
 
         def mask_kw(m):      # the producer's ReLU pattern: its fp32 output, or its parts (part 0's sign)
             if m is None:
@@ -1227,7 +1235,7 @@ class _ConvFn(torch.autograd.Function):
                                        want_colsum=ci["want_bias"], post_scale=ci["scale"],
                                        yslot=ci["gz_slot"], **mask_kw(mask_x), **qs)
                 ci["gz"], ci["gbias"] = gz_up, gb_up
-                ci["gzq"] = ci["gz_slot"].scale if parts == 2 else None
+                ci["gzq"] = ci["gz_slot"].scale if parts <= 2 else None
                 gx = None
                 CHAIN_STATS[0] += 1
             elif ctx.chain_in is not None and (ctx.chain_in["with_res"] or ctx.chain_in.get("keep_dx")):
@@ -1242,7 +1250,7 @@ class _ConvFn(torch.autograd.Function):
                                         want_colsum=ci["want_bias"], post_scale=ci["scale"],
                                         yslot=ci["gz_slot"], **mask_kw(mask_x), **qs)
                 ci["gz"], ci["gbias"], ci["gu_ref"], ci["gu_version"] = gz_up, gb_up, gx, gx._version
-                ci["gzq"] = ci["gz_slot"].scale if parts == 2 else None
+                ci["gzq"] = ci["gz_slot"].scale if parts <= 2 else None
                 CHAIN_STATS[0] += 1
             elif ctx.chain_in is not None and not (ctx.chain_in.get("soft") and
                                                    (ctx.inbox is None or "g" not in ctx.inbox)):
@@ -1261,7 +1269,7 @@ class _ConvFn(torch.autograd.Function):
                                        post_scale=ci["scale"] if extra is not None else None,
                                        **mask_kw(mask_x), **qs)
                 ci["gz"], ci["gbias"] = gz_up, gb_up
-                ci["gzq"] = ci["gz_slot"].scale if parts == 2 else None
+                ci["gzq"] = ci["gz_slot"].scale if parts <= 2 else None
                 gx = _dummy_grad(weight.device).expand(N, Ci, H, W)   # never read: see chain_out above
                 CHAIN_STATS[0] += 1
             elif stride == (1, 1):
@@ -1386,7 +1394,7 @@ class _StemFn(torch.autograd.Function):
         K = Ci * KH * KW
         Kp = (K + 31) // 32 * 32
         M = N * OH * OW
-        xslot = _slot(weight, ("x", H, W)) if parts == 2 else None
+        xslot = _slot(weight, ("x", H, W)) if parts <= 2 else None
         xp = torch.empty((parts, M, Kp), dtype=torch.bfloat16, device=xc.device)
 
         def launch(dst):
@@ -1421,7 +1429,7 @@ class _StemFn(torch.autograd.Function):
         ctx.geom = (H, W, stride, pt, pl)
         ctx.w2 = w2 if ctx.needs_input_grad[0] else None
         ctx.own = weight
-        ctx.gzslot = _slot(weight, ("gz", OH, OW)) if parts == 2 else None
+        ctx.gzslot = _slot(weight, ("gz", OH, OW)) if parts <= 2 else None
         ctx.scale_epoch = SCALE_EPOCH[0]
         return y
 
@@ -1444,7 +1452,7 @@ class _StemFn(torch.autograd.Function):
                 POOL_HANDOFF_STATS[0] += 1
             else:
                 gz, _, g_bias = _grad_prep(gy, y, scale, False, want_bias, parts, slot=ctx.gzslot)
-            gzq = ctx.gzslot.scale if parts == 2 else None
+            gzq = ctx.gzslot.scale if parts <= 2 else None
         if need_x:     # (module-level use only: the model's image carries no gradient)
             H, W, stride, pt, pl = ctx.geom
             gcols = _fwd(gz, N, OH, OW, wsrc(ctx.w2, parts, True, ctx.own), Kp, 1, 1, (1, 1), (1, 1), 0, 0, OH, OW,
@@ -1467,6 +1475,122 @@ class _StemFn(torch.autograd.Function):
                       "wgrad stem N%d %dx%d K%d->%d" % (N, OH, OW, K, Co), _nbytes(gz, xp), _nbytes(gw_t))
             gw = gw_t.view(Co, Kp)[:, :K].reshape(Co, KH, KW, Ci).permute(0, 3, 1, 2)
         return gx, gw, g_bias, None, None, None, None, None, None
+
+
+# ------------------------------------------------------------------ grouped 3x3 on the fp16 matrix cores (PARTS = 1)
+def _pack_grouped(weight, groups, flip):
+    """-> (fragment-ordered scaled fp16 weights, scale tensor); cached on the parameter by version (csrc/grouped_conv.hip
+    grouped_pack_weights_kernel).  flip: the data gradient's orientation."""
+    cache = getattr(weight, "_sln_gpack", None)
+    if cache is None:
+        cache = weight._sln_gpack = {}
+    hit = cache.get(flip)
+    if hit is not None and hit[0] == weight._version:
+        return hit[1], hit[2]
+    w = weight.detach().contiguous()
+    C = w.shape[0]
+    n = _lib.lib().sln_grouped_conv3x3_packed_weight_elems(C, groups)
+    if n <= 0:
+        raise ValueError("grouped 3x3 on the fp16 path needs C %% 64 == 0 (C = %d, groups = %d)" % (C, groups))
+    out = torch.empty((n,), dtype=torch.bfloat16, device=w.device)        # (16-bit containers, like every part)
+    slot = _slot(weight, ("w",))
+
+    def launch(dst):
+        _lib.check(_lib.lib().sln_grouped_conv3x3_pack_weights_f16(ops._ptr(w), C, groups, 1 if flip else 0,
+                                                                    ops._ptr(dst), *_q3(slot), ops._stream()),
+                   "sln_grouped_conv3x3_pack_weights_f16")
+    if slot.fresh:
+        launch(None)
+        slot.book.settle(slot)
+    launch(out)
+    cache[flip] = (weight._version, out, slot.scale)
+    return out, slot.scale
+
+
+class _GroupedF16Fn(torch.autograd.Function):
+    """conv (groups, 3x3, padding 1, stride 1 / 2) -> frozen-BN affine -> ReLU on v_mfma_f32_16x16x32_f16 with single
+    scaled fp16 operands (reference: nn.Conv2d(groups=32) + BN + ReLU, modal/resnext.py:36, 50-52, differentiated by
+    autograd).  Forward: x's fp16 part (shared with the other readers of x) -> y fp32 + its fp16 part, or the part alone
+    (parts_only: the reader is a convolution, the ReLU pattern is the part's sign).  Backward: the ordinary gradient
+    preparation (ReLU mask, BN scale -> fp16 part), then the same kernel in its data-gradient mode and the MFMA weight
+    gradient (per-range partial sums + ordered reduce: bit-reproducible)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, scale, shift, relu, groups, stride, parts_only):
+        N, C, H, W = x.shape
+        OH, OW = (H - 1) // stride + 1, (W - 1) // stride + 1
+        xp, xq = act_parts(x, 1, owner=weight)
+        wpk, wq = _pack_grouped(weight, groups, False)
+        yslot, gzslot = _slot(weight, ("y", OH, OW)), _slot(weight, ("gz", OH, OW))
+        sc = scale.detach().contiguous() if scale is not None else None
+        sf = shift.detach().contiguous() if shift is not None else None
+        fresh = yslot.fresh
+        po = bool(parts_only and PARTS_ONLY_TRAIN and not fresh)
+        dev = x.device
+        y = None if po else torch.empty((N, OH, OW, C), dtype=torch.float32, device=dev).permute(0, 3, 1, 2)
+        yp = None if fresh else torch.empty((1, N * OH * OW, C), dtype=torch.bfloat16, device=dev)
+        e0 = _prof_begin()
+        _lib.check(_lib.lib().sln_grouped_conv3x3_f16(
+            ops._ptr(xp), N, H, W, C, groups, ops._ptr(wpk), stride, 0, ops._ptr(sc), ops._ptr(sf), 1 if relu else 0,
+            ops._ptr(y), ops._ptr(yp), ops._ptr(xq), ops._ptr(wq), *_q3(yslot if yp is not None else None),
+            ops._stream()), "sln_grouped_conv3x3_f16")
+        _prof_end(e0, 2.0 * N * OH * OW * C * 9 * (C // groups), "grouped_mfma_kernel",
+                  "fwd grouped N%d %dx%d C%d g%d s%d" % (N, H, W, C, groups, stride), _nbytes(xp, wpk), _nbytes(y, yp))
+        if fresh:          # first use of the output's slot: exact amax pass over the fp32 output, then the split
+            yp = _act_split(_nhwc(y), N * OH * OW, C, 1, yslot)
+        if po:
+            y = _placeholder((N, C, OH, OW), dev)
+            y._sln_po = (yp, yslot.scale, SCALE_EPOCH[0])
+            PO_STATS[0] += 1
+        y._sln_parts = ((y._version, 1, SCALE_EPOCH[0]), yp, yslot.scale)
+        need_w = ctx.needs_input_grad[1]
+        ctx.save_for_backward(xp if need_w else None, weight, sc, (yp if po else y) if relu else None,
+                              xq if need_w else None)
+        ctx.cfg = (bool(relu), int(groups), int(stride), (N, C, H, W), (OH, OW))
+        ctx.gzslot = gzslot
+        ctx.scale_epoch = SCALE_EPOCH[0]
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        xp, weight, sc, y, xq = ctx.saved_tensors
+        relu, groups, stride, (N, C, H, W), (OH, OW) = ctx.cfg
+        _check_epoch(ctx, 1)
+        gz, _, _ = _grad_prep(gy, y if relu else None, sc, False, False, 1, slot=ctx.gzslot)
+        gzq = ctx.gzslot.scale
+        gx = gw = None
+        L = _lib.lib()
+        if ctx.needs_input_grad[0]:
+            wpk, wq = _pack_grouped(weight, groups, True)
+            gxb = torch.empty((N, H, W, C), dtype=torch.float32, device=gz.device)
+            e0 = _prof_begin()
+            _lib.check(L.sln_grouped_conv3x3_f16(ops._ptr(gz), N, H, W, C, groups, ops._ptr(wpk), stride, 1, None, None,
+                                                 0, ops._ptr(gxb), None, ops._ptr(gzq), ops._ptr(wq), None, None, None,
+                                                 ops._stream()), "sln_grouped_conv3x3_f16")
+            _prof_end(e0, 2.0 * N * OH * OW * C * 9 * (C // groups), "grouped_mfma_kernel",
+                      "dgrad grouped N%d %dx%d C%d g%d s%d" % (N, H, W, C, groups, stride), _nbytes(gz, wpk), _nbytes(gxb))
+            gx = gxb.permute(0, 3, 1, 2)
+        if ctx.needs_input_grad[1]:
+            gw = torch.empty_like(weight)
+            nbytes = L.sln_grouped_conv3x3_wgrad_workspace_bytes(N, H, W, C, groups, stride)
+            ws = ops._workspace(nbytes, gz.device)
+            e0 = _prof_begin()
+            _lib.check(L.sln_grouped_conv3x3_wgrad_f16(ops._ptr(xp), ops._ptr(gz), N, H, W, C, groups, stride,
+                                                       ops._ptr(gzq), ops._ptr(xq), ops._ptr(gw), ops._ptr(ws), nbytes,
+                                                       ops._stream()), "sln_grouped_conv3x3_wgrad_f16")
+            _prof_end(e0, 2.0 * N * OH * OW * C * 9 * (C // groups), "grouped_wgrad_mfma_kernel",
+                      "wgrad grouped N%d %dx%d C%d g%d s%d" % (N, H, W, C, groups, stride), _nbytes(gz, xp), _nbytes(gw))
+        return gx, gw, None, None, None, None, None, None
+
+
+def grouped_supported(conv, x):
+    """Grouped 3x3 layers the fp16 MFMA kernels take: PARTS = 1, C % 64 == 0, 4 ... 32 channels per group."""
+    return (PARTS == 1 and x.dtype == torch.float32 and conv.in_channels == conv.out_channels and
+            conv.in_channels % 64 == 0 and (conv.in_channels // conv.groups) in (4, 8, 16, 32))
+
+
+def grouped_conv_bn_act(x, conv, scale, shift, relu, parts_only=False):
+    return _GroupedF16Fn.apply(x, conv.weight, scale, shift, bool(relu), conv.groups, conv.stride[0], bool(parts_only))
 
 
 def is_stem(conv, x):

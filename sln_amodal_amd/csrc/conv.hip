@@ -9,6 +9,10 @@
 //           1-3e-7 relative per layer against fp64, the accuracy of an fp32 GEMM
 //   P = 3: three bf16 parts, vi = bf16_rne(v - v0 - ... - v(i-1)), six products
 //           a2*b0 + a0*b2 + a1*b1 + a1*b0 + a0*b1 + a0*b0 on v_mfma_f32_32x32x16_bf16 (~1e-8, no scales)
+//   P = 1 (round 5, BASELINE.json configs[4] "fp16 MFMA"): ONE scaled fp16 part h0 = fp16_rne(v*s) -- plain fp16
+//           storage of activations, weights and gradients with the same per-tensor delayed scaling, one product
+//           a0*b0 per multiply-add, fp32 accumulate: fp16-class results (~5e-4 relative per element), selected
+//           per model (conv_hip.PARTS = 1), never the default; runs on the generic 128-wide kernels below.
 // (two UNSCALED bf16 parts, ~4e-6 per layer, were measured in round 1 and rejected.)
 // The 16-bit MFMA issues at 16x the rate of the fp32-input MFMA (MI355X_MICROARCH.md), so 3 / 6
 // part products per fp32-equivalent product leave 5.3x / 2.7x the fp32-MFMA roofline.  Details of the
@@ -115,10 +119,10 @@ __device__ __forceinline__ bool split4(const float4 v, bf16x4 *parts, float s = 
             sat = true;
         }
         h0[j] = (_Float16)q;
-        h1[j] = (_Float16)(q - (float)h0[j]);
+        if (P == 2) h1[j] = (_Float16)(q - (float)h0[j]);
     }
     parts[0] = __builtin_bit_cast(bf16x4, h0);
-    parts[1] = __builtin_bit_cast(bf16x4, h1);
+    if (P == 2) parts[1] = __builtin_bit_cast(bf16x4, h1);      // P = 1: the scaled fp16 value alone (fp16 storage)
     return sat;
 }
 
@@ -185,7 +189,7 @@ __global__ __launch_bounds__(256) void act_split_kernel(const float *__restrict_
     const int q4 = Cp / 4;
     const long total = M * q4;
     const long pstride = M * Cp;
-    const float qs = (P == 2 && q.scale) ? *q.scale : 1.f;
+    const float qs = (P <= 2 && q.scale) ? *q.scale : 1.f;
     float amx = 0.f;
     bool sat = false;
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
@@ -200,7 +204,7 @@ __global__ __launch_bounds__(256) void act_split_kernel(const float *__restrict_
                 if (c + j < C) t[j] = x[m * C + c + j];
             v = make_float4(t[0], t[1], t[2], t[3]);
         }
-        if (P == 2) {
+        if (P <= 2) {
             const float t4[4] = {v.x, v.y, v.z, v.w};
             amx = amax4(amx, t4);
         }
@@ -210,7 +214,7 @@ __global__ __launch_bounds__(256) void act_split_kernel(const float *__restrict_
 #pragma unroll
         for (int p = 0; p < P; ++p) *(bf16x4 *)(parts + p * pstride + m * Cp + c) = ps[p];
     }
-    if (P == 2) amax_commit(amx, sat, q, s_word);
+    if (P <= 2) amax_commit(amx, sat, q, s_word);
 }
 
 // Patch matrix of a small-Cin convolution (the 3-channel 7x7/2 stems, modals.py:311 and
@@ -237,7 +241,7 @@ __global__ __launch_bounds__(256) void im2col_split_kernel(const float *__restri
     __syncthreads();
     const int q4 = Kp / 4;
     const long M = (long)N * OH * OW, total = M * q4;
-    const float qs = (P == 2 && q.scale) ? *q.scale : 1.f;
+    const float qs = (P <= 2 && q.scale) ? *q.scale : 1.f;
     float amx = 0.f;
     bool sat = false;
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
@@ -260,14 +264,14 @@ __global__ __launch_bounds__(256) void im2col_split_kernel(const float *__restri
             const bool ok = (pos >> 16) && ih >= 0 && ih < H && iw >= 0 && iw < W;
             v[j] = ok ? px[offv[j]] : 0.f;
         }
-        if (P == 2) amx = amax4(amx, v);
+        if (P <= 2) amx = amax4(amx, v);
         if (!parts) continue;
         bf16x4 ps[P];
         sat |= split4<P>(make_float4(v[0], v[1], v[2], v[3]), ps, qs);
 #pragma unroll
         for (int p = 0; p < P; ++p) *(bf16x4 *)(parts + p * pstride + (row0 + m) * Kp + kq) = ps[p];
     }
-    if (P == 2) amax_commit(amx, sat, q, s_word);
+    if (P <= 2) amax_commit(amx, sat, q, s_word);
 }
 
 // Adjoint of the patch matrix (data gradient of a stem, needed only when the image itself carries a
@@ -413,7 +417,7 @@ __device__ __forceinline__ void grad_prep_emit(float g[4], long m, int c, int C,
 #pragma clang fp contract(off)
         for (int j = 0; j < 4; ++j) g[j] = g[j] * sc[j];
     }
-    if (P == 2) amx = amax4(amx, g);
+    if (P <= 2) amx = amax4(amx, g);
     if (!parts) return;                      // amax-only pass (first use of the tensor's scale slot)
     for (int j = 0; j < 4; ++j) acc[j] += g[j];
     bf16x4 ps[P];
@@ -439,7 +443,7 @@ __global__ __launch_bounds__(256) void grad_prep_kernel(const float *__restrict_
     const int cq_l = threadIdx.x & (tw - 1), r0 = threadIdx.x >> sh;
     const long pstride = M * Cp;
     const long rstep = (long)gridDim.x * R;
-    const float qs = (P == 2 && q.scale) ? *q.scale : 1.f;
+    const float qs = (P <= 2 && q.scale) ? *q.scale : 1.f;
     float amx = 0.f;
     bool sat = false;
     for (int ct = 0; ct * tw < q4; ++ct) {
@@ -476,7 +480,7 @@ __global__ __launch_bounds__(256) void grad_prep_kernel(const float *__restrict_
             __syncthreads();
         }
     }
-    if (P == 2) amax_commit(amx, sat, q, s_word);
+    if (P <= 2) amax_commit(amx, sat, q, s_word);
 }
 
 // K order of conv_fwd256_kernel: stage s <-> (tap, 16-channel chunk cc).  64-channel group major,
@@ -510,7 +514,7 @@ __global__ __launch_bounds__(256) void split_weights_tiled_kernel(const float *_
     const int ntap = KH * KW, ncc = (I + T2K - 1) / T2K, nk = ntap * ncc, gn = (O + T2 - 1) / T2;
     const long per_part = (long)T2 * T2K;                       // 4096 elements = 8 KB
     const long total = (long)gn * nk * per_part;                // logical elements (one part)
-    const float qs = (P == 2 && q.scale) ? *q.scale : 1.f;
+    const float qs = (P <= 2 && q.scale) ? *q.scale : 1.f;
     float amx = 0.f;
     bool sat = false;
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
@@ -543,7 +547,7 @@ __global__ __launch_bounds__(256) void split_weights_tiled_kernel(const float *_
             v -= (float)h;
         }
     }
-    if (P == 2) amax_commit(amx, sat, q, s_word);
+    if (P <= 2) amax_commit(amx, sat, q, s_word);
 }
 
 // ---- conv_fwd256h_kernel (two fp16 parts, 32-channel stages) ----
@@ -607,7 +611,7 @@ __global__ __launch_bounds__(256) void split_weights_kernel(const float *__restr
                                                             __bf16 *__restrict__ out, SplitScale q) {
     __shared__ unsigned s_word[2];
     const long total = (long)O * KH * KW * Ip;
-    const float qs = (P == 2 && q.scale) ? *q.scale : 1.f;
+    const float qs = (P <= 2 && q.scale) ? *q.scale : 1.f;
     float amx = 0.f;
     bool sat = false;
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
@@ -618,15 +622,14 @@ __global__ __launch_bounds__(256) void split_weights_kernel(const float *__restr
         const int o = (int)(r / KH);
         const int skh = flip ? KH - 1 - kh : kh, skw = flip ? KW - 1 - kw : kw;
         float v = (i < I) ? w[o * s_o + i * s_i + skh * s_kh + skw * s_kw] : 0.f;
-        if (P == 2) {
+        if (P <= 2) {
             amx = fmaxf(amx, fabsf(v));
             if (!out) continue;
             float qv = v * qs;
             if (fabsf(qv) > SLN_F16_MAX) { qv = copysignf(SLN_F16_MAX, qv); sat = true; }
             const _Float16 h0 = (_Float16)qv;
-            const _Float16 h1 = (_Float16)(qv - (float)h0);
             out[idx] = __builtin_bit_cast(__bf16, h0);
-            out[total + idx] = __builtin_bit_cast(__bf16, h1);
+            if (P == 2) out[total + idx] = __builtin_bit_cast(__bf16, (_Float16)(qv - (float)h0));
             continue;
         }
         for (int pp = 0; pp < P; ++pp) {
@@ -635,7 +638,7 @@ __global__ __launch_bounds__(256) void split_weights_kernel(const float *__restr
             v -= (float)h;
         }
     }
-    if (P == 2) amax_commit(amx, sat, q, s_word);
+    if (P <= 2) amax_commit(amx, sat, q, s_word);
 }
 
 // All stale weight tensors of a step in ONE launch (parts = 2).  A training step re-splits every trainable
@@ -785,6 +788,9 @@ __device__ __forceinline__ void mfma_products(const bf16x8 (&a)[P], const bf16x8
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], c, 0, 0, 0);
+    } else if (P == 1) {   // one scaled fp16 part per operand: one product
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a[0]), __builtin_bit_cast(h16x8, b[0]), c,
+                                                   0, 0, 0);
     } else {   // two fp16 parts: the same 16-bit containers, the f16 matrix instruction
         const h16x8 a0 = __builtin_bit_cast(h16x8, a[0]), a1 = __builtin_bit_cast(h16x8, a[P - 1]);
         const h16x8 b0 = __builtin_bit_cast(h16x8, b[0]), b1 = __builtin_bit_cast(h16x8, b[P - 1]);
@@ -825,7 +831,7 @@ __device__ __forceinline__ void epilogue_slab(const ConvParams &p, const float *
                 if (p.scale) sc[e] = p.scale[c + e];
                 if (p.shift) sf[e] = p.shift[c + e];
                 if (p.post_scale) ps_[e] = p.post_scale[c + e];
-                if (P == 2) sc[e] *= alpha;      // exact (power of two): acc * alpha * scale == acc * (alpha*scale)
+                if (P <= 2) sc[e] *= alpha;      // exact (power of two): acc * alpha * scale == acc * (alpha*scale)
             }
         // all residual rows of this half are requested before the first store: the
         // loads cannot be moved across the y stores by the compiler (may alias)
@@ -895,7 +901,7 @@ __device__ __forceinline__ void epilogue_slab(const ConvParams &p, const float *
             for (int e = 0; e < 4; ++e) csum[e] += v[e];
             if (p.yparts) {   // fused act_split of the output (Cop % 8 == 0, c % 4 == 0)
                 bf16x4 ps[3];
-                if (P == 2) amx = amax4(amx, v);
+                if (P <= 2) amx = amax4(amx, v);
                 sat |= split4<P>(make_float4(v[0], v[1], v[2], v[3]), ps, yqs);
 #pragma unroll
                 for (int pp = 0; pp < P; ++pp)
@@ -918,7 +924,7 @@ __device__ __forceinline__ void epilogue_slab(const ConvParams &p, const float *
 // (stamps, tools/conv_stamps.py: the slab calls themselves, not their barriers or the store drain) -- more
 // than the whole k-loop of a K = 256 layer; 17-40 k with this one.  Same arithmetic per element as
 // epilogue_slab + split4<2> (bit-identical y, parts and column sums up to their summation order).
-template <int NCOLQ, int LD, int NTHREADS, int RES, bool PARTS>
+template <int NCOLQ, int LD, int NTHREADS, int RES, bool PARTS, int NP = 2>
 __device__ __forceinline__ void epilogue_slab_f16(const ConvParams &p, const float *stage, int m_base, int n0,
                                                   int t, float *s_colsum, float alpha, float yqs, float &amx) {
     // RES: 0 no residual, 1 fp32 residual, 2 residual from its two fp16 parts ((h0 + h1) / s_res: what the
@@ -957,7 +963,7 @@ __device__ __forceinline__ void epilogue_slab_f16(const ConvParams &p, const flo
         for (int q = 0; q < NQ; ++q) {
             const bool ok = (m_base + row0 + RG * q) < p.M;
             rp0[q] = ok ? *(const h16x4 *)r0 : z4;
-            rp1[q] = ok ? *(const h16x4 *)r1 : z4;
+            rp1[q] = (ok && NP == 2) ? *(const h16x4 *)r1 : z4;      // (NP = 1: the tensor is its one fp16 part)
             r0 += pstep; r1 += pstep;
         }
     }
@@ -1005,12 +1011,17 @@ __device__ __forceinline__ void epilogue_slab_f16(const ConvParams &p, const flo
             if (RES == 1) {
                 v[0] += res4[q].x; v[1] += res4[q].y; v[2] += res4[q].z; v[3] += res4[q].w;
             }
-            if (RES == 2) {
+            if (RES == 2 && NP == 2) {
                 const h16x4 a0 = rp0[q], a1 = rp1[q];
                 v[0] += ((float)a0.x + (float)a1.x) * rinv;
                 v[1] += ((float)a0.y + (float)a1.y) * rinv;
                 v[2] += ((float)a0.z + (float)a1.z) * rinv;
                 v[3] += ((float)a0.w + (float)a1.w) * rinv;
+            }
+            if (RES == 2 && NP == 1) {
+                const h16x4 a0 = rp0[q];
+                v[0] += (float)a0.x * rinv; v[1] += (float)a0.y * rinv;
+                v[2] += (float)a0.z * rinv; v[3] += (float)a0.w * rinv;
             }
             if (relu) {
 #pragma unroll
@@ -1045,12 +1056,12 @@ __device__ __forceinline__ void epilogue_slab_f16(const ConvParams &p, const flo
                 const float rmax = amax4(0.f, v);
                 amx = fmaxf(amx, rmax);
                 bf16x4 ps[2];
-                if (!(p.dbg & 128) && __builtin_amdgcn_ballot_w64(rmax * yqs > SLN_F16_MAX) == 0)
+                if (NP == 2 && !(p.dbg & 128) && __builtin_amdgcn_ballot_w64(rmax * yqs > SLN_F16_MAX) == 0)
                     split4_inrange(make_float4(v[0], v[1], v[2], v[3]), ps, yqs);
                 else
-                    (void)split4<2>(make_float4(v[0], v[1], v[2], v[3]), ps, yqs);
+                    (void)split4<NP>(make_float4(v[0], v[1], v[2], v[3]), ps, yqs);
                 *(bf16x4 *)p0 = ps[0];
-                *(bf16x4 *)p1 = ps[1];
+                if (NP == 2) *(bf16x4 *)p1 = ps[1];
             }
         }
         if (yp) yp += ostep;
@@ -1377,8 +1388,8 @@ template <int P, int NCOLQ, int LD, int NTHREADS>
 __device__ __forceinline__ void epilogue_any(const ConvParams &p, const float *stage, int m_base, int n0, int t,
                                              float *s_colsum, float alpha, float yqs, float &amx, bool &sat,
                                              bool fast) {
-    if (P == 2 && fast) {
-#define SLN_EPI(R, Q) epilogue_slab_f16<NCOLQ, LD, NTHREADS, R, Q>(p, stage, m_base, n0, t, s_colsum, alpha, yqs, amx)
+    if (P <= 2 && fast) {
+#define SLN_EPI(R, Q) epilogue_slab_f16<NCOLQ, LD, NTHREADS, R, Q, (P <= 2 ? P : 2)>(p, stage, m_base, n0, t, s_colsum, alpha, yqs, amx)
         if (p.res_parts) {
             if (p.yparts) SLN_EPI(2, true); else SLN_EPI(2, false);
         } else if (p.residual) {
@@ -1418,8 +1429,8 @@ __global__ __launch_bounds__(256, BNT == 128 ? SLN_FWD128_BLOCKS : 1) void conv_
     __shared__ float s_colsum[BNT];   // per-block column sums of the output (colsum mode)
     __shared__ unsigned s_word[2];    // block amax / saturation flag of the output parts (P = 2)
     if (threadIdx.x < BNT) s_colsum[threadIdx.x] = 0.f;   // ordered by the k-loop's barriers
-    const float alpha = P == 2 ? operand_unscale(p.x_scale, p.w_scale) : 1.f;
-    const float yqs = (P == 2 && p.yq.scale) ? *p.yq.scale : 1.f;
+    const float alpha = P <= 2 ? operand_unscale(p.x_scale, p.w_scale) : 1.f;
+    const float yqs = (P <= 2 && p.yq.scale) ? *p.yq.scale : 1.f;
     float amx = 0.f;
     bool sat = false;
 
@@ -1559,7 +1570,7 @@ __global__ __launch_bounds__(256, BNT == 128 ? SLN_FWD128_BLOCKS : 1) void conv_
     // tiles), read back row-major: thread t owns columns 4*(t&31)..+3 of rows
     // (t>>5) + 8q.  Per element: v = acc*scale[c] + shift[c] (+ residual) (ReLU).
     float(*stage)[SLD] = (float(*)[SLD])smem;
-    const bool plain = P == 2 && epilogue_is_plain(p) && !(p.dbg & 16);
+    const bool plain = P <= 2 && epilogue_is_plain(p) && !(p.dbg & 16);
     auto stage_slab = [&](int h) {
         // rows 64h .. 64h+63 of the tile: waves wr == h (BNT 128, 64 rows each) or wr>>1 == h (BNT 64, 32 each)
         if ((BNT == 128 ? wr : wr >> 1) == h) {
@@ -1585,7 +1596,7 @@ __global__ __launch_bounds__(256, BNT == 128 ? SLN_FWD128_BLOCKS : 1) void conv_
             else if (EPI == 4) SLN_W8E(1, 2, false); else if (EPI == 5) SLN_W8E(1, 0, false); else SLN_W8E(0, 0, false);
         }
 #undef SLN_W8E
-    } else if (plain && epilogue_is_w8(p)) {
+    } else if (P == 2 && plain && epilogue_is_w8(p)) {
         epilogue_tile_w8_any<BNT / 8, SLD, 256, 2>(p, &stage[0][0], m0, n0, t, s_colsum, alpha, yqs, amx, stage_slab);
     } else {
 #pragma unroll
@@ -1598,8 +1609,8 @@ __global__ __launch_bounds__(256, BNT == 128 ? SLN_FWD128_BLOCKS : 1) void conv_
     }
     if (p.colsum && t < BNT && n0 + t < p.Cout && s_colsum[t] != 0.f)   // one global atomic per column
         atomicAdd(p.colsum + n0 + t, s_colsum[t]);
-    if (P == 2 && plain) sat = amx * yqs > SLN_F16_MAX;
-    if (P == 2 && p.yparts) amax_commit(amx, sat, p.yq, s_word);
+    if (P <= 2 && plain) sat = amx * yqs > SLN_F16_MAX;
+    if (P <= 2 && p.yparts) amax_commit(amx, sat, p.yq, s_word);
 }
 
 // ---------------------------------------------------------------- 256x256 forward tile
@@ -2868,7 +2879,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
         }
     }
     // epilogue: row = co, col = ci; atomics (split-K partial sums)
-    const float alpha = P == 2 ? operand_unscale(p.gz_scale, p.x_scale) : 1.f;
+    const float alpha = P <= 2 ? operand_unscale(p.gz_scale, p.x_scale) : 1.f;
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
         const int ci = n0 + wc * (TN / 2) + j * 32 + (lane & 31);
@@ -3486,10 +3497,10 @@ extern "C" int sln_conv_split_weights_f32(const float *w, int O, int I, int I_pa
                                           int layout, uint16_t *out, const float *q_scale, float *q_amax,
                                           int32_t *q_saturated, sln_stream_t stream) {
     sln_enter();
-    if (!w || O < 1 || I < 1 || I_pad < I || KH < 1 || KW < 1 || parts < 2 || parts > 3 || layout < 0 ||
-        layout > 2 || (layout == SLN_WEIGHTS_TILED256H && parts != 2))
+    if (!w || O < 1 || I < 1 || I_pad < I || KH < 1 || KW < 1 || parts < 1 || parts > 3 || layout < 0 ||
+        layout > 2 || (layout == SLN_WEIGHTS_TILED256H && parts != 2) || (layout != SLN_WEIGHTS_ROWS && parts == 1))
         return SLN_ERR_INVALID_ARG;
-    if (!out && !(parts == 2 && q_amax)) return SLN_ERR_INVALID_ARG;   // out == NULL: amax-only pass
+    if (!out && !(parts <= 2 && q_amax)) return SLN_ERR_INVALID_ARG;   // out == NULL: amax-only pass
     const SplitScale q = {q_scale, q_amax, q_saturated};
     if (layout == SLN_WEIGHTS_TILED256H) {
         const long total = sln_conv_tiled_weight_elems(O, I, KH, KW, layout);
@@ -3513,11 +3524,14 @@ extern "C" int sln_act_split_f32(const float *x, int64_t M, int C, int C_pad, in
                                  const float *q_scale, float *q_amax, int32_t *q_saturated,
                                  sln_stream_t stream) {
     sln_enter();
-    if (M < 0 || C < 1 || C_pad < C || (C_pad & 7) || parts < 2 || parts > 3) return SLN_ERR_INVALID_ARG;
+    if (M < 0 || C < 1 || C_pad < C || (C_pad & 7) || parts < 1 || parts > 3) return SLN_ERR_INVALID_ARG;
     if (M == 0) return SLN_OK;
-    if (!x || (!out && !(parts == 2 && q_amax))) return SLN_ERR_INVALID_ARG;
+    if (!x || (!out && !(parts <= 2 && q_amax))) return SLN_ERR_INVALID_ARG;
     const SplitScale q = {q_scale, q_amax, q_saturated};
-    if (parts == 2)
+    if (parts == 1)
+        hipLaunchKernelGGL(act_split_kernel<1>, dim3(ew_grid(M * (C_pad / 4))), dim3(256), 0,
+                           (hipStream_t)stream, x, (long)M, C, C_pad, (__bf16 *)out, q);
+    else if (parts == 2)
         hipLaunchKernelGGL(act_split_kernel<2>, dim3(ew_grid(M * (C_pad / 4))), dim3(256), 0,
                            (hipStream_t)stream, x, (long)M, C, C_pad, (__bf16 *)out, q);
     else
@@ -3545,17 +3559,21 @@ extern "C" int sln_im2col_split_f32(const float *x, int N, int H, int W, int C, 
                                     sln_stream_t stream) {
     sln_enter();
     if (N < 0 || H < 1 || W < 1 || C < 1 || KH < 1 || KW < 1 || KH > 255 || KW > 255 || stride_h < 1 ||
-        stride_w < 1 || OH < 1 || OW < 1 || parts < 2 || parts > 3)
+        stride_w < 1 || OH < 1 || OW < 1 || parts < 1 || parts > 3)
         return SLN_ERR_INVALID_ARG;
     if (K_pad < KH * KW * C || (K_pad & 7) || K_pad > 4096) return SLN_ERR_INVALID_ARG;
     const long M = (long)N * OH * OW;
     if (row0 < 0 || row0 + M > out_rows) return SLN_ERR_INVALID_ARG;
     if (M == 0) return SLN_OK;
-    if (!x || (!out && !(parts == 2 && q_amax))) return SLN_ERR_INVALID_ARG;
+    if (!x || (!out && !(parts <= 2 && q_amax))) return SLN_ERR_INVALID_ARG;
     const SplitScale q = {q_scale, q_amax, q_saturated};
     const size_t lds = sizeof(int) * 2 * (size_t)K_pad;
     const long pstride = (long)out_rows * K_pad;
-    if (parts == 2)
+    if (parts == 1)
+        hipLaunchKernelGGL(im2col_split_kernel<1>, dim3(ew_grid(M * (K_pad / 4))), dim3(256), lds,
+                           (hipStream_t)stream, x, N, H, W, C, KH, KW, stride_h, stride_w, pad_top, pad_left, OH,
+                           OW, K_pad, pstride, (long)row0, (__bf16 *)out, q);
+    else if (parts == 2)
         hipLaunchKernelGGL(im2col_split_kernel<2>, dim3(ew_grid(M * (K_pad / 4))), dim3(256), lds,
                            (hipStream_t)stream, x, N, H, W, C, KH, KW, stride_h, stride_w, pad_top, pad_left, OH,
                            OW, K_pad, pstride, (long)row0, (__bf16 *)out, q);
@@ -3590,9 +3608,9 @@ extern "C" int sln_conv_grad_prep_f32(const float *gy, const float *y, const uin
     // per step -- and the fill launch per layer is saved)
     const bool sums_zero = (parts & SLN_SUMS_PREZEROED) != 0;
     parts &= ~SLN_SUMS_PREZEROED;
-    if (M < 0 || C < 1 || C_pad < C || (C_pad & 7) || parts < 2 || parts > 3) return SLN_ERR_INVALID_ARG;
-    if (!gy || (!gz_parts && !(parts == 2 && q_amax))) return SLN_ERR_INVALID_ARG;
-    if (y_part0 && (y || parts != 2)) return SLN_ERR_INVALID_ARG;   // one ReLU pattern; fp16 parts only
+    if (M < 0 || C < 1 || C_pad < C || (C_pad & 7) || parts < 1 || parts > 3) return SLN_ERR_INVALID_ARG;
+    if (!gy || (!gz_parts && !(parts <= 2 && q_amax))) return SLN_ERR_INVALID_ARG;
+    if (y_part0 && (y || parts > 2)) return SLN_ERR_INVALID_ARG;   // one ReLU pattern; fp16 parts only
     hipStream_t st = (hipStream_t)stream;
     if (!sums_zero && gz_parts && gbias && hipMemsetAsync(gbias, 0, sizeof(float) * C, st) != hipSuccess)
         return SLN_ERR_LAUNCH;
@@ -3603,7 +3621,10 @@ extern "C" int sln_conv_grad_prep_f32(const float *gy, const float *y, const uin
     if (grid > 2048) grid = 2048;
     const SplitScale q = {q_scale, q_amax, q_saturated};
     const PoolSrc nopool = {};
-    if (parts == 2)
+    if (parts == 1)
+        hipLaunchKernelGGL(grad_prep_kernel<1>, dim3((unsigned)grid), dim3(256), 0, st, gy, y,
+                           (const __bf16 *)y_part0, scale, (long)M, C, C_pad, gu, (__bf16 *)gz_parts, gbias, q, nopool);
+    else if (parts == 2)
         hipLaunchKernelGGL(grad_prep_kernel<2>, dim3((unsigned)grid), dim3(256), 0, st, gy, y,
                            (const __bf16 *)y_part0, scale, (long)M, C, C_pad, gu, (__bf16 *)gz_parts, gbias, q, nopool);
     else
@@ -3624,10 +3645,10 @@ extern "C" int sln_conv_grad_prep_pooled_f32(const float *g_pool, const uint8_t 
     sln_enter();
     const bool sums_zero = (parts & SLN_SUMS_PREZEROED) != 0;
     parts &= ~SLN_SUMS_PREZEROED;
-    if (N < 0 || H < 1 || W < 1 || C < 8 || (C & 7) || parts < 2 || parts > 3 || K < 1 || K > 15 || S < 1 || pad_top < 0 ||
+    if (N < 0 || H < 1 || W < 1 || C < 8 || (C & 7) || parts < 1 || parts > 3 || K < 1 || K > 15 || S < 1 || pad_top < 0 ||
         pad_left < 0 || pad_top >= K || pad_left >= K || OH < 1 || OW < 1)
         return SLN_ERR_INVALID_ARG;
-    if (!g_pool || !argmax || (!gz_parts && !(parts == 2 && q_amax))) return SLN_ERR_INVALID_ARG;
+    if (!g_pool || !argmax || (!gz_parts && !(parts <= 2 && q_amax))) return SLN_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (!sums_zero && gz_parts && gbias && hipMemsetAsync(gbias, 0, sizeof(float) * C, st) != hipSuccess)
         return SLN_ERR_LAUNCH;
@@ -3639,7 +3660,10 @@ extern "C" int sln_conv_grad_prep_pooled_f32(const float *g_pool, const uint8_t 
     if (grid > 2048) grid = 2048;
     const SplitScale q = {q_scale, q_amax, q_saturated};
     const PoolSrc ps = {g_pool, argmax, H, W, K, S, pad_top, pad_left, OH, OW};
-    if (parts == 2)
+    if (parts == 1)
+        hipLaunchKernelGGL(grad_prep_kernel<1>, dim3((unsigned)grid), dim3(256), 0, st, g_pool, y, (const __bf16 *)nullptr,
+                           scale, M, C, C, (float *)nullptr, (__bf16 *)gz_parts, gbias, q, ps);
+    else if (parts == 2)
         hipLaunchKernelGGL(grad_prep_kernel<2>, dim3((unsigned)grid), dim3(256), 0, st, g_pool, y, (const __bf16 *)nullptr,
                            scale, M, C, C, (float *)nullptr, (__bf16 *)gz_parts, gbias, q, ps);
     else
@@ -3672,7 +3696,7 @@ extern "C" int sln_conv_fwd_last_kernel(void) { return sln_last_fwd_kernel; }
 
 extern "C" int sln_conv_fwd_tile(int64_t M, int Cout, int64_t K, int parts) {
     const int mode = sln_knob("SLN_CONV_TILE256", 1);
-    if (M < 1 || Cout < 1 || M > 2147483647L - T2) return BM;
+    if (M < 1 || Cout < 1 || M > 2147483647L - T2 || parts == 1) return BM;     // (single fp16 part: the generic kernel)
     if (mode == 2) return T2;
     if (mode != 1) return BM;
     const long nb2 = sln_div_up(M, T2) * (long)sln_div_up(Cout, T2);
@@ -3700,7 +3724,7 @@ extern "C" int sln_conv2d_fwd_ms_f32(const uint16_t *x_parts, int nseg, const in
     if (!x_parts || !w_parts || (!y && !y_parts) || !seg_nhw || nseg < 1 || nseg > SLN_MAX_SEG || Cin < 1 || Cout < 1 ||
         KH < 1 || KW < 1 || stride_h < 1 || stride_w < 1 || dil_h < 1 || dil_w < 1)
         return SLN_ERR_INVALID_ARG;
-    if (parts != 2 && parts != 3) return SLN_ERR_INVALID_ARG;
+    if (parts < 1 || parts > 3) return SLN_ERR_INVALID_ARG;
     if (Cin % 8 != 0) return SLN_ERR_UNSUPPORTED;  // 16-B vector loads along (padded) channels
     ConvParams p;
     long M = 0, Min = 0;
@@ -3753,7 +3777,7 @@ extern "C" int sln_conv2d_fwd_ms_f32(const uint16_t *x_parts, int nseg, const in
     if (residual_parts || mask_part0) {
         // parts-only operands of the epilogue exist in the fixed-feature slab only: fp16 x 2, whole 16-B row
         // groups, and not the round-1 256^2 kernel (operands beyond the 4-GiB buffer range)
-        if (parts != 2 || (Cout & 7) || w_layout == SLN_WEIGHTS_TILED256) return SLN_ERR_UNSUPPORTED;
+        if (parts > 2 || (Cout & 7) || w_layout == SLN_WEIGHTS_TILED256) return SLN_ERR_UNSUPPORTED;
         p.dbg &= ~16;
     }
     const long gm2 = sln_div_up(M, T2), gn2 = sln_div_up(Cout, T2);
@@ -3838,7 +3862,9 @@ extern "C" int sln_conv2d_fwd_ms_f32(const uint16_t *x_parts, int nseg, const in
     const dim3 g((unsigned)nblk), b(256);
     const bool w8 = parts == 2 && epilogue_is_plain(p) && !(p.dbg & 16) && epilogue_is_w8(p) && !(p.dbg & 256) &&
                     sln_knob("SLN_CONV_EPI", 1) != 0;
-    if (parts == 2 && narrow) hipLaunchKernelGGL((conv_fwd_kernel<2, 64>), g, b, 0, (hipStream_t)stream, p);
+    if (parts == 1 && narrow) hipLaunchKernelGGL((conv_fwd_kernel<1, 64>), g, b, 0, (hipStream_t)stream, p);
+    else if (parts == 1) hipLaunchKernelGGL((conv_fwd_kernel<1, 128>), g, b, 0, (hipStream_t)stream, p);
+    else if (parts == 2 && narrow) hipLaunchKernelGGL((conv_fwd_kernel<2, 64>), g, b, 0, (hipStream_t)stream, p);
     else if (parts == 2 && w8) {       // the instance that carries only the epilogue this launch needs
         if (p.res_parts) hipLaunchKernelGGL((conv_fwd_kernel<2, 128, 2>), g, b, 0, (hipStream_t)stream, p);
         else if (p.residual && p.mask_part0) hipLaunchKernelGGL((conv_fwd_kernel<2, 128, 4>), g, b, 0, (hipStream_t)stream, p);
@@ -3880,7 +3906,7 @@ extern "C" int sln_conv2d_fwd_f32(const uint16_t *x_parts, int N, int H, int W, 
 // are enough pixels; else 128.  SLN_WGRAD_TILE256 = 0 never, 1 (default) by this rule, 2 always.
 extern "C" int sln_conv_wgrad_tile(int64_t M, int Cout, int Cin, int taps, int parts) {
     const int mode = sln_knob("SLN_WGRAD_TILE256", 1);
-    if (M < 1 || Cout < 1 || Cin < 1 || taps < 1) return BM;
+    if (M < 1 || Cout < 1 || Cin < 1 || taps < 1 || parts == 1) return BM;      // (single fp16 part: the generic kernel)
     if (mode == 2) return T2;
     if (mode != 1) return BM;
     const long nt2 = (long)sln_div_up(Cout, T2) * sln_div_up(Cin, T2) * taps;
@@ -3910,7 +3936,7 @@ extern "C" int sln_conv2d_wgrad_f32(const uint16_t *gz_parts, int Cout, int Cout
     if (!gz_parts || !x_parts || (!gw && !defer) || N < 0 || H < 1 || W < 1 || Cin < 1 || Cout < 1 || KH < 1 || KW < 1 ||
         OH < 1 || OW < 1 || Cin_pad < Cin || Cout_pad < Cout || (Cin_pad & 7) || (Cout_pad & 7))
         return SLN_ERR_INVALID_ARG;
-    if (parts != 2 && parts != 3) return SLN_ERR_INVALID_ARG;
+    if (parts < 1 || parts > 3) return SLN_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream;
     const long M = (long)N * OH * OW;
     const size_t gw_elems = (size_t)Cout * KH * KW * Cin;
@@ -3960,7 +3986,10 @@ extern "C" int sln_conv2d_wgrad_f32(const uint16_t *gz_parts, int Cout, int Cout
         const dim3 g((unsigned)nblk), b(256);
         const int TMs = w.tm, TNs = w.tn;
 #define SLN_WG(PP, A, B) hipLaunchKernelGGL((conv_wgrad_kernel<PP, A, B>), g, b, 0, st, p)
-        if (parts == 2) {
+        if (parts == 1) {
+            if (TMs == 64 && TNs == 64) SLN_WG(1, 64, 64); else if (TMs == 64) SLN_WG(1, 64, 128);
+            else if (TNs == 64) SLN_WG(1, 128, 64); else SLN_WG(1, 128, 128);
+        } else if (parts == 2) {
             if (TMs == 64 && TNs == 64) SLN_WG(2, 64, 64); else if (TMs == 64) SLN_WG(2, 64, 128);
             else if (TNs == 64) SLN_WG(2, 128, 64); else SLN_WG(2, 128, 128);
         } else {

@@ -285,3 +285,343 @@ extern "C" int sln_grouped_conv3x3_wgrad_f32(const float *x, const float *gy, co
                        (const float *)workspace, ranges, n, gw);
     return sln_launch_status();
 }
+
+// =====================================================================================================================
+// fp16 MFMA path (round 5): BASELINE.json configs[4] in its stated form -- "fp16 MFMA", fp16 storage.
+//
+// Operands are single scaled fp16 parts (conv.hip, P = 1: h = fp16(v * s), s a per-tensor power of two from the
+// delayed-scaling table), accumulation is fp32 inside v_mfma_f32_16x16x32_f16, the epilogue multiplies by
+// 1 / (sx * sw).  A grouped 3x3 with CG channels per group is block-diagonal: the GEMM runs on 16-channel tiles,
+//   * CG = 32: a tile's 16 outputs reduce over their group's 32 channels -- one 16x16x32 instruction per tap (9);
+//   * CG = 16: the tile IS a group; K = 32 holds TWO taps of its 16 channels per instruction (5, the last half empty);
+//   * CG = 8 / 4: a tile spans 2 / 4 groups of the same 16 channels; the packed weights are block-diagonal with zeros
+//     off the diagonal (2x / 4x the useful FLOPs: these layers are HBM-bound at 2 + 2 B per element anyway).
+// The WEIGHTS are the A operand (D[channel][pixel]): a lane then holds four consecutive CHANNELS of one pixel -- 16
+// contiguous bytes of an fp32 row, 8 of an fp16 row -- and the epilogue goes from registers to global memory with no
+// LDS staging.  Weight fragments come pre-packed in fragment order (one coalesced 16-B load per lane and
+// instruction, kept in registers for the block's four pixel tiles); activation fragments are 16-B gathers straight
+// from the NHWC rows (a lane = one pixel's 8 consecutive channels of one tap; taps outside the image are zeros).
+// A block = 64 channels (one tile per wave: the four waves read the same pixels' 128-B line) x 64 pixels.
+// MODE 0: forward (BN affine + ReLU fused, fp32 and / or scaled-fp16 output with its running amax).
+// MODE 1: data gradient: a pixel = an INPUT pixel, tap (kh, kw) reads the prepared gradient at
+//         (ih + 1 - kh, iw + 1 - kw) / stride where that is an output position; fp32 out.
+typedef __attribute__((ext_vector_type(8))) _Float16 gh16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 gh16x4;
+typedef __attribute__((ext_vector_type(4))) float gf32x4;
+#define SLN_GF16_MAX 65504.0f
+
+struct GroupedParams {
+    const _Float16 *x;        // [pixels read][C] scaled fp16
+    const _Float16 *wpk;      // packed fragments [C/16][NM][64][8]
+    const float *scale, *shift;      // [C] or NULL (MODE 0)
+    float *y;                 // [pixels produced][C] fp32 or NULL
+    _Float16 *y16;            // [pixels produced][C] scaled fp16 or NULL (MODE 0)
+    const float *x_scale, *w_scale, *yq_scale;
+    float *yq_amax;
+    int32_t *yq_sat;
+    int N, H, W, C, stride, OH, OW, relu;
+    long M;                   // produced pixels
+};
+
+__device__ __forceinline__ void g_amax_commit(float m, bool sat, float *amax, int32_t *saturated, unsigned *s_word) {
+    if (!amax && !saturated) return;
+    if (threadIdx.x == 0) { s_word[0] = 0u; s_word[1] = 0u; }
+    __syncthreads();
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    const bool any_sat = __any(sat);
+    if ((threadIdx.x & 63) == 0) {
+        if (m > 0.f) atomicMax(&s_word[0], __float_as_uint(m));
+        if (any_sat) s_word[1] = 1u;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned bits = s_word[0];
+        if (amax && bits > __float_as_uint(*(volatile const float *)amax)) atomicMax((unsigned *)amax, bits);
+        if (saturated && s_word[1]) atomicAdd(saturated, 1);
+    }
+}
+
+template <int CG, int MODE>
+__global__ __launch_bounds__(256) void grouped_mfma_kernel(const GroupedParams p) {
+    constexpr int NM = CG == 32 ? 9 : 5;          // MFMA instructions per 16 x 16 output tile
+    __shared__ unsigned s_word[2];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int tile = blockIdx.y * 4 + wave, c0 = tile * 16;
+    const int cb = CG == 32 ? (c0 & ~31) : c0;    // first channel of the reduced range
+    const int q = lane >> 4;                      // this lane's 8-wide k chunk
+    gh16x8 a[NM];
+#pragma unroll
+    for (int m = 0; m < NM; ++m) a[m] = *(const gh16x8 *)(p.wpk + (((long)tile * NM + m) * 64 + lane) * 8);
+    const float alpha = 1.0f / ((p.x_scale ? *p.x_scale : 1.f) * (p.w_scale ? *p.w_scale : 1.f));
+    const float yqs = p.yq_scale ? *p.yq_scale : 1.f;
+    const int cq = c0 + 4 * q;                    // the four channels this lane holds of every output pixel
+    float sc[4] = {alpha, alpha, alpha, alpha}, sf[4] = {0.f, 0.f, 0.f, 0.f};
+    if (MODE == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (p.scale) sc[r] = p.scale[cq + r] * alpha;
+            if (p.shift) sf[r] = p.shift[cq + r];
+        }
+    }
+    const int PH = MODE == 0 ? p.OH : p.H, PW = MODE == 0 ? p.OW : p.W;      // produced grid
+    const int QH = MODE == 0 ? p.H : p.OH, QW = MODE == 0 ? p.W : p.OW;      // grid that is read
+    float amx = 0.f;
+    bool sat = false;
+#pragma unroll 1
+    for (int pt = 0; pt < 4; ++pt) {
+        const long pix = (long)blockIdx.x * 64 + pt * 16 + (lane & 15);
+        const bool pok = pix < p.M;
+        const long pp = pok ? pix : 0;
+        const int pw = (int)(pp % PW), ph = (int)((pp / PW) % PH);
+        const long n = pp / ((long)PW * PH);
+        gh16x8 b[NM];
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            const int tap = CG == 32 ? m : 2 * m + (q >> 1);
+            const int choff = CG == 32 ? cb + 8 * q : cb + 8 * (q & 1);
+            const int kh = tap / 3, kw = tap - 3 * kh;
+            int qh, qw;
+            bool ok = pok && tap < 9;
+            if (MODE == 0) {
+                qh = ph * p.stride - 1 + kh; qw = pw * p.stride - 1 + kw;
+            } else {
+                const int th = ph + 1 - kh, tw = pw + 1 - kw;
+                ok = ok && th >= 0 && tw >= 0 && (th % p.stride) == 0 && (tw % p.stride) == 0;
+                qh = th / p.stride; qw = tw / p.stride;
+            }
+            ok = ok && (unsigned)qh < (unsigned)QH && (unsigned)qw < (unsigned)QW;
+            const gh16x8 z = {};
+            b[m] = ok ? *(const gh16x8 *)(p.x + ((n * QH + qh) * (long)QW + qw) * p.C + choff) : z;
+        }
+        gf32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int m = 0; m < NM; ++m) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[m], b[m], acc, 0, 0, 0);
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            v[r] = acc[r] * sc[r] + sf[r];
+            if (MODE == 0 && p.relu) v[r] = fmaxf(v[r], 0.f);
+        }
+        if (pok) {
+            if (p.y) *(float4 *)(p.y + pix * p.C + cq) = make_float4(v[0], v[1], v[2], v[3]);
+            if (MODE == 0 && p.y16) {
+                gh16x4 h;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    amx = fmaxf(amx, fabsf(v[r]));
+                    float s = v[r] * yqs;
+                    if (fabsf(s) > SLN_GF16_MAX) { s = copysignf(SLN_GF16_MAX, s); sat = true; }
+                    h[r] = (_Float16)s;
+                }
+                *(gh16x4 *)(p.y16 + pix * p.C + cq) = h;
+            }
+        }
+    }
+    if (MODE == 0 && p.y16) g_amax_commit(amx, sat, p.yq_amax, p.yq_sat, s_word);
+}
+
+// Weights fp32 [C][CG][3][3] (the parameter) -> fragment-ordered scaled fp16 [C/16][NM][64][8] (+ the tensor's amax).
+// flip = 0: forward (rows = output channels, k = (tap, input channel)); 1: data gradient (rows = INPUT channels,
+// k = (tap, output channel)).  out == NULL: amax only (first use of the weight's scale slot).
+__global__ __launch_bounds__(256) void grouped_pack_weights_kernel(const float *__restrict__ w, int C, int CG, int flip,
+                                                                   _Float16 *__restrict__ out,
+                                                                   const float *__restrict__ q_scale, float *q_amax,
+                                                                   int32_t *q_sat) {
+    __shared__ unsigned s_word[2];
+    const int NM = CG == 32 ? 9 : 5;
+    const long total = (long)(C / 16) * NM * 512;
+    const float qs = q_scale ? *q_scale : 1.f;
+    float amx = 0.f;
+    bool sat = false;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int j = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
+        const int m = (int)((idx >> 9) % NM), tile = (int)(idx / (512L * NM));
+        const int row = lane & 15, k = 8 * (lane >> 4) + j;
+        const int c_row = tile * 16 + row;
+        int tap, kc;
+        if (CG == 32) { tap = m; kc = ((tile * 16) & ~31) + k; }
+        else { tap = 2 * m + (k >> 4); kc = tile * 16 + (k & 15); }
+        float v = 0.f;
+        if (tap < 9 && kc / CG == c_row / CG)
+            v = flip ? w[((long)kc * CG + (c_row % CG)) * 9 + tap] : w[((long)c_row * CG + (kc % CG)) * 9 + tap];
+        amx = fmaxf(amx, fabsf(v));
+        if (!out) continue;
+        float s = v * qs;
+        if (fabsf(s) > SLN_GF16_MAX) { s = copysignf(SLN_GF16_MAX, s); sat = true; }
+        out[idx] = (_Float16)s;
+    }
+    g_amax_commit(amx, sat, q_amax, q_sat, s_word);
+}
+
+// Weight gradient on the matrix cores: per tap D[co][ci] = sum over pixels of gz[pix][co] * x[pix @ tap][ci], K = the
+// pixels (32 per instruction).  Both operands are pixel-major in memory, the MFMA wants them channel-major: a wave
+// stages 32 pixels of its 16 gz channels and of the nine shifted inputs in LDS as [pixel][channel] rows and reads the
+// fragments with ds_read_b64_tr_b16 (the transposing read: a 16-lane group gets a 4 x 16 block column-major).
+// A block = 64 channels (a 16-channel tile per wave, wave-private LDS) x one pixel range; partial sums per range
+// in the parameter's own order, then grouped_wgrad_reduce_kernel (ordered: the same bits on every run).
+template <int LD>
+__device__ __forceinline__ gh16x8 g_tr_frag(const _Float16 *tile, int k0, int m0, int lane) {
+    // lane 4q+p of a 16-lane group addresses row k0+q, columns m0+4p..+3; lane i receives column m0+i, rows k0..k0+3
+    const int li = lane & 15, qq = li >> 2, pq = li & 3;
+    // (the transposing read moves 16-bit containers: the bf16 form of the builtin, as in conv.hip's tr_frag)
+    typedef __attribute__((ext_vector_type(4))) __bf16 g_bf16x4;
+    typedef __attribute__((address_space(3))) g_bf16x4 lds_b16x4;
+    const _Float16 *p0 = tile + (k0 + qq) * LD + m0 + 4 * pq;
+    const gh16x4 lo = __builtin_bit_cast(gh16x4, __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b16x4 *)p0));
+    const gh16x4 hi = __builtin_bit_cast(gh16x4, __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b16x4 *)(p0 + 4 * LD)));
+    gh16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+}
+
+template <int CG>
+__global__ __launch_bounds__(256) void grouped_wgrad_mfma_kernel(const _Float16 *__restrict__ x,
+                                                                 const _Float16 *__restrict__ gz, int N, int H, int W,
+                                                                 int C, int stride, int OH, int OW, long pix_per_range,
+                                                                 const float *gz_scale, const float *x_scale,
+                                                                 float *__restrict__ partial) {
+    constexpr int KC = CG == 32 ? 32 : 16, NB = KC / 16;
+    constexpr int LDG = 16 + 8, LDX = KC + 8;          // row strides in halves: 48 / 48 or 80 B (multiples of 16 B)
+    __shared__ __attribute__((aligned(16))) _Float16 s_g[4][32 * LDG];
+    __shared__ __attribute__((aligned(16))) _Float16 s_x[4][9 * 32 * LDX];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int tile = blockIdx.y * 4 + wave, c0 = tile * 16;
+    const int cb = CG == 32 ? (c0 & ~31) : c0;
+    const long total = (long)N * OH * OW;
+    const long p0 = (long)blockIdx.x * pix_per_range, p1 = min(total, p0 + pix_per_range);
+    gf32x4 acc[9][NB];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int h = 0; h < NB; ++h) acc[tap][h] = gf32x4{0.f, 0.f, 0.f, 0.f};
+    _Float16 *sg = s_g[wave], *sx = s_x[wave];
+    const int row = lane >> 1, half8 = (lane & 1) * 8;      // staging: lane = (pixel row of the step, 8-channel chunk)
+    const gh16x8 z = {};
+    for (long base = p0; base < p1; base += 32) {            // (the same trip count for every wave of the block)
+        const long pq = base + row;
+        const bool pok = pq < p1;
+        const long pp = pok ? pq : 0;
+        const int ow = (int)(pp % OW), oh = (int)((pp / OW) % OH);
+        const long n = pp / ((long)OW * OH);
+        __syncthreads();
+        *(gh16x8 *)(sg + row * LDG + half8) = pok ? *(const gh16x8 *)(gz + pp * C + c0 + half8) : z;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ih = oh * stride - 1 + tap / 3, iw = ow * stride - 1 + tap % 3;
+            const bool ok = pok && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+            const _Float16 *src = x + ((n * H + ih) * (long)W + iw) * C + cb + half8;
+#pragma unroll
+            for (int h = 0; h < NB; ++h)
+                *(gh16x8 *)(sx + (tap * 32 + row) * LDX + 16 * h + half8) = ok ? *(const gh16x8 *)(src + 16 * h) : z;
+        }
+        __syncthreads();
+        const gh16x8 a = g_tr_frag<LDG>(sg, 8 * (lane >> 4), 0, lane);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int h = 0; h < NB; ++h) {
+                const gh16x8 b = g_tr_frag<LDX>(sx + tap * 32 * LDX, 8 * (lane >> 4), 16 * h, lane);
+                acc[tap][h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc[tap][h], 0, 0, 0);
+            }
+    }
+    const float alpha = 1.0f / ((gz_scale ? *gz_scale : 1.f) * (x_scale ? *x_scale : 1.f));
+    float *out = partial + (size_t)blockIdx.x * C * CG * 9;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int h = 0; h < NB; ++h)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = c0 + 4 * (lane >> 4) + r, ci = cb + 16 * h + (lane & 15);
+                if (co / CG == ci / CG) out[((size_t)co * CG + (ci % CG)) * 9 + tap] = acc[tap][h][r] * alpha;
+            }
+}
+
+static inline int g_nm(int cg) { return cg == 32 ? 9 : 5; }
+
+extern "C" int64_t sln_grouped_conv3x3_packed_weight_elems(int C, int groups) {
+    if (C < 16 || groups < 1 || C % groups || C % 64) return 0;
+    return (int64_t)(C / 16) * g_nm(C / groups) * 512;
+}
+
+extern "C" int sln_grouped_conv3x3_pack_weights_f16(const float *w, int C, int groups, int flip, uint16_t *out,
+                                                    const float *q_scale, float *q_amax, int32_t *q_saturated,
+                                                    sln_stream_t stream) {
+    sln_enter();
+    if (!w || C < 64 || groups < 1 || C % groups || C % 64 || (flip != 0 && flip != 1)) return SLN_ERR_INVALID_ARG;
+    const int cg = C / groups;
+    if (cg != 4 && cg != 8 && cg != 16 && cg != 32) return SLN_ERR_UNSUPPORTED;
+    if (!out && !q_amax) return SLN_ERR_INVALID_ARG;
+    const long total = sln_grouped_conv3x3_packed_weight_elems(C, groups);
+    long grid = (total + 255) / 256;
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(grouped_pack_weights_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, w, C, cg, flip,
+                       (_Float16 *)out, q_scale, q_amax, q_saturated);
+    return sln_launch_status();
+}
+
+// mode 0: forward, x16 [N,H,W,C] -> y / y16 [N,OH,OW,C] = relu?(conv * scale + shift); mode 1: data gradient, x16 =
+// the prepared gradient [N,OH,OW,C] (ReLU mask and BN scale already applied: sln_conv_grad_prep_f32, parts = 1),
+// w_packed packed with flip = 1 -> y = gx [N,H,W,C] fp32 (y16 must be NULL).
+extern "C" int sln_grouped_conv3x3_f16(const uint16_t *x16, int N, int H, int W, int C, int groups,
+                                       const uint16_t *w_packed, int stride, int mode, const float *scale,
+                                       const float *shift, int relu, float *y, uint16_t *y16, const float *x_scale,
+                                       const float *w_scale, const float *y_q_scale, float *y_q_amax,
+                                       int32_t *y_q_saturated, sln_stream_t stream) {
+    sln_enter();
+    if (N < 0 || H < 1 || W < 1 || C < 64 || groups < 1 || C % groups || C % 64 || stride < 1 || stride > 2 ||
+        (mode != 0 && mode != 1))
+        return SLN_ERR_INVALID_ARG;
+    const int cg = C / groups;
+    if (cg != 4 && cg != 8 && cg != 16 && cg != 32) return SLN_ERR_UNSUPPORTED;
+    if (N == 0) return SLN_OK;
+    if (!x16 || !w_packed || (!y && !y16) || (mode == 1 && (y16 || !y))) return SLN_ERR_INVALID_ARG;
+    if ((((size_t)x16) | ((size_t)y) | ((size_t)y16) | ((size_t)w_packed)) & 15) return SLN_ERR_INVALID_ARG;
+    GroupedParams p;
+    p.x = (const _Float16 *)x16; p.wpk = (const _Float16 *)w_packed; p.scale = scale; p.shift = shift;
+    p.y = y; p.y16 = (_Float16 *)y16; p.x_scale = x_scale; p.w_scale = w_scale; p.yq_scale = y_q_scale;
+    p.yq_amax = y_q_amax; p.yq_sat = y_q_saturated;
+    p.N = N; p.H = H; p.W = W; p.C = C; p.stride = stride; p.relu = relu;
+    p.OH = (H + 2 - 3) / stride + 1; p.OW = (W + 2 - 3) / stride + 1;
+    p.M = mode == 0 ? (long)N * p.OH * p.OW : (long)N * H * W;
+    const long gx = (p.M + 63) / 64;
+    if (gx > 2147483647L) return SLN_ERR_UNSUPPORTED;
+    const dim3 grid((unsigned)gx, (unsigned)(C / 64)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+#define SLN_GM(CGV) do { if (mode == 0) hipLaunchKernelGGL((grouped_mfma_kernel<CGV, 0>), grid, block, 0, st, p); \
+                         else hipLaunchKernelGGL((grouped_mfma_kernel<CGV, 1>), grid, block, 0, st, p); } while (0)
+    if (cg == 4) SLN_GM(4); else if (cg == 8) SLN_GM(8); else if (cg == 16) SLN_GM(16); else SLN_GM(32);
+#undef SLN_GM
+    return sln_launch_status();
+}
+
+// gw [C][C/groups][3][3] fp32 from the prepared gradient gz16 [N,OH,OW,C] and the layer's input x16 [N,H,W,C] (both
+// scaled fp16 parts).  workspace: sln_grouped_conv3x3_wgrad_workspace_bytes() bytes (the same plan as the fp32 path).
+extern "C" int sln_grouped_conv3x3_wgrad_f16(const uint16_t *x16, const uint16_t *gz16, int N, int H, int W, int C,
+                                             int groups, int stride, const float *gz_scale, const float *x_scale,
+                                             float *gw, void *workspace, size_t workspace_bytes, sln_stream_t stream) {
+    sln_enter();
+    if (N < 0 || H < 1 || W < 1 || C < 64 || groups < 1 || C % groups || C % 64 || stride < 1 || stride > 2 || !gw)
+        return SLN_ERR_INVALID_ARG;
+    const int cg = C / groups;
+    if (cg != 4 && cg != 8 && cg != 16 && cg != 32) return SLN_ERR_UNSUPPORTED;
+    const long n = (long)C * cg * 9;
+    hipStream_t st = (hipStream_t)stream;
+    if (N == 0) return hipMemsetAsync(gw, 0, sizeof(float) * n, st) == hipSuccess ? SLN_OK : SLN_ERR_LAUNCH;
+    if (!x16 || !gz16 || ((((size_t)x16) | ((size_t)gz16)) & 15)) return SLN_ERR_INVALID_ARG;
+    if (!workspace || workspace_bytes < sln_grouped_conv3x3_wgrad_workspace_bytes(N, H, W, C, groups, stride))
+        return SLN_ERR_WORKSPACE;
+    const int OH = (H - 1) / stride + 1, OW = (W - 1) / stride + 1;
+    const long npix = (long)N * OH * OW;
+    const int ranges = gw_ranges(npix);
+    const long per = ((npix + ranges - 1) / ranges + 31) / 32 * 32;
+    const dim3 grid((unsigned)ranges, (unsigned)(C / 64)), block(256);
+#define SLN_GWM(CGV) hipLaunchKernelGGL(grouped_wgrad_mfma_kernel<CGV>, grid, block, 0, st, (const _Float16 *)x16, (const _Float16 *)gz16, N, H, W, C, stride, OH, OW, per, gz_scale, x_scale, (float *)workspace)
+    if (cg == 4) SLN_GWM(4); else if (cg == 8) SLN_GWM(8); else if (cg == 16) SLN_GWM(16); else SLN_GWM(32);
+#undef SLN_GWM
+    hipLaunchKernelGGL(grouped_wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                       (const float *)workspace, ranges, n, gw);
+    return sln_launch_status();
+}

@@ -158,6 +158,7 @@ class PrefetchLoader(object):
         self._out = queue.Queue(maxsize=self.depth)
         self._stop = threading.Event()
         self._err = None
+        self._device_index = 0
         self.stats = {"batches": 0, "wait_s": 0.0, "depth_sum": 0, "depth_min": None, "host_zoomed": 0}
 
     # -------------------------------------------------------------- lifecycle
@@ -234,6 +235,9 @@ class PrefetchLoader(object):
             dev = self.device
             cuda = dev is not None and torch.device(dev).type == "cuda"
             if cuda:
+                dev = torch.device(dev)
+                if dev.index is None:            # a bare "cuda": the device the training thread made current
+                    dev = torch.device("cuda", self._device_index)
                 torch.cuda.set_device(dev)
                 stream = torch.cuda.Stream(device=dev)
             B, dim = self.batch, self.dim
@@ -322,6 +326,10 @@ class PrefetchLoader(object):
     def __iter__(self):
         self.start()
         if self._thread is None:
+            if self.device is not None:
+                import torch
+                if torch.device(self.device).type == "cuda":
+                    self._device_index = torch.cuda.current_device()     # (read on the consumer's thread)
             self._thread = threading.Thread(target=self._feed, name="sln-loader-feeder", daemon=True)
             self._thread.start()
         while True:

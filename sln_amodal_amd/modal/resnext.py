@@ -19,9 +19,22 @@ def _bn(c):
     return nn.BatchNorm2d(c, eps=1e-5, momentum=0.001)
 
 
-def _cba(x, conv, bn, residual=None):
+def _fp16_storage():
+    """conv_hip.PARTS == 1 (configs[4] as stated: fp16 MFMA, fp16 storage): the tensors inside a block -- read by the
+    next convolution and as ReLU patterns only -- and the block outputs -- read by convolutions and as the next
+    shortcut -- then exist as their scaled fp16 part alone (conv_bn_act(parts_only=True)): no fp32 copy is written."""
+    if nn_ops.BACKEND == "torch":
+        return False
+    try:
+        from .. import conv_hip
+    except ImportError:          # pragma: no cover
+        return False
+    return conv_hip.PARTS == 1
+
+
+def _cba(x, conv, bn, residual=None, parts_only=False):
     """conv -> frozen BN -> (+ shortcut) -> ReLU, one fused launch on the HIP path."""
-    return nn_ops.conv_bn_act(x, conv, bn, relu=True, residual=residual)
+    return nn_ops.conv_bn_act(x, conv, bn, relu=True, residual=residual, parts_only=parts_only)
 
 
 class GroupBottleneck(nn.Module):
@@ -39,11 +52,14 @@ class GroupBottleneck(nn.Module):
         self.relu = nn.ReLU(inplace=True)       # (kept for module-tree parity; the ReLUs run inside the fused convs)
         self.downsample = downsample
         self.stride = stride
+        self.materialize_output = False      # True on a stage's last block when something other than a conv reads it
 
     def forward(self, x):
-        shortcut = x if self.downsample is None else nn_ops.conv_bn_act(x, self.downsample[0], self.downsample[1])
-        h = _cba(_cba(x, self.conv1, self.bn1), self.conv2, self.bn2)
-        return _cba(h, self.conv3, self.bn3, residual=shortcut)
+        po = _fp16_storage() and x.is_cuda
+        shortcut = x if self.downsample is None else \
+            nn_ops.conv_bn_act(x, self.downsample[0], self.downsample[1], parts_only=po)
+        h = _cba(_cba(x, self.conv1, self.bn1, parts_only=po), self.conv2, self.bn2, parts_only=po)
+        return _cba(h, self.conv3, self.bn3, residual=shortcut, parts_only=po and not self.materialize_output)
 
 
 _STEM = ((3, 64, 2), (64, 64, 1), (64, 128, 1))                  # three 3x3 convolutions (modal/resnext.py:73-81)
@@ -91,7 +107,9 @@ class ResNeXt(nn.Module):
     def forward(self, x):
         x = _stem_forward(self, x)
         for i in (1, 2, 3, 4):
-            x = getattr(self, "layer%d" % i)(x)
+            layer = getattr(self, "layer%d" % i)
+            layer[-1].materialize_output = i == 4        # the pooling below is not a convolution: fp32 copy wanted
+            x = layer(x)
         return self.fc(self.avgpool(x).flatten(1))
 
 
@@ -114,7 +132,11 @@ class ResNeXtEncoder(nn.Module):
         x = _stem_forward(self, x)
         maps = []
         for i in (1, 2, 3, 4):
-            x = getattr(self, "layer%d" % i)(x)
+            layer = getattr(self, "layer%d" % i)
+            # (fp16 storage: a stage output handed to the caller gets its fp32 copy; layer4's sole reader otherwise is
+            # the ASPP's convolutions, which take the fp16 part)
+            layer[-1].materialize_output = bool(return_feature_maps)
+            x = layer(x)
             maps.append(x)
         return maps if return_feature_maps else maps[-1:]
 

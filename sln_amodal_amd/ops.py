@@ -204,10 +204,15 @@ def grouped_conv3x3(x, weight, groups, stride=1, scale=None, shift=None, relu=Fa
     OH, OW = (H - 1) // stride + 1, (W - 1) // stride + 1
     y = torch.empty((N, OH, OW, C), dtype=torch.float32, device=x.device)
     w = weight.detach().contiguous()
+    from . import conv_hip                       # (the live per-launch profile of bench.py: the forward entries)
+    e0 = conv_hip._prof_begin()
     _lib.check(_lib.lib().sln_grouped_conv3x3_f32(_ptr(xc), N, H, W, C, int(groups), _ptr(w), int(stride),
                                                   _ptr(scale.detach().contiguous()) if scale is not None else None,
                                                   _ptr(shift.detach().contiguous()) if shift is not None else None,
                                                   1 if relu else 0, _ptr(y), _stream()), "sln_grouped_conv3x3_f32")
+    conv_hip._prof_end(e0, 2.0 * N * OH * OW * C * 9 * (C // groups), "grouped_conv3x3_kernel",
+                       "fwd grouped N%d %dx%d C%d g%d s%d" % (N, H, W, C, groups, stride),
+                       4 * (xc.numel() + w.numel()), 4 * y.numel())
     return y.permute(0, 3, 1, 2)
 
 

@@ -1,0 +1,255 @@
+"""BASELINE.json configs[4] in its stated form ("fp16 MFMA"): the single-part fp16 operand format (conv_hip.PARTS = 1:
+h = fp16(v * s), per-tensor power-of-two scale, one product per multiply-add, fp32 accumulate; csrc/conv.hip P = 1)
+and the grouped 3x3 on v_mfma_f32_16x16x32_f16 (csrc/grouped_conv.hip).
+
+The reference has no fp16 anywhere (its ResNeXt / MSC classes are fp32 dead code, modal/resnext.py:31-157,
+modal/msc_deeplab.py:13-48), so the tolerance is OURS and stated here: an fp16 operand carries 11 significand bits
+(relative rounding error <= 2^-12 = 2.4e-4 per element, independent between elements), so one layer's output differs from the
+fp64 result by ~3e-4 of its scale, a gradient by ~1e-3, and a 100-layer network's logits by ~1e-2 (errors add like a
+random walk over depth).  Held: 2e-3 (forward) / 5e-3 (gradients) per layer against fp64, 2e-2 on the reference-module
+fixture `module_resnext.npz`; the fp32-class path (PARTS = 2, 1e-4 on the same fixture) stays the checker."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+FWD_TOL, BWD_TOL = 2e-3, 5e-3
+
+
+@pytest.fixture(autouse=True)
+def _single_part(monkeypatch):
+    from sln_amodal_amd import conv_hip, nn_ops
+    monkeypatch.setattr(conv_hip, "PARTS", 1)
+    monkeypatch.setattr(nn_ops, "BACKEND", "hip")
+    yield
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-300))
+
+
+def test_single_part_is_the_rounded_scaled_fp16_value():
+    """act_split with parts = 1: one 16-bit word per element = fp16(v * s); (h / s) is v to 2^-11 relative for every
+    element within 2^-14 of the tensor's maximum, and exactly what torch's own fp16 cast of v * s gives."""
+    from sln_amodal_amd import conv_hip
+    g = torch.Generator(device="cuda").manual_seed(0)
+    x = (torch.randn(3, 40, 17, 19, device="cuda", generator=g) * 37.5).contiguous(memory_format=torch.channels_last)
+    owner = torch.nn.Parameter(torch.zeros(1, device="cuda"))
+    parts, q = conv_hip.act_parts(x, 1, owner=owner)
+    assert parts.shape == (1, 3 * 17 * 19, 40) and parts.dtype == torch.bfloat16
+    s = float(q)
+    assert s > 0 and np.log2(s) == round(np.log2(s))
+    amax = float(x.abs().max())
+    assert 2 ** 10 <= amax * s < 2 ** 11
+    want = (x.permute(0, 2, 3, 1).reshape(-1, 40) * s).to(torch.float16)
+    assert torch.equal(parts[0].view(torch.float16), want)
+    back = parts[0].view(torch.float16).float() / s
+    ref = x.permute(0, 2, 3, 1).reshape(-1, 40)
+    big = ref.abs() > amax * 2.0 ** -13
+    assert float(((back - ref).abs() / ref.abs().clamp_min(1e-30))[big].max()) <= 2.0 ** -11
+
+
+CASES = [
+    # Cin, Cout, k, stride, dil, pads, H, W, N
+    (64, 64, 1, 1, 1, (0, 0, 0, 0), 33, 29, 2),
+    (64, 256, 3, 1, 1, (1, 1, 1, 1), 40, 40, 2),
+    (256, 128, 1, 2, 1, (0, 0, 0, 0), 32, 32, 2),
+    (128, 128, 3, 1, 2, (2, 2, 2, 2), 31, 31, 1),
+    (256, 182, 3, 1, 12, (12, 12, 12, 12), 33, 33, 1),     # ASPP: Cout not a multiple of 8 (general epilogue)
+    (2048, 21, 3, 1, 6, (6, 6, 6, 6), 11, 11, 2),
+    (3, 64, 3, 2, 1, (1, 1, 1, 1), 65, 65, 2),             # ResNeXt stem (im2col path)
+]
+
+
+def _ref(x, w, b, scale, shift, res, relu, stride, dil, pads):
+    pt, pb, pl, pr = pads
+    y = F.conv2d(F.pad(x.double(), (pl, pr, pt, pb)), w.double(), None if b is None else b.double(), stride, 0, dil)
+    if scale is not None:
+        y = y * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
+    if res is not None:
+        y = y + res.double()
+    return F.relu(y) if relu else y
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_single_part_conv_forward_and_backward_against_fp64(case):
+    from sln_amodal_amd import nn_ops
+    Cin, Cout, k, stride, dil, pads, H, W, N = case
+    g = torch.Generator(device="cuda").manual_seed(Cin + 3 * Cout)
+    conv = torch.nn.Conv2d(Cin, Cout, k, stride, padding=(pads[0], pads[2]), dilation=dil, bias=True).cuda()
+    bn = torch.nn.BatchNorm2d(Cout).cuda().eval()
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, device="cuda", generator=g) / (Cin * k * k) ** 0.5)
+        conv.bias.copy_(torch.randn(Cout, device="cuda", generator=g) * 0.1)
+        bn.weight.copy_(torch.rand(Cout, device="cuda", generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(Cout, device="cuda", generator=g) * 0.1)
+        bn.running_var.copy_(torch.rand(Cout, device="cuda", generator=g) + 0.5)
+        bn.running_mean.copy_(torch.randn(Cout, device="cuda", generator=g) * 0.1)
+    for p in bn.parameters():
+        p.requires_grad = False
+    x = torch.randn(N, Cin, H, W, device="cuda", generator=g).contiguous(memory_format=torch.channels_last)
+    scale, shift = nn_ops.bn_affine(bn)
+    ref0 = _ref(x, conv.weight, conv.bias, scale, shift, None, False, stride, dil, pads)
+    res = torch.randn(ref0.shape, device="cuda", generator=g).contiguous(memory_format=torch.channels_last)
+    use_res = Cin >= 8
+    for step in range(2):          # (step 0 bootstraps every scale slot exactly, step 1 runs on delayed scales)
+        from sln_amodal_amd import conv_hip
+        conv_hip.update_scales()
+        xl = x.clone().requires_grad_(Cin >= 8)
+        rl = res.clone().requires_grad_(True) if use_res else None
+        conv.zero_grad(set_to_none=True)
+        y = nn_ops.conv_bn_act(xl, conv, bn, relu=True, residual=rl)
+        want = _ref(x, conv.weight, conv.bias, scale, shift, res if use_res else None, True, stride, dil, pads)
+        err = float((y.double() - want).abs().max() / want.abs().max())
+        assert err < FWD_TOL, (case, step, err)
+        up = torch.randn(y.shape, device="cuda", generator=g)
+        y.backward(up)
+        xr, wr, br = x.double().requires_grad_(True), conv.weight.detach().double().requires_grad_(True), \
+            conv.bias.detach().double().requires_grad_(True)
+        rr = res.double().requires_grad_(True)
+        pt, pb, pl, pr = pads
+        yr = F.conv2d(F.pad(xr, (pl, pr, pt, pb)), wr, br, stride, 0, dil) * scale.double().view(1, -1, 1, 1) + \
+            shift.double().view(1, -1, 1, 1)
+        if use_res:
+            yr = yr + rr
+        yr = yr * (y.detach() > 0)                 # the kernel's own ReLU pattern
+        yr.backward(up.double())
+        pairs = [("gw", conv.weight.grad, wr.grad), ("gb", conv.bias.grad, br.grad)]
+        if Cin >= 8:
+            pairs.append(("gx", xl.grad, xr.grad))
+        if use_res:
+            pairs.append(("gres", rl.grad, rr.grad))
+        for name, got, ref in pairs:
+            assert got is not None and got.shape == ref.shape, name
+            assert _rel(got, ref) < BWD_TOL, (case, step, name, _rel(got, ref))
+
+
+@pytest.mark.parametrize("cg", [4, 8, 16, 32])
+@pytest.mark.parametrize("stride", [1, 2])
+def test_grouped_mfma_forward_and_gradients_against_fp64(cg, stride):
+    """csrc/grouped_conv.hip on the matrix cores (reference modal/resnext.py:36: groups 32, padding 1, no bias; BN
+    affine + ReLU fused): forward, data gradient (same kernel, gradient mode) and MFMA weight gradient against the
+    unfused fp64 ops with the kernel's own ReLU pattern; odd sizes; the weight gradient bit-reproducible; both the fp32 +
+    fp16 output form and the fp16-only (parts-only) form."""
+    from sln_amodal_amd import conv_hip, nn_ops
+    G = 32
+    C = G * cg
+    g = torch.Generator(device="cuda").manual_seed(5 * cg + stride)
+    conv = torch.nn.Conv2d(C, C, 3, stride, 1, groups=G, bias=False).cuda()
+    bn = torch.nn.BatchNorm2d(C).cuda().eval()
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, device="cuda", generator=g) / (9 * cg) ** 0.5)
+        bn.weight.copy_(torch.rand(C, device="cuda", generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(C, device="cuda", generator=g) * 0.1)
+    for p in bn.parameters():
+        p.requires_grad = False
+    scale, shift = nn_ops.bn_affine(bn)
+    x = torch.randn(3, C, 21, 18, device="cuda", generator=g).contiguous(memory_format=torch.channels_last)
+    first = None
+    for step in range(3):
+        conv_hip.update_scales()
+        xl = x.clone().requires_grad_(True)
+        conv.zero_grad(set_to_none=True)
+        y = nn_ops.conv_bn_act(xl, conv, bn, relu=True, parts_only=(step == 2))
+        yv = conv_hip.materialize(y)
+        if step == 2:
+            assert conv_hip.parts_only_of(y) is not None       # no fp32 copy was written
+        want = F.relu(F.conv2d(x.double(), conv.weight.double(), None, stride, 1, 1, G) *
+                      scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1))
+        assert yv.shape == want.shape
+        err = float((yv.double() - want).abs().max() / want.abs().max())
+        assert err < FWD_TOL, (cg, stride, step, err)
+        up = torch.randn(want.shape, device="cuda", generator=torch.Generator(device="cuda").manual_seed(7))
+        y.backward(up)
+        xr, wr = x.double().requires_grad_(True), conv.weight.detach().double().requires_grad_(True)
+        yr = F.conv2d(xr, wr, None, stride, 1, 1, G) * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
+        (yr * (yv.detach() > 0)).backward(up.double())
+        assert _rel(xl.grad, xr.grad) < BWD_TOL, (cg, stride, step, "gx", _rel(xl.grad, xr.grad))
+        assert _rel(conv.weight.grad, wr.grad) < BWD_TOL, (cg, stride, step, "gw", _rel(conv.weight.grad, wr.grad))
+        if step == 1:
+            first = conv.weight.grad.clone()
+    # the same inputs and scales give the same bits (no atomics anywhere on the path)
+    conv_hip.update_scales()
+    grads = []
+    for _ in range(3):
+        xl = x.clone().requires_grad_(True)
+        conv.zero_grad(set_to_none=True)
+        nn_ops.conv_bn_act(xl, conv, bn, relu=True).backward(up)
+        grads.append((conv.weight.grad.clone(), xl.grad.clone()))
+    assert all(torch.equal(a[0], grads[0][0]) and torch.equal(a[1], grads[0][1]) for a in grads[1:])
+    assert first is not None
+
+
+def test_group_bottleneck_fp16_storage_against_aten():
+    """A GroupBottleneck (modal/resnext.py:31-66) in the fp16 format with fp16 STORAGE: from the second step on every
+    tensor inside the block and the block output exist as their fp16 part alone (PO_STATS counts them); output and every
+    gradient against the same block on aten fp32 within the fp16 bounds."""
+    from sln_amodal_amd import conv_hip, nn_ops
+    from sln_amodal_amd.modal.resnext import GroupBottleneck
+    from tests._util import key_init_
+    down = torch.nn.Sequential(torch.nn.Conv2d(128, 256, kernel_size=1, stride=2, bias=False), torch.nn.BatchNorm2d(256))
+    b0 = GroupBottleneck(128, 128, stride=2, groups=32, downsample=down).cuda().eval()
+    b1 = GroupBottleneck(256, 128, groups=32).cuda().eval()
+    head = torch.nn.Conv2d(256, 24, 3, padding=1).cuda()
+    for m in (b0, b1, head):
+        key_init_(m)
+    params = [p for m in (b0, b1, head) for n, p in m.named_parameters() if "bn" not in n and "downsample.1" not in n]
+    for m in (b0, b1):
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.weight.requires_grad = mod.bias.requires_grad = False
+    x = torch.randn(2, 128, 24, 24, device="cuda").contiguous(memory_format=torch.channels_last)
+
+    def run():
+        for p in params:
+            p.grad = None
+        xi = x.clone().requires_grad_(True)
+        y = nn_ops.conv_bn_act(b1(b0(xi)), head)          # the block output's readers: convolutions only
+        return xi, y
+
+    nn_ops.BACKEND = "torch"
+    xi, want = run()
+    up = torch.randn_like(want)
+    (want * up).sum().backward()
+    ref = [xi.grad.clone()] + [p.grad.clone() for p in params]
+    nn_ops.BACKEND = "hip"
+    for step in range(2):
+        conv_hip.update_scales()
+        po0 = conv_hip.PO_STATS[0]
+        xi, got = run()
+        (got * up).sum().backward()
+        made = conv_hip.PO_STATS[0] - po0
+        assert made == (0 if step == 0 else 7), made       # conv1, conv2, conv3 of both blocks + b0's downsample
+        assert _rel(got, want) < 4e-3, (step, _rel(got, want))
+        grads = [xi.grad] + [p.grad for p in params]
+        for i, (a, b) in enumerate(zip(grads, ref)):
+            assert a is not None and _rel(a, b) < 1e-2, (step, i, _rel(a, b))
+
+
+def test_resnext_encoder_and_msc_heads_match_the_reference_modules_in_fp16():
+    """tools/gen_golden_resnext.py's fixtures of the reference's own ResNeXt / GroupBottleneck / _ASPP / MSC classes at
+    the stated fp16 tolerance (2e-2 of each output's scale; the fp32-class path holds 1e-4 in tests/test_resnext_gpu.py),
+    on the first pass (every scale bootstrapped exactly, fp32 copies written) and on the second (delayed scales, the
+    tensors inside the stages as fp16 only)."""
+    from sln_amodal_amd import conv_hip
+    from tests._util import golden
+    from tests.test_resnext_cpu import build_encoder, build_msc
+    g = golden("module_resnext")
+    enc, msc = build_encoder(g, "cuda"), build_msc(g, "cuda")
+    x, xm = torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["xm"]).cuda()
+    for step in range(2):
+        conv_hip.update_scales()
+        po0 = conv_hip.PO_STATS[0]
+        with torch.no_grad():
+            outs = enc(x, return_feature_maps=True)
+            lg = msc(xm)
+        for i, o in enumerate(outs):
+            want = g["stage%d" % i]
+            err = np.abs(o.cpu().numpy() - want).max() / np.abs(want).max()
+            assert tuple(o.shape) == want.shape and err < 2e-2, (step, i, err)
+        want = g["msc_logits"]
+        err = np.abs(lg.cpu().numpy() - want).max() / np.abs(want).max()
+        assert tuple(lg.shape) == want.shape and err < 2e-2, (step, "logits", err)
+        print("fp16 pass %d: parts-only activations %d, logits err %.2e" % (step, conv_hip.PO_STATS[0] - po0, err))
