@@ -256,14 +256,22 @@ def main_resnext(args, rank, world, dev):
         fwd_flops[0] += 2.0 * y.numel() * (conv.in_channels // conv.groups) * kh * kw
         return y
     nn_ops.conv_bn_act = counting_cba
+    conv_hip.PROFILE = []
     try:
         with torch.no_grad():
             conv_hip.update_scales()
             outs = net(xs[0])
     finally:
         nn_ops.conv_bn_act = real_cba
+        prof_fwd, conv_hip.PROFILE = sum(e[2] for e in conv_hip.PROFILE), None
     if fwd_flops[0] <= 0:
         raise SystemExit("bench.py --config resnext: no convolution was counted")
+    # cross-check of the FLOP count: the per-launch profile of this forward-only pass -- every convolution
+    # kernel the library launched -- must add up to what the patched conv_bn_act counted: a convolution that reaches
+    # the kernels another way would be missing from step_roofline
+    if abs(prof_fwd - fwd_flops[0]) > 1e-6 * fwd_flops[0]:
+        raise SystemExit("bench.py --config resnext: counted %.6e forward FLOPs, the launches' profile says %.6e" %
+                         (fwd_flops[0], prof_fwd))
     oh = outs[0].shape[2]
     target = torch.randint(0, classes, (batch, oh, oh), device=dev, generator=g)
     params = [p for p in net.parameters() if p.requires_grad]
@@ -289,19 +297,15 @@ def main_resnext(args, rank, world, dev):
 
     for i in range(max(args.warmup, 2)):        # (>= 2: the first step bootstraps every operand scale exactly)
         step(i)
-    # cross-check of the FLOP count: one step under the live profile -- the forward entries of every
-    # convolution launch must add up to what the patched conv_bn_act counted
+    # one step under the live profile: every launch's algorithmic FLOPs (forward + data + weight gradients) next to
+    # the 3 x forward estimate below, and the activations that exist as their fp16 part alone
     conv_hip.PROFILE = []
     po0 = conv_hip.PO_STATS[0]
     step(0)
     torch.cuda.synchronize()
-    po_per_step = conv_hip.PO_STATS[0] - po0       # activations that exist as their fp16 part alone (fp16 storage)
-    prof_fwd = sum(e[2] for e in conv_hip.PROFILE if e[4].startswith("fwd"))
+    po_per_step = conv_hip.PO_STATS[0] - po0
     prof_all = sum(e[2] for e in conv_hip.PROFILE)
     conv_hip.PROFILE = None
-    if abs(prof_fwd - fwd_flops[0]) > 1e-6 * fwd_flops[0]:
-        raise SystemExit("bench.py --config resnext: counted %.6e forward FLOPs, the launches' profile says %.6e" %
-                         (fwd_flops[0], prof_fwd))
     if rank == 0:
         conv_hip.PROFILE = []
     barrier()

@@ -223,9 +223,14 @@ def test_group_bottleneck_fp16_storage_against_aten():
         made = conv_hip.PO_STATS[0] - po0
         assert made == (0 if step == 0 else 7), made       # conv1, conv2, conv3 of both blocks + b0's downsample
         assert _rel(got, want) < 4e-3, (step, _rel(got, want))
+        # Gradients against ATEN's (not against the kernel's own ReLU pattern, as the per-layer tests above do): the
+        # fp16 forward moves every pre-activation by ~5e-4 of its scale, so ~4e-4 of the units of each of the six
+        # ReLU layers fall on the other side of zero, and a gradient through them differs by ~sqrt(fraction switched)
+        # -- measured 2.1e-2 on the input gradient (gpurun_out/r5_b_f16_tests.log); 5e-2 is held.
         grads = [xi.grad] + [p.grad for p in params]
-        for i, (a, b) in enumerate(zip(grads, ref)):
-            assert a is not None and _rel(a, b) < 1e-2, (step, i, _rel(a, b))
+        errs = [(_rel(a, b) if a is not None else float("inf")) for a, b in zip(grads, ref)]
+        print("fp16 block, step %d: output %.2e, gradients %s" % (step, _rel(got, want), ["%.1e" % e for e in errs]))
+        assert max(errs) < 5e-2, (step, errs)
 
 
 def test_resnext_encoder_and_msc_heads_match_the_reference_modules_in_fp16():

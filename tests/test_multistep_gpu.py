@@ -142,7 +142,10 @@ def test_five_optimiser_steps_follow_the_reference_loop(scene):
             bad.append("step %d heads update" % k)
     # the control: worst step against worst step (floors: aten at rounding level)
     worst = lambda rows, key: max((r[key][0] if isinstance(r[key], tuple) else r[key]) for r in rows)
-    for key, floor in (("dl", 1e-4), ("dnorm", 2e-3), ("deep", 2e-2), ("rest", 2e-3)):
+    # floors: the largest worst-step error ATEN itself showed over the recorded runs of the two scenes -- its own
+    # distance from the reference moves by up to x 10 between runs behind the step-3 excursion (scene 1, worst loss
+    # difference: 1.2e-2 in one run, 1.4e-3 in the next; gpurun_out r5_a / r5_b)
+    for key, floor in (("dl", 2.3e-2), ("dnorm", 8.3e-3), ("deep", 0.14), ("rest", 9.2e-2)):
         hw, cw = worst(hip, key), worst(ctl, key)
         report.append("worst step, %s: hip %.2e aten %.2e (ratio %.2f)" % (key, hw, cw, hw / max(cw, 1e-30)))
         print(report[-1])
@@ -194,9 +197,9 @@ def test_ten_steps_hip_convolutions_against_aten_convolutions():
     1e-6 where the controls sit at their own perturbation.  (The first time this test ran, aten's two replicas had
     been given different MIOpen algorithms by a cold find cache: that accidental control tracked the HIP replica
     to three digits -- drift ratios 0.99 .. 1.22, profiles/r4_a_gpu_suite.log.)
-    Held: (a) the HIP forward pass is closer to aten's than the control's; (b) per step and group, update cosine
-    no more than max(0.003, a quarter of the control's own 1 - cosine) below the control's and weight drift at most
-    3 x the control's (+ 1e-6); (c) the six
+    Held: (a) the HIP forward pass is closer to aten's than the control's; (b) per step and group, the update's
+    decorrelation 1 - cosine at most 1.5 x the control's + 0.003 and weight drift at most 3 x the control's (+ 1e-6);
+    (c) the six
     losses within 1e-3 of aten's over the first four steps, then within max(2e-2, 5 x the control's largest loss
     difference so far) -- measured up to 1.0e-2 at step 9, where the control itself is 5.9e-3 off."""
     from sln_amodal_amd import conv_hip, nn_ops
@@ -263,7 +266,11 @@ def test_ten_steps_hip_convolutions_against_aten_convolutions():
         # the margin grows with the control's own decorrelation: by step 9 both replicas' updates have turned ~14 degrees
         # away from aten's (cosine 0.97) and two RUNS of this build differ by more than 0.003 there (profiles/
         # r4_flake2_run3.log: one group 0.003 + below the control at step 9 in one run of eight)
-        low = [grp for grp in GROUPS if cos[grp] < ccos[grp] - max(0.003, 0.25 * (1.0 - ccos[grp]))]
+        # (multiplicative in the decorrelation 1 - cos, which grows ~ x 1.5 per step for BOTH replicas: at step 9 the
+        # control's groups sit at 0.017 ... 0.028 and two RUNS of this build differ by 0.005 there -- r4_flake2_run3,
+        # r5_b_gpu_suite.log: fpn.C2 0.0218 against the control's 0.0168 -- so an additive 0.003 + a quarter was red
+        # one run in eight)
+        low = [grp for grp in GROUPS if (1.0 - cos[grp]) > 1.5 * (1.0 - ccos[grp]) + 0.003]
         if low:
             bad.append("step %d cosine %s" % (k, ["%s %.6f / %.6f" % (grp, cos[grp], ccos[grp]) for grp in low]))
         if any(drift[grp] > 3 * cdrift[grp] + 1e-6 for grp in GROUPS):
