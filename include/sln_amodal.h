@@ -458,9 +458,9 @@ typedef struct {
     float *q_amax;
     int32_t *q_saturated;
     int64_t s_o, s_i, s_kh, s_kw, total;
-    int32_t O, I, Ip, KH, KW, flip, layout, reserved;
+    int32_t O, I, Ip, KH, KW, flip, layout, reserved;   /* reserved: 1 = ONE scaled fp16 part (ABI 11), else two */
 } sln_split_desc_t;
-/* Every stale weight tensor of a step in one launch (parts = 2): chunk b covers elements
+/* Every stale weight tensor of a step in one launch (parts = 2, or 1 per entry): chunk b covers elements
  * [chunk_first[b], chunk_first[b] + chunk_elems) of entry chunk_entry[b]; all three arrays in device memory. */
 int sln_conv_split_weights_batch_f32(const sln_split_desc_t *descs, const int32_t *chunk_entry,
                                      const int64_t *chunk_first, int n_chunks, int chunk_elems,

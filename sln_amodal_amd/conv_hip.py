@@ -357,7 +357,7 @@ def _split_weights(weight, flip_swap=False, parts=None, owner=None, layout=ROWS)
     hit = cache.get((flip_swap, parts, layout))
     if hit is not None and hit[0] == weight._version:
         return hit[1], hit[2]
-    if hit is not None and parts == 2 and BATCH_WEIGHT_SPLITS and (id(weight), flip_swap, layout) in _WSPLIT:
+    if hit is not None and parts <= 2 and BATCH_WEIGHT_SPLITS and (id(weight), flip_swap, layout, parts) in _WSPLIT:
         # stale (the optimiser stepped): every stale registered entry is refreshed in one launch
         _refresh_weight_parts(weight.device)
         hit = cache.get((flip_swap, parts, layout))
@@ -388,8 +388,8 @@ def _split_weights(weight, flip_swap=False, parts=None, owner=None, layout=ROWS)
     launch(out)
     q = slot.scale if slot is not None else None
     cache[(flip_swap, parts, layout)] = (weight._version, out, q)
-    if parts == 2 and BATCH_WEIGHT_SPLITS and weight.requires_grad and weight.is_leaf:   # (Parameters: stable objects)
-        _register_weight_split(weight, flip_swap, layout, out, slot, (O, I, Ip, KH, KW, so, si, s[2], s[3]))
+    if parts <= 2 and BATCH_WEIGHT_SPLITS and weight.requires_grad and weight.is_leaf:   # (Parameters: stable objects)
+        _register_weight_split(weight, flip_swap, layout, out, slot, (O, I, Ip, KH, KW, so, si, s[2], s[3]), parts)
     return out, q
 
 
@@ -405,14 +405,17 @@ _DESC = np.dtype([("w", "<u8"), ("out", "<u8"), ("q_scale", "<u8"), ("q_amax", "
                   ("layout", "<i4"), ("reserved", "<i4")])     # == sln_split_desc_t
 
 
-def _register_weight_split(weight, flip, layout, out, slot, geom):
+def _register_weight_split(weight, flip, layout, out, slot, geom, parts=2):
     import weakref
     O, I, Ip, KH, KW, so, si, skh, skw = geom
-    total = out.numel() // 2
-    _WSPLIT[(id(weight), flip, layout)] = dict(ref=weakref.ref(weight), flip=flip, layout=layout, out=out, slot=slot,
-                                               desc=(weight.data_ptr(), out.data_ptr(), slot.scale.data_ptr(),
-                                                     slot.amax.data_ptr(), slot.sat.data_ptr(), so, si, skh,
-                                                     skw, total, O, I, Ip, KH, KW, 1 if flip else 0, layout, 0))
+    total = out.numel() // parts
+    # (the descriptor's last word: 1 = ONE scaled fp16 part, else two -- sln_split_desc_t.reserved, ABI 11)
+    _WSPLIT[(id(weight), flip, layout, parts)] = dict(ref=weakref.ref(weight), flip=flip, layout=layout, out=out,
+                                                      slot=slot, parts=parts,
+                                                      desc=(weight.data_ptr(), out.data_ptr(), slot.scale.data_ptr(),
+                                                            slot.amax.data_ptr(), slot.sat.data_ptr(), so, si, skh,
+                                                            skw, total, O, I, Ip, KH, KW, 1 if flip else 0, layout,
+                                                            1 if parts == 1 else 0))
     _WSPLIT_STATE["order"] = None        # the device table is rebuilt at the next refresh
 
 
@@ -435,7 +438,7 @@ def _refresh_weight_parts(device):
     for i, k in enumerate(st["order"]):
         e = _WSPLIT[k]
         wt = e["ref"]()
-        c = getattr(wt, "_sln_wparts", {}).get((e["flip"], 2, e["layout"]))
+        c = getattr(wt, "_sln_wparts", {}).get((e["flip"], e["parts"], e["layout"]))
         if c is not None and c[1] is e["out"] and c[0] != wt._version and not e["slot"].fresh:
             stale.append(i)
     if not stale:
@@ -457,7 +460,7 @@ def _refresh_weight_parts(device):
     for i in stale:
         e = _WSPLIT[st["order"][i]]
         wt = e["ref"]()
-        wt._sln_wparts[(e["flip"], 2, e["layout"])] = (wt._version, e["out"], e["slot"].scale)
+        wt._sln_wparts[(e["flip"], e["parts"], e["layout"])] = (wt._version, e["out"], e["slot"].scale)
     WSPLIT_STATS[0] += 1
     WSPLIT_STATS[1] += len(stale)
 

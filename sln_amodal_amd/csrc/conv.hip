@@ -704,9 +704,8 @@ __global__ __launch_bounds__(256) void split_weights_batch_kernel(const sln_spli
         float qv = v * qs;
         if (fabsf(qv) > SLN_F16_MAX) { qv = copysignf(SLN_F16_MAX, qv); sat = true; }
         const _Float16 h0 = (_Float16)qv;
-        const _Float16 h1 = (_Float16)(qv - (float)h0);
         out[dst0] = __builtin_bit_cast(__bf16, h0);
-        out[dst1] = __builtin_bit_cast(__bf16, h1);
+        if (d.reserved != 1) out[dst1] = __builtin_bit_cast(__bf16, (_Float16)(qv - (float)h0));   // (reserved = 1: ONE part, ABI 11)
     }
     amax_commit(amx, sat, q, s_word);
 }

@@ -56,10 +56,25 @@ class GroupBottleneck(nn.Module):
 
     def forward(self, x):
         po = _fp16_storage() and x.is_cuda
-        shortcut = x if self.downsample is None else \
-            nn_ops.conv_bn_act(x, self.downsample[0], self.downsample[1], parts_only=po)
-        h = _cba(_cba(x, self.conv1, self.bn1, parts_only=po), self.conv2, self.bn2, parts_only=po)
-        return _cba(h, self.conv3, self.bn3, residual=shortcut, parts_only=po and not self.materialize_output)
+        conv = nn_ops.conv_bn_act
+        # the backward fusions of modal.modals.Bottleneck (conv_hip._ConvFn): an identity shortcut's gradient is added
+        # inside conv1's data-gradient epilogue (`link`) instead of by an autograd accumulation pass, and the block
+        # output's gradient preparation (ReLU mask, BN scale -> operand parts) is done by the next identity block's
+        # conv1 data gradient (`chain`): inside a stage that conv1 -- with its shortcut through `link` -- is the
+        # output's only reader.  (conv1 -> grouped conv2 -> conv3 are not chained: the grouped kernels prepare their
+        # own gradient.)
+        shortcut, link = x, {}
+        if self.downsample is not None:
+            shortcut, link = conv(x, self.downsample[0], self.downsample[1], parts_only=po), None
+        cx_in = getattr(x, "_sln_chain", None) if link is not None else None
+        cx_out = {}
+        h = conv(x, self.conv1, self.bn1, relu=True, link=link, chain_in=cx_in, parts_only=po)
+        h = conv(h, self.conv2, self.bn2, relu=True, parts_only=po)
+        out = conv(h, self.conv3, self.bn3, relu=True, residual=shortcut, link=link, chain_out=cx_out,
+                   parts_only=po and not self.materialize_output)
+        if cx_out.get("active"):
+            out._sln_chain = cx_out
+        return out
 
 
 _STEM = ((3, 64, 2), (64, 64, 1), (64, 128, 1))                  # three 3x3 convolutions (modal/resnext.py:73-81)
