@@ -369,7 +369,7 @@ def main():
     ap.add_argument("--dim", type=int, default=None, help="image edge (default: 1024 for sln, 321 for resnext)")
     ap.add_argument("--arch", default="resnet101")
     ap.add_argument("--stage", default="all", choices=["all", "heads"])
-    ap.add_argument("--settle", type=int, default=8,
+    ap.add_argument("--settle", type=int, default=16,
                     help="untimed set-up train steps that seed the operand-scale window (see conv_saturated_blocks)")
     ap.add_argument("--data", default="synthetic", choices=["synthetic", "files"],
                     help="synthetic: two device-resident batches (BASELINE.json's metric).  files: --files generated jpg + "

@@ -417,6 +417,7 @@ def main(argv=None):
                 n += 1
             if n >= limit:
                 break
+    data.close()
 
 
 if __name__ == "__main__":

@@ -787,14 +787,14 @@ struct ConvParams {
 template <int P>
 __device__ __forceinline__ void mfma_products(const bf16x8 (&a)[P], const bf16x8 (&b)[P], f32x16 &c) {
     // smallest terms first
-    if (P == 3) {
+    if constexpr (P == 3) {
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], c, 0, 0, 0);
-    } else if (P == 1) {   // one scaled fp16 part per operand: one product
+    } else if constexpr (P == 1) {   // one scaled fp16 part per operand: one product
         c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a[0]), __builtin_bit_cast(h16x8, b[0]), c,
                                                    0, 0, 0);
     } else {   // two fp16 parts: the same 16-bit containers, the f16 matrix instruction
@@ -1855,6 +1855,17 @@ __device__ __forceinline__ void mfma16_products_t(const bf16x8 (&x)[2], const bf
     c = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0, x0, c, 0, 0, 0);
 }
 
+// MEASURED AND SWITCHED OFF (profiles/r5_e_ab_register_epilogue.txt, same box, 16 x 1024^2 train step): bit-identical
+// to the LDS-staged slabs on all three kernels (tests/test_conv_gpu.py, 288 cases) but not faster -- the plain 256^2
+// instances +0.04 %, the tap-row instances -0.7 %, the 128 x 256 kernel -14 % on its own launches (204 -> 175 TFLOP/s,
+// -1.6 % on the step): a store or load instruction of this layout touches 16 pixels x 64 B (a part) or 16 half-filled
+// lines (fp32) where the staged slabs touch 8 whole 128-B lines per instruction, which costs what the eight barriers
+// and the LDS round trip cost; and the 128 x 256 kernel already hides its staged epilogue under the other resident
+// block's k-loop.  The instances are compiled only with -DSLN_BUILD_DIRECT=1 (then SLN_CONV_DIRECT = 1 | 2 | 4 selects
+// the 128 x 256 / plain / tap-row instances).
+#ifndef SLN_BUILD_DIRECT
+#define SLN_BUILD_DIRECT 0
+#endif
 // Register epilogue (round 5): the eight-channel tile epilogue WITHOUT the LDS staging.  The LDS-staged epilogues
 // exist because the C layout of v_mfma_f32_16x16x32_f16 hands a lane four consecutive ROWS of one column; staging a
 // 256 x 256 tile through LDS behind eight barriers is 26 % of a K = 256 pointwise launch (profiles/
@@ -4042,9 +4053,13 @@ extern "C" int sln_conv2d_fwd_ms_f32(const uint16_t *x_parts, int nseg, const in
                     const dim3 g1((unsigned)(gm1 * gn2)), b1(256);
                     sln_last_fwd_kernel = 3;
                     // the register epilogue (epilogue_direct; SLN_CONV_DIRECT=0: the LDS-staged slabs, A/B)
-                    const bool direct = (sln_knob("SLN_CONV_DIRECT", 7) & 1) != 0 && !(p.dbg & (8192 | 16384 | 131072));
+                    const bool direct = (sln_knob("SLN_CONV_DIRECT", 0) & 1) != 0 && !(p.dbg & (8192 | 16384 | 131072));
+#if SLN_BUILD_DIRECT
 #define SLN_L128(E) do { if (direct) hipLaunchKernelGGL((conv_fwd128x256h_kernel<E, true>), g1, b1, 0, (hipStream_t)stream, p); \
                          else hipLaunchKernelGGL((conv_fwd128x256h_kernel<E, false>), g1, b1, 0, (hipStream_t)stream, p); } while (0)
+#else
+#define SLN_L128(E) do { (void)direct; hipLaunchKernelGGL((conv_fwd128x256h_kernel<E, false>), g1, b1, 0, (hipStream_t)stream, p); } while (0)
+#endif
                     if (p.res_parts) SLN_L128(2);
                     else if (p.residual && p.mask_part0) SLN_L128(4);
                     else if (p.residual) SLN_L128(5);
@@ -4067,9 +4082,13 @@ extern "C" int sln_conv2d_fwd_ms_f32(const uint16_t *x_parts, int nseg, const in
                 p.tapmode = row ? 1 : colm ? 2 : 0;
                 // the register epilogue (epilogue_direct): SLN_CONV_DIRECT bit 0 the 128 x 256 kernel (above), bit 1 the
                 // plain 256^2 instances, bit 2 the tap-row instances (default 7: all; 0: the LDS-staged slabs, A/B)
-                const int dk = (p.dbg & (8192 | 16384 | 131072)) ? 0 : sln_knob("SLN_CONV_DIRECT", 7);
+                const int dk = (p.dbg & (8192 | 16384 | 131072)) ? 0 : sln_knob("SLN_CONV_DIRECT", 0);
+#if SLN_BUILD_DIRECT
 #define SLN_L256(E, R) do { if (dk & ((R) ? 4 : 2)) hipLaunchKernelGGL((conv_fwd256h_kernel<false, 2, 16, E, R, true>), g2, b2, 0, (hipStream_t)stream, p); \
                             else hipLaunchKernelGGL((conv_fwd256h_kernel<false, 2, 16, E, R, false>), g2, b2, 0, (hipStream_t)stream, p); } while (0)
+#else
+#define SLN_L256(E, R) do { (void)dk; hipLaunchKernelGGL((conv_fwd256h_kernel<false, 2, 16, E, R, false>), g2, b2, 0, (hipStream_t)stream, p); } while (0)
+#endif
                 if (row || colm) {
                     sln_last_fwd_kernel = 4;
                     if (!w8) hipLaunchKernelGGL((conv_fwd256h_kernel<false, 2, 16, 0, true>), g2, b2, 0, (hipStream_t)stream, p);

@@ -181,6 +181,8 @@ class PrefetchLoader(object):
                                                        self._done_q), daemon=True)
             p.start()
             self._procs.append(p)
+        import atexit
+        atexit.register(self.close)          # (the shared-memory segments live in /dev/shm: never left behind)
         return self
 
     def close(self):

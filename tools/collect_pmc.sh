@@ -10,7 +10,7 @@ out=$root/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE MfmaUtil MfmaFlopsF16; do
     rm -rf /tmp/pmc_$c
-    rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -- python3 $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-strict > $out/${tag}_pmc_${c}_bench.json 2> /tmp/pmc_$c.err
+    rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -- python3 $root/bench.py --steps 2 --warmup 1 --settle 2 --no-cpu-baseline --no-strict > $out/${tag}_pmc_${c}_bench.json 2> /tmp/pmc_$c.err
     echo "pass $c rc=$?" >> $out/${tag}_pmc_passes.txt
 done
 cd $root
