@@ -241,7 +241,9 @@ int sln_grouped_conv3x3_wgrad_f32(const float *x, const float *gy, const float *
  *   out NULL: only the tensor's amax is recorded (first use of its scale slot).
  * sln_grouped_conv3x3_f16: mode 0 forward, x16 [N,H,W,C] -> y fp32 and / or y16 scaled fp16 [N,OH,OW,C] (+ its running
  *   amax / clamp count); mode 1 data gradient, x16 = the PREPARED gradient [N,OH,OW,C] (ReLU mask and BN scale applied:
- *   sln_conv_grad_prep_f32 with parts = 1), w_packed packed with flip = 1 -> y = gx [N,H,W,C] fp32.
+ *   sln_conv_grad_prep_f32 with parts = 1), w_packed packed with flip = 1 -> y = gx [N,H,W,C] fp32 and / or y16 = the
+ *   prepared gradient of the layer BELOW: (mask16 > 0 ? gx : 0) * post_scale[c] as a scaled fp16 part (mask16 = that
+ *   layer's output part, post_scale = its BN scale; both NULL in mode 0).
  * sln_grouped_conv3x3_wgrad_f16: gw fp32 [C][C/groups][3][3] from the prepared gradient and the layer's input parts;
  *   workspace as for the fp32 entry point (per-range partial sums + ordered reduce: bit-reproducible). */
 int64_t sln_grouped_conv3x3_packed_weight_elems(int C, int groups);
@@ -250,7 +252,8 @@ int sln_grouped_conv3x3_pack_weights_f16(const float *w, int C, int groups, int 
 int sln_grouped_conv3x3_f16(const uint16_t *x16, int N, int H, int W, int C, int groups, const uint16_t *w_packed,
                             int stride, int mode, const float *scale, const float *shift, int relu, float *y,
                             uint16_t *y16, const float *x_scale, const float *w_scale, const float *y_q_scale,
-                            float *y_q_amax, int32_t *y_q_saturated, sln_stream_t stream);
+                            float *y_q_amax, int32_t *y_q_saturated, const uint16_t *mask16, const float *post_scale,
+                            sln_stream_t stream);
 int sln_grouped_conv3x3_wgrad_f16(const uint16_t *x16, const uint16_t *gz16, int N, int H, int W, int C, int groups,
                                   int stride, const float *gz_scale, const float *x_scale, float *gw, void *workspace,
                                   size_t workspace_bytes, sln_stream_t stream);

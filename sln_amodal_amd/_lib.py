@@ -75,7 +75,7 @@ SIGNATURES = {
     "sln_grouped_conv3x3_wgrad_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, C.c_size_t, _p]),
     "sln_grouped_conv3x3_packed_weight_elems": (C.c_int64, [_i, _i]),
     "sln_grouped_conv3x3_pack_weights_f16": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p]),
-    "sln_grouped_conv3x3_f16": (_i, [_p, _i, _i, _i, _i, _i, _p, _i, _i, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "sln_grouped_conv3x3_f16": (_i, [_p, _i, _i, _i, _i, _i, _p, _i, _i, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "sln_grouped_conv3x3_wgrad_f16": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, C.c_size_t, _p]),
     "sln_msc_softmax_tail_f32": (_i, [_p, C.c_int64, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p]),
     "sln_conv_grad_prep_pooled_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p]),

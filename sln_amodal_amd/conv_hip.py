@@ -1519,7 +1519,7 @@ class _GroupedF16Fn(torch.autograd.Function):
     gradient (per-range partial sums + ordered reduce: bit-reproducible)."""
 
     @staticmethod
-    def forward(ctx, x, weight, scale, shift, relu, groups, stride, parts_only):
+    def forward(ctx, x, weight, scale, shift, relu, groups, stride, parts_only, chain_in=None, chain_out=None):
         N, C, H, W = x.shape
         OH, OW = (H - 1) // stride + 1, (W - 1) // stride + 1
         xp, xq = act_parts(x, 1, owner=weight)
@@ -1536,7 +1536,7 @@ class _GroupedF16Fn(torch.autograd.Function):
         _lib.check(_lib.lib().sln_grouped_conv3x3_f16(
             ops._ptr(xp), N, H, W, C, groups, ops._ptr(wpk), stride, 0, ops._ptr(sc), ops._ptr(sf), 1 if relu else 0,
             ops._ptr(y), ops._ptr(yp), ops._ptr(xq), ops._ptr(wq), *_q3(yslot if yp is not None else None),
-            ops._stream()), "sln_grouped_conv3x3_f16")
+            None, None, ops._stream()), "sln_grouped_conv3x3_f16")
         _prof_end(e0, 2.0 * N * OH * OW * C * 9 * (C // groups), "grouped_mfma_kernel",
                   "fwd grouped N%d %dx%d C%d g%d s%d" % (N, H, W, C, groups, stride), _nbytes(xp, wpk), _nbytes(y, yp))
         if fresh:          # first use of the output's slot: exact amax pass over the fp32 output, then the split
@@ -1547,8 +1547,29 @@ class _GroupedF16Fn(torch.autograd.Function):
             PO_STATS[0] += 1
         y._sln_parts = ((y._version, 1, SCALE_EPOCH[0]), yp, yslot.scale)
         need_w = ctx.needs_input_grad[1]
+        # chained gradient preparation, as in _ConvFn.  PRODUCER side (chain_out: this output's ONLY reader is a
+        # convolution -- the block's conv3): that reader's data-gradient epilogue writes this layer's prepared
+        # gradient (ReLU mask, BN scale -> fp16 part) and hands it over; no fp32 gradient of this output, no
+        # sln_conv_grad_prep_f32 launch.  From the second step on (the gradient's scale slot needs a history).
+        ctx.chain_out = ctx.chain_in = None
+        if CHAIN_GRAD_PREP and chain_out is not None and (ctx.needs_input_grad[0] or need_w) and not gzslot.fresh:
+            chain_out.update(active=True, scale=sc, relu=bool(relu), parts=1, with_res=False, want_bias=False,
+                             gz_slot=gzslot)
+            chain_out.setdefault("readers", 1)
+            ctx.chain_out = chain_out if chain_out["readers"] == 1 else None
+            if ctx.chain_out is None:
+                chain_out["active"] = False
+        # READER side (chain_in: the layer below -- the block's conv1 -- has this convolution as its only reader):
+        # the data-gradient kernel's epilogue prepares THAT layer's gradient (its ReLU pattern = the sign of the input
+        # part this layer read, its BN scale as post_scale)
+        if CHAIN_GRAD_PREP and chain_in is not None and chain_in.get("active") and ctx.needs_input_grad[0] and \
+                chain_in["parts"] == 1 and not chain_in["with_res"] and chain_in.get("readers", 1) == 1 and \
+                not chain_in.get("want_bias"):
+            chain_in["consumer"] = chain_in.get("consumer", 0) + 1
+            ctx.chain_in = chain_in
+        mask_x = xp if (ctx.chain_in is not None and chain_in["relu"]) else None
         ctx.save_for_backward(xp if need_w else None, weight, sc, (yp if po else y) if relu else None,
-                              xq if need_w else None)
+                              xq if need_w else None, mask_x)
         ctx.cfg = (bool(relu), int(groups), int(stride), (N, C, H, W), (OH, OW))
         ctx.gzslot = gzslot
         ctx.scale_epoch = SCALE_EPOCH[0]
@@ -1556,23 +1577,49 @@ class _GroupedF16Fn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy):
-        xp, weight, sc, y, xq = ctx.saved_tensors
+        xp, weight, sc, y, xq, mask_x = ctx.saved_tensors
         relu, groups, stride, (N, C, H, W), (OH, OW) = ctx.cfg
         _check_epoch(ctx, 1)
-        gz, _, _ = _grad_prep(gy, y if relu else None, sc, False, False, 1, slot=ctx.gzslot)
-        gzq = ctx.gzslot.scale
+        ch = ctx.chain_out
+        if ch is not None and ch.get("consumer") and "gz" in ch:
+            # the reader prepared this layer's gradient: what arrives must be its zero-stride placeholder -- anything
+            # else means the output had a second consumer whose share the handed-over part does not contain
+            if gy.stride() != (0, 0, 0, 0):
+                raise RuntimeError("chained gradient (grouped 3x3): the output has a second consumer")
+            gz, gzq = ch.pop("gz"), ch.pop("gzq", None)
+            ch.pop("gbias", None)
+            CHAIN_STATS[1] += 1
+        else:
+            if ch is not None and ch.get("consumer"):
+                raise RuntimeError("chained gradient (grouped 3x3): the reader's data gradient did not run")
+            gz, _, _ = _grad_prep(gy, y if relu else None, sc, False, False, 1, slot=ctx.gzslot)
+            gzq = ctx.gzslot.scale
         gx = gw = None
         L = _lib.lib()
         if ctx.needs_input_grad[0]:
             wpk, wq = _pack_grouped(weight, groups, True)
-            gxb = torch.empty((N, H, W, C), dtype=torch.float32, device=gz.device)
+            ci = ctx.chain_in
             e0 = _prof_begin()
-            _lib.check(L.sln_grouped_conv3x3_f16(ops._ptr(gz), N, H, W, C, groups, ops._ptr(wpk), stride, 1, None, None,
-                                                 0, ops._ptr(gxb), None, ops._ptr(gzq), ops._ptr(wq), None, None, None,
-                                                 ops._stream()), "sln_grouped_conv3x3_f16")
+            if ci is not None:
+                # the layer below gets its PREPARED gradient from this kernel's epilogue; autograd gets a placeholder
+                gz_up = torch.empty((1, N * H * W, C), dtype=torch.bfloat16, device=gz.device)
+                _lib.check(L.sln_grouped_conv3x3_f16(ops._ptr(gz), N, H, W, C, groups, ops._ptr(wpk), stride, 1, None,
+                                                     None, 0, None, ops._ptr(gz_up), ops._ptr(gzq), ops._ptr(wq),
+                                                     *_q3(ci["gz_slot"]), ops._ptr(mask_x), ops._ptr(ci["scale"]),
+                                                     ops._stream()), "sln_grouped_conv3x3_f16")
+                ci["gz"], ci["gbias"], ci["gzq"] = gz_up, None, ci["gz_slot"].scale
+                gx = _dummy_grad(gz.device).expand(N, C, H, W)
+                CHAIN_STATS[0] += 1
+                wrote = gz_up
+            else:
+                gxb = torch.empty((N, H, W, C), dtype=torch.float32, device=gz.device)
+                _lib.check(L.sln_grouped_conv3x3_f16(ops._ptr(gz), N, H, W, C, groups, ops._ptr(wpk), stride, 1, None,
+                                                     None, 0, ops._ptr(gxb), None, ops._ptr(gzq), ops._ptr(wq), None,
+                                                     None, None, None, None, ops._stream()), "sln_grouped_conv3x3_f16")
+                gx = gxb.permute(0, 3, 1, 2)
+                wrote = gxb
             _prof_end(e0, 2.0 * N * OH * OW * C * 9 * (C // groups), "grouped_mfma_kernel",
-                      "dgrad grouped N%d %dx%d C%d g%d s%d" % (N, H, W, C, groups, stride), _nbytes(gz, wpk), _nbytes(gxb))
-            gx = gxb.permute(0, 3, 1, 2)
+                      "dgrad grouped N%d %dx%d C%d g%d s%d" % (N, H, W, C, groups, stride), _nbytes(gz, wpk), _nbytes(wrote))
         if ctx.needs_input_grad[1]:
             gw = torch.empty_like(weight)
             nbytes = L.sln_grouped_conv3x3_wgrad_workspace_bytes(N, H, W, C, groups, stride)
@@ -1583,7 +1630,7 @@ class _GroupedF16Fn(torch.autograd.Function):
                                                        ops._stream()), "sln_grouped_conv3x3_wgrad_f16")
             _prof_end(e0, 2.0 * N * OH * OW * C * 9 * (C // groups), "grouped_wgrad_mfma_kernel",
                       "wgrad grouped N%d %dx%d C%d g%d s%d" % (N, H, W, C, groups, stride), _nbytes(gz, xp), _nbytes(gw))
-        return gx, gw, None, None, None, None, None, None
+        return gx, gw, None, None, None, None, None, None, None, None
 
 
 def grouped_supported(conv, x):
@@ -1592,8 +1639,9 @@ def grouped_supported(conv, x):
             conv.in_channels % 64 == 0 and (conv.in_channels // conv.groups) in (4, 8, 16, 32))
 
 
-def grouped_conv_bn_act(x, conv, scale, shift, relu, parts_only=False):
-    return _GroupedF16Fn.apply(x, conv.weight, scale, shift, bool(relu), conv.groups, conv.stride[0], bool(parts_only))
+def grouped_conv_bn_act(x, conv, scale, shift, relu, parts_only=False, chain_in=None, chain_out=None):
+    return _GroupedF16Fn.apply(x, conv.weight, scale, shift, bool(relu), conv.groups, conv.stride[0], bool(parts_only),
+                               chain_in, chain_out)
 
 
 def is_stem(conv, x):

@@ -319,6 +319,11 @@ struct GroupedParams {
     const float *x_scale, *w_scale, *yq_scale;
     float *yq_amax;
     int32_t *yq_sat;
+    // MODE 1 only: the data gradient handed on as the PREPARED gradient of the layer below (chained gradient
+    // preparation, conv_hip._GroupedF16Fn): zero where that layer's ReLU was off (mask16 = its output's fp16 part,
+    // sign test), times its BN scale (post_scale), stored as a scaled fp16 part (y16) with the running amax
+    const _Float16 *mask16;
+    const float *post_scale;
     int N, H, W, C, stride, OH, OW, relu;
     long M;                   // produced pixels
 };
@@ -357,12 +362,16 @@ __global__ __launch_bounds__(256) void grouped_mfma_kernel(const GroupedParams p
     const float yqs = p.yq_scale ? *p.yq_scale : 1.f;
     const int cq = c0 + 4 * q;                    // the four channels this lane holds of every output pixel
     float sc[4] = {alpha, alpha, alpha, alpha}, sf[4] = {0.f, 0.f, 0.f, 0.f};
+    float ps[4] = {1.f, 1.f, 1.f, 1.f};
     if (MODE == 0) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             if (p.scale) sc[r] = p.scale[cq + r] * alpha;
             if (p.shift) sf[r] = p.shift[cq + r];
         }
+    } else if (p.post_scale) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ps[r] = p.post_scale[cq + r];
     }
     const int PH = MODE == 0 ? p.OH : p.H, PW = MODE == 0 ? p.OW : p.W;      // produced grid
     const int QH = MODE == 0 ? p.H : p.OH, QW = MODE == 0 ? p.W : p.OW;      // grid that is read
@@ -403,9 +412,19 @@ __global__ __launch_bounds__(256) void grouped_mfma_kernel(const GroupedParams p
             v[r] = acc[r] * sc[r] + sf[r];
             if (MODE == 0 && p.relu) v[r] = fmaxf(v[r], 0.f);
         }
+        if (MODE == 1 && pok && p.mask16) {
+            const gh16x4 mk = *(const gh16x4 *)(p.mask16 + pix * p.C + cq);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (!(mk[r] > (_Float16)0)) v[r] = 0.f;
+        }
         if (pok) {
             if (p.y) *(float4 *)(p.y + pix * p.C + cq) = make_float4(v[0], v[1], v[2], v[3]);
-            if (MODE == 0 && p.y16) {
+            if (MODE == 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = v[r] * ps[r];
+            }
+            if (p.y16) {
                 gh16x4 h;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -418,7 +437,7 @@ __global__ __launch_bounds__(256) void grouped_mfma_kernel(const GroupedParams p
             }
         }
     }
-    if (MODE == 0 && p.y16) g_amax_commit(amx, sat, p.yq_amax, p.yq_sat, s_word);
+    if (p.y16) g_amax_commit(amx, sat, p.yq_amax, p.yq_sat, s_word);
 }
 
 // Weights fp32 [C][CG][3][3] (the parameter) -> fragment-ordered scaled fp16 [C/16][NM][64][8] (+ the tensor's amax).
@@ -564,12 +583,14 @@ extern "C" int sln_grouped_conv3x3_pack_weights_f16(const float *w, int C, int g
 
 // mode 0: forward, x16 [N,H,W,C] -> y / y16 [N,OH,OW,C] = relu?(conv * scale + shift); mode 1: data gradient, x16 =
 // the prepared gradient [N,OH,OW,C] (ReLU mask and BN scale already applied: sln_conv_grad_prep_f32, parts = 1),
-// w_packed packed with flip = 1 -> y = gx [N,H,W,C] fp32 (y16 must be NULL).
+// w_packed packed with flip = 1 -> y = gx [N,H,W,C] fp32 and / or y16 = the prepared gradient of the layer below
+// ((mask16 > 0 ? gx : 0) * post_scale[c] as a scaled fp16 part with its amax: chained gradient preparation).
 extern "C" int sln_grouped_conv3x3_f16(const uint16_t *x16, int N, int H, int W, int C, int groups,
                                        const uint16_t *w_packed, int stride, int mode, const float *scale,
                                        const float *shift, int relu, float *y, uint16_t *y16, const float *x_scale,
                                        const float *w_scale, const float *y_q_scale, float *y_q_amax,
-                                       int32_t *y_q_saturated, sln_stream_t stream) {
+                                       int32_t *y_q_saturated, const uint16_t *mask16, const float *post_scale,
+                                       sln_stream_t stream) {
     sln_enter();
     if (N < 0 || H < 1 || W < 1 || C < 64 || groups < 1 || C % groups || C % 64 || stride < 1 || stride > 2 ||
         (mode != 0 && mode != 1))
@@ -577,12 +598,13 @@ extern "C" int sln_grouped_conv3x3_f16(const uint16_t *x16, int N, int H, int W,
     const int cg = C / groups;
     if (cg != 4 && cg != 8 && cg != 16 && cg != 32) return SLN_ERR_UNSUPPORTED;
     if (N == 0) return SLN_OK;
-    if (!x16 || !w_packed || (!y && !y16) || (mode == 1 && (y16 || !y))) return SLN_ERR_INVALID_ARG;
-    if ((((size_t)x16) | ((size_t)y) | ((size_t)y16) | ((size_t)w_packed)) & 15) return SLN_ERR_INVALID_ARG;
+    if (!x16 || !w_packed || (!y && !y16) || (mode == 0 && (mask16 || post_scale))) return SLN_ERR_INVALID_ARG;
+    if ((((size_t)x16) | ((size_t)y) | ((size_t)y16) | ((size_t)w_packed) | ((size_t)mask16)) & 15) return SLN_ERR_INVALID_ARG;
     GroupedParams p;
     p.x = (const _Float16 *)x16; p.wpk = (const _Float16 *)w_packed; p.scale = scale; p.shift = shift;
     p.y = y; p.y16 = (_Float16 *)y16; p.x_scale = x_scale; p.w_scale = w_scale; p.yq_scale = y_q_scale;
     p.yq_amax = y_q_amax; p.yq_sat = y_q_saturated;
+    p.mask16 = (const _Float16 *)mask16; p.post_scale = post_scale;
     p.N = N; p.H = H; p.W = W; p.C = C; p.stride = stride; p.relu = relu;
     p.OH = (H + 2 - 3) / stride + 1; p.OW = (W + 2 - 3) / stride + 1;
     p.M = mode == 0 ? (long)N * p.OH * p.OW : (long)N * H * W;

@@ -61,16 +61,17 @@ class GroupBottleneck(nn.Module):
         # inside conv1's data-gradient epilogue (`link`) instead of by an autograd accumulation pass, and the block
         # output's gradient preparation (ReLU mask, BN scale -> operand parts) is done by the next identity block's
         # conv1 data gradient (`chain`): inside a stage that conv1 -- with its shortcut through `link` -- is the
-        # output's only reader.  (conv1 -> grouped conv2 -> conv3 are not chained: the grouped kernels prepare their
-        # own gradient.)
+        # output's only reader.  Inside the block conv1 -> grouped conv2 -> conv3 chain the same way on the fp16 path
+        # (conv_hip._GroupedF16Fn is both a reader and a producer of the protocol; ignored on the fp32 grouped kernels).
         shortcut, link = x, {}
         if self.downsample is not None:
             shortcut, link = conv(x, self.downsample[0], self.downsample[1], parts_only=po), None
         cx_in = getattr(x, "_sln_chain", None) if link is not None else None
         cx_out = {}
-        h = conv(x, self.conv1, self.bn1, relu=True, link=link, chain_in=cx_in, parts_only=po)
-        h = conv(h, self.conv2, self.bn2, relu=True, parts_only=po)
-        out = conv(h, self.conv3, self.bn3, relu=True, residual=shortcut, link=link, chain_out=cx_out,
+        c12, c23 = ({}, {}) if po else (None, None)
+        h = conv(x, self.conv1, self.bn1, relu=True, link=link, chain_in=cx_in, chain_out=c12, parts_only=po)
+        h = conv(h, self.conv2, self.bn2, relu=True, chain_in=c12, chain_out=c23, parts_only=po)
+        out = conv(h, self.conv3, self.bn3, relu=True, residual=shortcut, link=link, chain_in=c23, chain_out=cx_out,
                    parts_only=po and not self.materialize_output)
         if cx_out.get("active"):
             out._sln_chain = cx_out

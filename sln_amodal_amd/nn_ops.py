@@ -143,7 +143,8 @@ def conv_bn_act(x, conv, bn=None, relu=False, residual=None, same=False, link=No
                 raise RuntimeError("grouped 3x3 convolution: the HIP path takes a FROZEN BatchNorm (as the whole hot "
                                    "path does); set nn_ops.BACKEND = 'torch' to train the normalisation on aten")
         if hip.grouped_supported(conv, x):          # conv_hip.PARTS = 1: the fp16 MFMA kernels (configs[4] as stated)
-            return hip.grouped_conv_bn_act(x, conv, scale, shift, relu, parts_only=parts_only and PARTS_ONLY)
+            return hip.grouped_conv_bn_act(x, conv, scale, shift, relu, parts_only=parts_only and PARTS_ONLY,
+                                           chain_in=chain_in, chain_out=chain_out)
         if getattr(x, "_sln_po", None) is not None:
             raise RuntimeError("grouped 3x3 (fp32 direct kernels): the input exists as parts only; its producer must "
                                "not be asked for parts_only outside conv_hip.PARTS = 1")

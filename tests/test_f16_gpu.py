@@ -217,11 +217,16 @@ def test_group_bottleneck_fp16_storage_against_aten():
     nn_ops.BACKEND = "hip"
     for step in range(2):
         conv_hip.update_scales()
-        po0 = conv_hip.PO_STATS[0]
+        po0, ch0 = conv_hip.PO_STATS[0], list(conv_hip.CHAIN_STATS)
         xi, got = run()
         (got * up).sum().backward()
         made = conv_hip.PO_STATS[0] - po0
         assert made == (0 if step == 0 else 7), made       # conv1, conv2, conv3 of both blocks + b0's downsample
+        # chained gradient preparation from the second step on: conv1 -> grouped conv2 -> conv3 in both blocks (the
+        # grouped kernel's data gradient prepares conv1's gradient, conv3's prepares the grouped layer's) and b0's
+        # output -> b1's conv1: five gradient-preparation launches less
+        chained = [conv_hip.CHAIN_STATS[i] - ch0[i] for i in (0, 1)]
+        assert chained == ([0, 0] if step == 0 else [5, 5]), chained
         assert _rel(got, want) < 4e-3, (step, _rel(got, want))
         # Gradients against ATEN's (not against the kernel's own ReLU pattern, as the per-layer tests above do): the
         # fp16 forward moves every pre-activation by ~5e-4 of its scale, so ~4e-4 of the units of each of the six
