@@ -4126,6 +4126,15 @@ extern "C" int sln_conv2d_fwd_ms_f32(const uint16_t *x_parts, int nseg, const in
                     sln_knob("SLN_CONV_EPI", 1) != 0;
     if (parts == 1 && narrow) hipLaunchKernelGGL((conv_fwd_kernel<1, 64>), g, b, 0, (hipStream_t)stream, p);
     else if (parts == 1) hipLaunchKernelGGL((conv_fwd_kernel<1, 128>), g, b, 0, (hipStream_t)stream, p);
+    else if (parts == 2 && narrow && w8 && sln_knob("SLN_CONV_EPI64", 1) != 0) {
+        // (round 5) the 64-wide tile with ONE epilogue kind per instance, like the 128-wide one below: the all-in-one
+        // instance carries every variant behind run-time branches
+        if (p.res_parts) hipLaunchKernelGGL((conv_fwd_kernel<2, 64, 2>), g, b, 0, (hipStream_t)stream, p);
+        else if (p.residual && p.mask_part0) hipLaunchKernelGGL((conv_fwd_kernel<2, 64, 4>), g, b, 0, (hipStream_t)stream, p);
+        else if (p.residual) hipLaunchKernelGGL((conv_fwd_kernel<2, 64, 5>), g, b, 0, (hipStream_t)stream, p);
+        else if (p.mask_part0) hipLaunchKernelGGL((conv_fwd_kernel<2, 64, 3>), g, b, 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((conv_fwd_kernel<2, 64, 1>), g, b, 0, (hipStream_t)stream, p);
+    }
     else if (parts == 2 && narrow) hipLaunchKernelGGL((conv_fwd_kernel<2, 64>), g, b, 0, (hipStream_t)stream, p);
     else if (parts == 2 && w8) {       // the instance that carries only the epilogue this launch needs
         if (p.res_parts) hipLaunchKernelGGL((conv_fwd_kernel<2, 128, 2>), g, b, 0, (hipStream_t)stream, p);
