@@ -360,6 +360,110 @@ def main_resnext(args, rank, world, dev):
         dist.destroy_process_group()
 
 
+def main_detect(args, rank, world, dev):
+    """BASELINE.json configs[1]: ResNet-50 + FPN SLN FORWARD ONLY, 8 x 800^2 synthetic images per GPU (reference:
+    MaskRCNN.predict(mode='inference'), model.py:576-628, one image at a time there): GLM + backbone + RPN + proposals
+    + NMS + classifier over the proposal slots + top-100 detections + mask head, batched, no host sync inside a step
+    (tests/test_e2e_gpu.py runs the same call under torch's sync-debug mode "error").  `--tail` adds the evaluation
+    hand-off of amodal_train.py:370-400 per image (unmold to full-size masks + COCO RLE on the device; one count read
+    per batch).  Same JSON schema; `metric` names what is timed."""
+    import numpy as np
+    from sln_amodal_amd import conv_hip, mask_rle, nn_ops
+    from sln_amodal_amd.config import Config
+    from sln_amodal_amd.model import MaskRCNN
+    batch = args.batch if args.batch is not None else 8
+    dim = args.dim if args.dim is not None else 800
+    arch = args.arch if args.arch_given else "resnet50"
+
+    class DetectConfig(Config):
+        NAME = "bench_detect"
+        IMAGE_MAX_DIM = dim
+        IMAGE_MIN_DIM = dim
+        ARCHITECTURE = arch
+        BATCH_SIZE = batch
+        DETECTION_MIN_CONFIDENCE = 0
+
+    cfg = DetectConfig()
+    torch.manual_seed(0)
+    model = MaskRCNN(cfg, "/tmp/sln_bench_logs").apply_amodal_heads().to(dev)
+    from sln_amodal_amd import synthetic
+    train_like = synthetic.make_batch(cfg, min(batch, 4), dim, dim, seed=1234 + rank, device=dev,
+                                      anchors_f64=model.anchors_f64)
+    synthetic.calibrate_batchnorm(model, train_like["images"][: min(4, batch)])
+    synthetic.calibrate_glm(model, train_like["images"][: min(2, batch)])
+    synthetic.warm_start_rpn(model, [train_like], iters=40)
+    model.eval()
+    gen = torch.Generator().manual_seed(5 + rank)
+    imgs = [torch.randint(0, 256, (dim, dim, 3), generator=gen, dtype=torch.uint8).numpy() for _ in range(batch)]
+    molded, metas, windows = model.mold_inputs(imgs)
+    x = torch.from_numpy(molded.transpose(0, 3, 1, 2)).float().to(dev).contiguous(memory_format=torch.channels_last)
+
+    def step():
+        with torch.no_grad():
+            detections, mrcnn_mask = model.predict([x, metas], mode="inference")
+        n_rle = 0
+        if args.tail:
+            counts = model.last_num_detections.cpu().numpy()          # the one host read of the hand-off
+            for b in range(batch):
+                n = int(counts[b])
+                if n:
+                    out = model.unmold_detections_device(detections[b, :n], mrcnn_mask[b, :n], imgs[b].shape, windows[b],
+                                                         keep_device=True)
+                    if out["rois"].shape[0]:
+                        n_rle += len(mask_rle.encode(out["masks_device"]))
+        return detections, n_rle
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(args.warmup, 2)):
+        step()
+    if rank == 0:
+        conv_hip.PROFILE = []
+    barrier()
+    t0 = time.perf_counter()
+    n_rle = 0
+    for _ in range(args.steps):
+        detections, k = step()
+        n_rle += k
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof, conv_hip.PROFILE = conv_hip.PROFILE, None
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    if rank == 0:
+        counts = model.last_num_detections.cpu().numpy()
+        flops = sum(e[2] for e in prof) / max(args.steps, 1)              # algorithmic conv FLOPs per step (forward only)
+        value = batch * world * args.steps / elapsed
+        achieved = flops * args.steps / elapsed / 1e12
+        peak = split_peak(conv_hip.PARTS)
+        out = {"metric": "images/sec forward-only (%s + FPN SLN inference%s, %d^2, bs%d/GPU)" %
+                         (arch, " + unmold + RLE tail" if args.tail else "", dim, batch),
+               "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(1e3 * elapsed / max(args.steps, 1), 3), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "roofline": dominant_kernel_roofline(prof, elapsed, conv_hip.PARTS, replay_traffic=False),
+               "config": {"workload": "BASELINE.json configs[1]: %s + FPN SLN forward-only (predict(mode='inference'): GLM, "
+                                      "backbone, RPN, proposals + NMS, classifier, top-100 detections, mask head), "
+                                      "%d x %dx%d images/GPU" % (arch, batch, dim, dim),
+                          "arch": arch, "images_per_gpu": batch, "image_dim": dim, "parallelism": "dp%d" % world,
+                          "conv_split_parts": conv_hip.PARTS, "tail": bool(args.tail),
+                          "detections_last_batch": [int(c) for c in counts], "rle_masks_encoded": n_rle,
+                          "max_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)},
+               "step_roofline": {"bound": "mfma", "kernel": "whole inference step (all kernels)",
+                                 "achieved": round(achieved, 3), "peak": round(peak, 1), "unit": "TFLOP/s",
+                                 "frac": round(achieved / peak, 4),
+                                 "algorithmic_tflop_per_step": round(flops / 1e12, 3)}}
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -367,7 +471,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=None, help="images per GPU (default: 16 for sln, 32 for resnext)")
     ap.add_argument("--dim", type=int, default=None, help="image edge (default: 1024 for sln, 321 for resnext)")
-    ap.add_argument("--arch", default="resnet101")
+    ap.add_argument("--arch", default=None)
     ap.add_argument("--stage", default="all", choices=["all", "heads"])
     ap.add_argument("--settle", type=int, default=16,
                     help="untimed set-up train steps that seed the operand-scale window (see conv_saturated_blocks)")
@@ -381,14 +485,18 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-strict", action="store_true", help="skip the 5 extra steps in the 3 x bf16 format")
     ap.add_argument("--conv-backend", default="auto", choices=["auto", "hip", "torch"])
-    ap.add_argument("--config", default="sln", choices=["sln", "resnext"],
+    ap.add_argument("--config", default="sln", choices=["sln", "resnext", "detect"],
                     help="sln: BASELINE.json's headline (configs[2] / [3]); resnext: configs[4], ResNeXt-101 + multi-scale "
-                         "heads train step (default there: --batch 32 --dim 321)")
+                         "heads train step (default there: --batch 32 --dim 321); detect: configs[1], ResNet-50 + FPN "
+                         "forward-only (default there: --batch 8 --dim 800 --arch resnet50)")
+    ap.add_argument("--tail", action="store_true", help="--config detect: include the unmold + RLE hand-off per image")
     ap.add_argument("--parts", type=int, default=None, choices=[1, 2, 3],
                     help="operand format of the conv stack: 2 = two scaled fp16 parts (default), 3 = three bf16 parts "
                          "(both fp32-class); 1 = one scaled fp16 part, fp16 storage (--config resnext only: configs[4] "
                          "as BASELINE.json states it, 'fp16 MFMA')")
     args = ap.parse_args()
+    args.arch_given = args.arch is not None
+    args.arch = args.arch or "resnet101"
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(launch_ranks(args.gpus))
 
@@ -427,6 +535,8 @@ def main():
     nn_ops.BACKEND = args.conv_backend
     if args.config == "resnext":
         return main_resnext(args, rank, world, dev)
+    if args.config == "detect":
+        return main_detect(args, rank, world, dev)
     args.batch = 16 if args.batch is None else args.batch
     args.dim = 1024 if args.dim is None else args.dim
     if args.parts == 1:

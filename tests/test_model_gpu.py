@@ -448,3 +448,29 @@ def test_mask_head_tail_gradients_with_the_chained_deconv(monkeypatch):
     for a, b in zip(res[1], res[0]):
         assert a.shape == b.shape
         assert (a - b).norm().item() <= 2e-5 * max(b.norm().item(), 1e-12)
+
+
+def test_bench_config_detect_prints_the_contract_line():
+    """`bench.py --config detect` (BASELINE.json configs[1]: ResNet-50 + FPN SLN forward-only; default 8 x 800^2) at a
+    small shape, with the evaluation hand-off (`--tail`: unmold + RLE on the device): one JSON line with the contract's
+    keys, a roofline for the dominant kernel, `traffic: null` (no counter file belongs to this problem)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    torch.cuda.empty_cache()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "detect", "--batch", "2", "--dim", "256",
+                        "--steps", "2", "--warmup", "1", "--tail"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "step_roofline"):
+        assert k in out, k
+    assert out["n_gpus"] == 1 and out["value"] > 0 and out["config"]["images_per_gpu"] == 2
+    assert out["config"]["arch"] == "resnet50" and out["config"]["tail"] is True
+    assert out["roofline"]["traffic"] is None and out["step_roofline"]["algorithmic_tflop_per_step"] > 0
+    assert len(out["config"]["detections_last_batch"]) == 2
