@@ -653,6 +653,23 @@ def main():
             strict = args.batch * world * 5 / (time.perf_counter() - t1)
         finally:
             conv_hip.PARTS = 2
+    # opt-in variant of the SAME train step: the mask head on the positive roi slots only (MaskRCNN.mask_train_slots:
+    # same losses and gradients, tests/test_model_gpu.py) -- 2 untimed + 5 timed steps, reported next to the headline,
+    # never as `value` (the headline runs the reference's graph: the mask branch on all sampled rois)
+    pos_slots = None
+    if not args.no_strict and nn_ops.BACKEND != "torch" and hasattr(model, "positive_slots"):
+        model.mask_train_slots = model.positive_slots()
+        try:
+            for i in range(2):
+                model.train_step(batches[i % 2], opt, sync)
+            barrier()
+            t1 = time.perf_counter()
+            for i in range(5):
+                model.train_step(batches[i % 2], opt, sync)
+            barrier()
+            pos_slots = args.batch * world * 5 / (time.perf_counter() - t1)
+        finally:
+            model.mask_train_slots = None
     if os.environ.get("SLN_DEBUG_BN_CACHE") and rank == 0:
         print("shortcut-gradient links handed over/consumed:", conv_hip.LINK_STATS, file=sys.stderr)
         print("chained gradient preparations handed over/used:", conv_hip.CHAIN_STATS, file=sys.stderr)
@@ -746,6 +763,12 @@ def main():
         # the committed counter passes were collected on the headline workload: any other problem gets traffic = null
         headline = (args.batch, args.dim, args.arch, args.stage) == (16, 1024, "resnet101", "all") and \
             conv_hip.PARTS == 2 and nn_ops.BACKEND != "torch" and file_data is None
+        if pos_slots is not None:
+            out["mask_head_positive_slots_images_per_sec"] = round(pos_slots, 4)
+            out["config"]["mask_head_positive_slots_note"] = (
+                "opt-in MaskRCNN.mask_train_slots = %d: mask head on the positive roi slots only -- same losses and "
+                "gradients, %d of %d rois less in the mask branch; NOT the headline (the reference computes all)" %
+                (model.positive_slots(), cfg.TRAIN_ROIS_PER_IMAGE - model.positive_slots(), cfg.TRAIN_ROIS_PER_IMAGE))
         out["roofline"] = dominant_kernel_roofline(prof, elapsed, conv_hip.PARTS, replay_traffic=headline)
         if not headline:
             out["roofline"]["traffic_note"] = "null: the committed PMC passes belong to 16 x 1024^2 resnet101 stage=all parts=2"

@@ -114,6 +114,14 @@ class MaskRCNN(nn.Module):
         self.layer_decoder = None
         self.amodal_refine = None
         self.GLM_modual = None
+        # training: mask head on the first k roi slots only (None: all TRAIN_ROIS_PER_IMAGE slots, the reference's
+        # graph).  positive_slots() = int(R * ROI_POSITIVE_RATIO), the most positives detection_target_layer returns:
+        # with it the train step computes the same losses and gradients without the mask branch of the negative rois
+        # (_training_heads; opt-in, bench.py reports it as a second number).
+        self.mask_train_slots = None
+
+    def positive_slots(self):
+        return int(self.config.TRAIN_ROIS_PER_IMAGE * self.config.ROI_POSITIVE_RATIO)
 
     # ------------------------------------------------------------------ build
     def build(self, config):
@@ -348,11 +356,15 @@ class MaskRCNN(nn.Module):
         cfg = self.config
         mrcnn_feature_maps = maps[:4]
         B, R = rois.shape[0], rois.shape[1]
+        k = self.mask_train_slots
+        k = k if (k is not None and 0 < k < R) else None
         # cropped into the head of the mask head's 439-channel input buffer (no torch.cat later)
-        GLM_feature = pyramid_roi_align_image([rois, probs], cfg.MASK_POOL_SIZE, (65, 65), istrain=True,
-                                              box_ind=box_ind, cat_extra=256)
-        if getattr(GLM_feature, "_sln_cat_buf", None) is None:
-            GLM_feature = GLM_feature.detach()
+        GLM_feature = None
+        if k is None:
+            GLM_feature = pyramid_roi_align_image([rois, probs], cfg.MASK_POOL_SIZE, (65, 65), istrain=True,
+                                                  box_ind=box_ind, cat_extra=256)
+            if getattr(GLM_feature, "_sln_cat_buf", None) is None:
+                GLM_feature = GLM_feature.detach()
         # both heads' crops are differentiated by the step loss: they share one set of P2..P5 gradient maps
         pool = None
         if rois.is_cuda and torch.is_grad_enabled() and all(
@@ -363,7 +375,23 @@ class MaskRCNN(nn.Module):
             pool.inboxes = getattr(self, "_crop_inboxes", None)
         mrcnn_class_logits, mrcnn_class, mrcnn_bbox = self.classifier(mrcnn_feature_maps, rois, box_ind,
                                                                       grad_pool=pool)
-        mrcnn_mask, _feat = self.mask(mrcnn_feature_maps, rois, GLM_feature, box_ind, grad_pool=pool)
+        if k is not None:
+            # OPT-IN (off by default: the reference runs its mask branch on all R sampled rois, model.py:664-700):
+            # the two mask losses read the POSITIVE rois only (loss.py:113-152) and detection_target_layer puts the
+            # positives first, at most int(R * ROI_POSITIVE_RATIO) of them -- the mask branch of the other slots
+            # feeds nothing in a train step.  The mask head then runs on the first k slots; the rows behind them
+            # are zeros (no loss reads them, no gradient flows from them): same losses, same gradients.
+            rois_m = rois[:, :k].contiguous()
+            ind_m = box_ind.view(B, R)[:, :k].reshape(-1).contiguous()
+            glm_m = pyramid_roi_align_image([rois_m, probs], cfg.MASK_POOL_SIZE, (65, 65), istrain=True,
+                                            box_ind=ind_m, cat_extra=256)
+            if getattr(glm_m, "_sln_cat_buf", None) is None:
+                glm_m = glm_m.detach()
+            mk, _feat = self.mask(mrcnn_feature_maps, rois_m, glm_m, ind_m, grad_pool=pool)
+            mrcnn_mask = torch.nn.functional.pad(mk.reshape(B, k, *mk.shape[1:]), (0, 0, 0, 0, 0, 0, 0, R - k)) \
+                .reshape(B * R, *mk.shape[1:])
+        else:
+            mrcnn_mask, _feat = self.mask(mrcnn_feature_maps, rois, GLM_feature, box_ind, grad_pool=pool)
         nc = mrcnn_class_logits.shape[1]
         return {
             "rpn_class_logits": rpn_class_logits, "rpn_bbox": rpn_bbox,

@@ -474,3 +474,47 @@ def test_bench_config_detect_prints_the_contract_line():
     assert out["config"]["arch"] == "resnet50" and out["config"]["tail"] is True
     assert out["roofline"]["traffic"] is None and out["step_roofline"]["algorithmic_tflop_per_step"] > 0
     assert len(out["config"]["detections_last_batch"]) == 2
+
+
+def test_mask_head_on_the_positive_slots_gives_the_same_train_step():
+    """MaskRCNN.mask_train_slots (opt-in; default None = the reference's graph, the mask branch on all 100 sampled rois,
+    model.py:664-700): with positive_slots() = int(R * ROI_POSITIVE_RATIO) the mask head runs on the first 70 slots
+    only -- detection_target_layer returns the positives first (Functions.py:223-416) and both mask losses read
+    positives only (loss.py:113-152) -- and the train step computes the SAME six losses (1e-6), the same clip norm and
+    the same update (the RoIAlign backward's fp32 atomics land in another order: 1e-4)."""
+    from sln_amodal_amd import conv_hip, nn_ops, synthetic
+    old = nn_ops.BACKEND
+    nn_ops.BACKEND = "hip"
+    try:
+        m, cfg = _small_model()
+        batch = synthetic.make_batch(cfg, 2, 256, 256, seed=3, anchors_f64=m.anchors_f64)
+        synthetic.calibrate_batchnorm(m, batch["images"])
+        synthetic.calibrate_glm(m, batch["images"])
+        synthetic.warm_start_rpn(m, [batch], iters=40)
+        gen = torch.Generator(device="cuda").manual_seed(5)
+        pr = {"pos": torch.rand(2, 1000, device="cuda", generator=gen),
+              "neg": torch.rand(2, 1000, device="cuda", generator=gen)}
+        assert m.mask_train_slots is None and m.positive_slots() == 70
+        start = {k: v.detach().clone() for k, v in m.state_dict().items()}
+        res = {}
+        for mode in (None, m.positive_slots()):
+            m.load_state_dict(start)
+            m.mask_train_slots = mode
+            opt = m.make_optimizer(0.001)
+            rows = []
+            for _ in range(3):          # (step 0 bootstraps the scale slots of the new roi count, steps 1-2 run on them)
+                loss, parts = m.train_step(batch, opt, priorities=pr)
+                rows.append((float(loss), {k: float(v) for k, v in parts.items()}, float(m.last_grad_norm)))
+            res[mode] = (rows, {k: v.detach().clone() for k, v in m.state_dict().items() if v.dtype == torch.float32})
+        m.mask_train_slots = None
+        (a, wa), (b, wb) = res[None], res[70]
+        for (la, pa, na), (lb, pb, nb) in zip(a, b):
+            assert abs(la - lb) <= 2e-5 * max(1.0, abs(la)), (a, b)
+            for k in pa:
+                assert abs(pa[k] - pb[k]) <= 2e-5 * max(1.0, abs(pa[k])), (k, pa[k], pb[k])
+            assert abs(na - nb) <= 1e-3 * na, (na, nb)
+        worst = max(float((wa[k] - wb[k]).norm() / (wa[k] - start[k]).norm().clamp_min(1e-12))
+                    for k in wa if float((wa[k] - start[k]).norm()) > 0)
+        assert worst < 5e-2, worst        # three clipped steps through the chaotic backbone (see test_multistep_gpu)
+    finally:
+        nn_ops.BACKEND = old
