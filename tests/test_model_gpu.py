@@ -480,9 +480,11 @@ def test_mask_head_on_the_positive_slots_gives_the_same_train_step():
     """MaskRCNN.mask_train_slots (opt-in; default None = the reference's graph, the mask branch on all 100 sampled rois,
     model.py:664-700): with positive_slots() = int(R * ROI_POSITIVE_RATIO) the mask head runs on the first 70 slots
     only -- detection_target_layer returns the positives first (Functions.py:223-416) and both mask losses read
-    positives only (loss.py:113-152) -- and the train step computes the SAME six losses (1e-6), the same clip norm and
-    the same update (the RoIAlign backward's fp32 atomics land in another order: 1e-4)."""
-    from sln_amodal_amd import conv_hip, nn_ops, synthetic
+    positives only (loss.py:113-152).  From the same weights the first train step gives the SAME six losses (1e-6),
+    the same clip norm (1e-4) and the same update of the mask head (1e-4; the RoIAlign backward's fp32 atomics land in
+    another order); the following steps -- on delayed scales of the new roi count -- stay within the spread two runs of
+    one build show in this clipped regime (1e-2; tests/test_multistep_gpu.py)."""
+    from sln_amodal_amd import nn_ops, synthetic
     old = nn_ops.BACKEND
     nn_ops.BACKEND = "hip"
     try:
@@ -501,20 +503,26 @@ def test_mask_head_on_the_positive_slots_gives_the_same_train_step():
             m.load_state_dict(start)
             m.mask_train_slots = mode
             opt = m.make_optimizer(0.001)
-            rows = []
-            for _ in range(3):          # (step 0 bootstraps the scale slots of the new roi count, steps 1-2 run on them)
+            rows, first = [], None
+            for it in range(3):
                 loss, parts = m.train_step(batch, opt, priorities=pr)
                 rows.append((float(loss), {k: float(v) for k, v in parts.items()}, float(m.last_grad_norm)))
-            res[mode] = (rows, {k: v.detach().clone() for k, v in m.state_dict().items() if v.dtype == torch.float32})
+                if it == 0:
+                    first = {k: v.detach().clone() for k, v in m.state_dict().items()
+                             if v.dtype == torch.float32 and k.startswith(("mask.", "classifier."))}
+            res[mode] = (rows, first)
         m.mask_train_slots = None
         (a, wa), (b, wb) = res[None], res[70]
-        for (la, pa, na), (lb, pb, nb) in zip(a, b):
-            assert abs(la - lb) <= 2e-5 * max(1.0, abs(la)), (a, b)
-            for k in pa:
-                assert abs(pa[k] - pb[k]) <= 2e-5 * max(1.0, abs(pa[k])), (k, pa[k], pb[k])
-            assert abs(na - nb) <= 1e-3 * na, (na, nb)
-        worst = max(float((wa[k] - wb[k]).norm() / (wa[k] - start[k]).norm().clamp_min(1e-12))
-                    for k in wa if float((wa[k] - start[k]).norm()) > 0)
-        assert worst < 5e-2, worst        # three clipped steps through the chaotic backbone (see test_multistep_gpu)
+        (la, pa, na), (lb, pb, nb) = a[0], b[0]
+        assert abs(la - lb) <= 2e-6 * max(1.0, abs(la)), (a[0], b[0])
+        for k in pa:
+            assert abs(pa[k] - pb[k]) <= 2e-6 * max(1.0, abs(pa[k])), (k, pa[k], pb[k])
+        assert abs(na - nb) <= 1e-4 * na, (na, nb)
+        moved = [k for k in wa if float((wa[k] - start[k]).norm()) > 0]
+        assert any(k.startswith("mask.") for k in moved)
+        worst = max(float((wa[k] - wb[k]).norm() / (wa[k] - start[k]).norm()) for k in moved)
+        assert worst < 1e-4, worst
+        for (la, pa, na), (lb, pb, nb) in zip(a[1:], b[1:]):
+            assert np.isfinite(lb) and abs(la - lb) <= 1e-2 * max(1.0, abs(la)), (a, b)
     finally:
         nn_ops.BACKEND = old
