@@ -499,7 +499,7 @@ def test_mask_head_on_the_positive_slots_gives_the_same_train_step():
         assert m.mask_train_slots is None and m.positive_slots() == 70
         start = {k: v.detach().clone() for k, v in m.state_dict().items()}
         res = {}
-        for tag, mode in (("boot", None), (None, None), (70, m.positive_slots())):
+        for tag, mode in (("boot", None), (None, None), ("again", None), (70, m.positive_slots())):
             m.load_state_dict(start)
             m.mask_train_slots = mode
             opt = m.make_optimizer(0.001)
@@ -515,9 +515,11 @@ def test_mask_head_on_the_positive_slots_gives_the_same_train_step():
         # ("boot": the same weights once before -- it bootstraps every scale slot, so that the two runs compared below
         # both start from slots with a history; its distance from the second all-slots run is printed as the noise floor)
         (a, wa), (b, wb) = res[None], res[70]
-        w0 = res["boot"][1]
-        print("noise floor (two all-slots runs):", sorted(((float((wa[k] - w0[k]).norm() / (wa[k] - start[k]).norm().clamp_min(1e-30)), k)
-                                                            for k in wa), reverse=True)[:4])
+        for other in ("boot", "again"):
+            w0 = res[other][1]
+            print("all slots vs all slots (%s):" % other,
+                  sorted(((float((wa[k] - w0[k]).norm() / (wa[k] - start[k]).norm().clamp_min(1e-30)), k) for k in wa),
+                         reverse=True)[:4])
         (la, pa, na), (lb, pb, nb) = a[0], b[0]
         assert abs(la - lb) <= 2e-6 * max(1.0, abs(la)), (a[0], b[0])
         for k in pa:
