@@ -515,11 +515,13 @@ def test_mask_head_on_the_positive_slots_gives_the_same_train_step():
         # ("boot": the same weights once before -- it bootstraps every scale slot, so that the two runs compared below
         # both start from slots with a history; its distance from the second all-slots run is printed as the noise floor)
         (a, wa), (b, wb) = res[None], res[70]
+        noise = {}
         for other in ("boot", "again"):
             w0 = res[other][1]
-            print("all slots vs all slots (%s):" % other,
-                  sorted(((float((wa[k] - w0[k]).norm() / (wa[k] - start[k]).norm().clamp_min(1e-30)), k) for k in wa),
-                         reverse=True)[:4])
+            d = {k: float((wa[k] - w0[k]).norm() / (wa[k] - start[k]).norm().clamp_min(1e-30)) for k in wa}
+            print("all slots vs all slots (%s):" % other, sorted(((v, k) for k, v in d.items()), reverse=True)[:4])
+            if other == "again":
+                noise = d
         (la, pa, na), (lb, pb, nb) = a[0], b[0]
         assert abs(la - lb) <= 2e-6 * max(1.0, abs(la)), (a[0], b[0])
         for k in pa:
@@ -529,8 +531,11 @@ def test_mask_head_on_the_positive_slots_gives_the_same_train_step():
         assert any(k.startswith("mask.") for k in moved)
         rel = sorted(((float((wa[k] - wb[k]).norm() / (wa[k] - start[k]).norm()), k) for k in moved), reverse=True)
         print("first-step update, all slots vs positive slots, worst tensors:", rel[:6])
-        # weights 1e-4; the bias / per-channel tensors are sums of 400 k terms by fp32 atomics whose order differs: 1e-2
-        assert all(r < (1e-4 if wa[k].dim() >= 2 else 1e-2) for r, k in rel), rel[:6]
+        # per tensor: what two runs of the SAME mode differ by (x 3; measured 1.6e-4 on mask.conv1.weight, <= 3.4e-5 on
+        # every other tensor -- delayed scales move with the slots' history), with floors of 1e-5 for weights and 1e-2
+        # for the per-channel tensors (sums of 400 k terms by fp32 atomics)
+        for r, k in rel:
+            assert r <= max(3.0 * noise.get(k, 0.0), 1e-5 if wa[k].dim() >= 2 else 1e-2), (k, r, noise.get(k))
         for (la, pa, na), (lb, pb, nb) in zip(a[1:], b[1:]):
             assert np.isfinite(lb) and abs(la - lb) <= 1e-2 * max(1.0, abs(la)), (a, b)
     finally:
