@@ -304,6 +304,10 @@ def parse_args(argv=None):
     ap.add_argument("--image-dim", default=1024, type=int)
     ap.add_argument("--batch", default=None, type=int, help="images per GPU")
     ap.add_argument("--steps-per-epoch", default=None, type=int)
+    ap.add_argument("--mask-positive-slots", action="store_true",
+                    help="train: run the mask head on the positive roi slots only (MaskRCNN.mask_train_slots): the same "
+                         "losses and gradients without the mask branch of the negative rois (the reference computes it "
+                         "for all sampled rois, model.py:664-700); off by default")
     ap.add_argument("--workers", default=None, type=int,
                     help="loader worker processes per rank (default 8, SLN_LOADER_WORKERS; 0 = load on the training "
                          "thread; the reference: DataLoader(num_workers=4), model.py:340-342)")
@@ -383,6 +387,8 @@ def main(argv=None):
     parallel.broadcast_parameters(model)
 
     if args.command == "train":
+        if args.mask_positive_slots:
+            model.mask_train_slots = model.positive_slots()
         params = lambda: [p for p in model.parameters() if p.requires_grad]
         reducer = None
         for lr, epochs, layers in ((config.LEARNING_RATE, 2, "heads"), (config.LEARNING_RATE, 3, "4+"),
