@@ -1417,21 +1417,33 @@ __host__ __device__ __forceinline__ bool epilogue_is_plain(const ConvParams &p) 
 // each 32x64 (1x2 tiles) -- half the B tile and half the MFMAs of a 128-wide tile that would be half empty.
 // EPI as in conv_fwd256h_kernel: 0 = every epilogue, chosen at run time; 1..5 = only that eight-channel tile
 // epilogue (the all-in-one 128-wide instance: 168 VGPRs at three blocks per CU with 144 B of scratch per lane).
-template <int P, int BNT, int EPI = 0>
-__global__ __launch_bounds__(256, BNT == 128 ? SLN_FWD128_BLOCKS : 1) void conv_fwd_kernel(const ConvParams p) {
+// ROW3 (round 5, the small-K 3-wide layers of C2 / C3: 64 -> 64 at 256^2, 128 -> 128 at 128^2): a k-step is (32-channel
+// chunk, kernel ROW) instead of (chunk, tap).  The tile's 128 pixels are consecutive pixels of ONE image row (the
+// launcher asks for W % 128 == 0, stride 1, pad_left == dil_w <= 8), so the three taps of a kernel row read the same
+// 128 + 2 dil_w input pixels shifted by 0 / d / 2d: they are staged ONCE (144 LDS rows, pixels outside the image row
+// as zeros) next to the three taps' weight tiles, and one pair of barriers covers three taps of MFMA work -- a third
+// of the activation loads, a third of the barriers per product.  The chunk swizzle (row bits 2..3) is conflict-free
+// for any 32 consecutive rows, so a shifted fragment read costs the same as an aligned one.  Same products, another
+// fp32 summation order (chunk, kh, kw).
+template <int P, int BNT, int EPI = 0, bool ROW3 = false>
+__global__ __launch_bounds__(256, ROW3 ? (BNT == 128 ? 2 : 3) : (BNT == 128 ? SLN_FWD128_BLOCKS : 1)) void conv_fwd_kernel(const ConvParams p) {
     constexpr int NI = BNT == 128 ? 2 : 1;        // 32-row MFMA tiles per wave along M
     constexpr int NBI = BNT / 64;                 // 64-row staging passes of the B tile
     constexpr int SLD = BNT + 4;                  // staging slab row stride (floats)
+    constexpr int AROWS = ROW3 ? BM + 16 : BM;    // activation rows of a stage (ROW3: the halo of 2 x 8 pixels at most)
+    constexpr int NT = ROW3 ? 3 : 1;              // weight tiles (taps) of a stage
+    constexpr int NAI = ROW3 ? 3 : 2;             // 64-row staging passes of the A tile
+    static_assert(!ROW3 || P == 2, "tap-row k-steps: the two-part format");
     // one LDS region: operand tiles during the k-loop, fp32 staging tile in the epilogue
     // Operand rows are 32 bf16 = 64 B, unpadded; the 16-B chunk index is XOR-swizzled
     // with bits 2..3 of the row, so the 16 rows a ds_read_b128 group touches cover
     // all 16 four-bank groups (conflict-free) and a block needs 48 KB -> 3 blocks/CU.
-    constexpr int TILE_B = P * (BM + BNT) * BK * 2, STAGE_B = 64 * SLD * 4;
+    constexpr int TILE_B = P * (AROWS + NT * BNT) * BK * 2, STAGE_B = 64 * SLD * 4;
     __shared__ __attribute__((aligned(16))) unsigned char smem[TILE_B > STAGE_B ? TILE_B : STAGE_B];
-    typedef __bf16 (*tile_t)[BM][BK];
-    typedef __bf16 (*tileb_t)[BNT][BK];
+    typedef __bf16 (*tile_t)[AROWS][BK];
+    typedef __bf16 (*tileb_t)[NT * BNT][BK];
     tile_t sA = (tile_t)smem;
-    tileb_t sB = (tileb_t)(smem + P * BM * BK * 2);
+    tileb_t sB = (tileb_t)(smem + P * AROWS * BK * 2);
     __shared__ float s_colsum[BNT];   // per-block column sums of the output (colsum mode)
     __shared__ unsigned s_word[2];    // block amax / saturation flag of the output parts (P = 2)
     if (threadIdx.x < BNT) s_colsum[threadIdx.x] = 0.f;   // ordered by the k-loop's barriers
@@ -1480,11 +1492,45 @@ __global__ __launch_bounds__(256, BNT == 128 ? SLN_FWD128_BLOCKS : 1) void conv_
         bptr[i] = p.w + (long)(n0 + (b_ok[i] ? row : 0)) * p.Ktot;
     }
 
-    bf16x8 ra[P][2], rb[P][NBI];
-    const int nk = p.KH * p.KW * p.cin_chunks;
+    bf16x8 ra[P][NAI], rb[P][NT * NBI];
+    const int nk = ROW3 ? p.KH * p.cin_chunks : p.KH * p.KW * p.cin_chunks;
     const bf16x8 zero8 = {};
+    // ROW3: the tile's image row (block-uniform)
+    const int r3_n = m0 / (p.segOH[0] * p.segOW[0]);
+    const int r3_rem = m0 - r3_n * (p.segOH[0] * p.segOW[0]);
+    const int r3_oh = r3_rem / p.segOW[0], r3_ow0 = r3_rem - r3_oh * p.segOW[0];
 
     auto load_tile = [&](int ks) {
+        if constexpr (ROW3) {
+            const int cc = ks / p.KH, kh = ks - cc * p.KH;
+            const int ci = cc * BK + chunk;
+            const bool cok = ci < p.Cin;
+            const int H = p.segH[0], W = p.segW[0];
+            const int ih = r3_oh - p.pt + kh * p.dh;
+            const bool rok = cok && ih >= 0 && ih < H;
+            const long rbase = ((long)r3_n * H + ih) * W;
+#pragma unroll
+            for (int i = 0; i < NAI; ++i) {
+                const int r = (t >> 2) + 64 * i;
+                const int iw = r3_ow0 - p.dw + r;
+                const bool ok = rok && r < BM + 2 * p.dw && iw >= 0 && iw < W;
+                const long off = (rbase + iw) * p.Cin + ci;
+#pragma unroll
+                for (int pp = 0; pp < P; ++pp)
+                    ra[pp][i] = ok ? *(const bf16x8 *)(p.x + pp * p.x_part_stride + off) : zero8;
+            }
+#pragma unroll
+            for (int kw = 0; kw < NT; ++kw) {
+                const long koff = (long)(kh * 3 + kw) * p.Cin + ci;
+#pragma unroll
+                for (int i = 0; i < NBI; ++i)
+#pragma unroll
+                    for (int pp = 0; pp < P; ++pp)
+                        rb[pp][kw * NBI + i] = (b_ok[i] && cok) ? *(const bf16x8 *)(bptr[i] + pp * p.w_part_stride + koff)
+                                                                : zero8;
+            }
+            return;
+        }
         // channel-chunk major, tap minor: the KH*KW shifted windows of one 32-channel
         // slab are read in consecutive k-steps, so the re-reads hit L1/L2
         // Order: channel-chunk PAIR major, tap, then the two 32-channel chunks of the
@@ -1520,6 +1566,24 @@ __global__ __launch_bounds__(256, BNT == 128 ? SLN_FWD128_BLOCKS : 1) void conv_
     };
     const int schunk = ((t & 3) ^ ((t >> 4) & 3)) * 8;   // swizzled chunk of this thread's rows
     auto store_tile = [&]() {
+        if constexpr (ROW3) {
+#pragma unroll
+            for (int i = 0; i < NAI; ++i) {
+                const int row = (t >> 2) + 64 * i;
+                if (row < AROWS) {
+#pragma unroll
+                    for (int pp = 0; pp < P; ++pp) *(bf16x8 *)&sA[pp][row][schunk] = ra[pp][i];
+                }
+            }
+#pragma unroll
+            for (int kw = 0; kw < NT; ++kw)
+#pragma unroll
+                for (int i = 0; i < NBI; ++i)
+#pragma unroll
+                    for (int pp = 0; pp < P; ++pp)
+                        *(bf16x8 *)&sB[pp][kw * BNT + (t >> 2) + 64 * i][schunk] = rb[pp][kw * NBI + i];
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int row = (t >> 2) + 64 * i;
@@ -1546,6 +1610,30 @@ __global__ __launch_bounds__(256, BNT == 128 ? SLN_FWD128_BLOCKS : 1) void conv_
     const int frow = lane & 31, fsw = (frow >> 2) & 3, fhi = lane >> 5;
     for (int ks = 0; ks < nk; ++ks) {
         if (ks + 1 < nk) load_tile(ks + 1);
+        if constexpr (ROW3) {
+#pragma unroll
+            for (int kw = 0; kw < NT; ++kw) {
+                const int ashift = kw * p.dw;
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    bf16x8 a[NI][P], b[2][P];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int pp = 0; pp < P; ++pp) {
+                            if (i < NI) {
+                                const int arow = wr * (32 * NI) + i * 32 + frow + ashift;
+                                a[i < NI ? i : 0][pp] = *(const bf16x8 *)&sA[pp][arow][((kk * 2 + fhi) ^ ((arow >> 2) & 3)) * 8];
+                            }
+                            b[i][pp] = *(const bf16x8 *)&sB[pp][kw * BNT + wc * 64 + i * 32 + frow][((kk * 2 + fhi) ^ fsw) * 8];
+                        }
+#pragma unroll
+                    for (int i = 0; i < NI; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) mfma_products<P>(a[i], b[j], acc[i][j]);
+                }
+            }
+        } else {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             bf16x8 a[NI][P], b[2][P];
@@ -1562,6 +1650,7 @@ __global__ __launch_bounds__(256, BNT == 128 ? SLN_FWD128_BLOCKS : 1) void conv_
             for (int i = 0; i < NI; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) mfma_products<P>(a[i], b[j], acc[i][j]);
+        }
         }
         __syncthreads();
         if (ks + 1 < nk) {
@@ -3933,7 +4022,8 @@ extern "C" int sln_scale_update_f32(float *amax, float *scale, float *history, i
 // and K is long enough to amortise the pipeline; else 128.  SLN_CONV_TILE256 = 0 never,
 // 1 (default) by this rule, 2 always (tests); read on every call.
 // Which forward kernel the last sln_conv2d_fwd*_f32 call of this thread launched (profiling labels): 0 the 128^2
-// kernel, 1 conv_fwd256_kernel, 2 conv_fwd256h_kernel, 3 conv_fwd128x256h_kernel, 4 conv_fwd256h_kernel's tap-row instances.
+// kernel, 1 conv_fwd256_kernel, 2 conv_fwd256h_kernel, 3 conv_fwd128x256h_kernel, 4 conv_fwd256h_kernel's tap-row instances,
+// 5 conv_fwd_kernel's ROW3 instances.
 static thread_local int sln_last_fwd_kernel = 0;
 extern "C" int sln_conv_fwd_last_kernel(void) { return sln_last_fwd_kernel; }
 
@@ -4124,6 +4214,22 @@ extern "C" int sln_conv2d_fwd_ms_f32(const uint16_t *x_parts, int nseg, const in
     const dim3 g((unsigned)nblk), b(256);
     const bool w8 = parts == 2 && epilogue_is_plain(p) && !(p.dbg & 16) && epilogue_is_w8(p) && !(p.dbg & 256) &&
                     sln_knob("SLN_CONV_EPI", 1) != 0;
+    // (round 5) 3-wide kernels, stride 1, on maps whose rows are whole 128-pixel tiles: k-steps per kernel ROW
+    // (conv_fwd_kernel's ROW3 instances; SLN_CONV_ROW3=0: the per-tap loop, A/B)
+    const bool row3 = parts == 2 && w8 && nseg == 1 && KW == 3 && stride_h == 1 && stride_w == 1 && pad_left == dil_w &&
+                      dil_w <= 8 && p.segOW[0] == p.segW[0] && p.segW[0] % BM == 0 && sln_knob("SLN_CONV_ROW3", 1) != 0;
+    if (row3) {
+        sln_last_fwd_kernel = 5;
+#define SLN_LR3(E) do { if (narrow) hipLaunchKernelGGL((conv_fwd_kernel<2, 64, E, true>), g, b, 0, (hipStream_t)stream, p); \
+                        else hipLaunchKernelGGL((conv_fwd_kernel<2, 128, E, true>), g, b, 0, (hipStream_t)stream, p); } while (0)
+        if (p.res_parts) SLN_LR3(2);
+        else if (p.residual && p.mask_part0) SLN_LR3(4);
+        else if (p.residual) SLN_LR3(5);
+        else if (p.mask_part0) SLN_LR3(3);
+        else SLN_LR3(1);
+#undef SLN_LR3
+        return sln_launch_status();
+    }
     if (parts == 1 && narrow) hipLaunchKernelGGL((conv_fwd_kernel<1, 64>), g, b, 0, (hipStream_t)stream, p);
     else if (parts == 1) hipLaunchKernelGGL((conv_fwd_kernel<1, 128>), g, b, 0, (hipStream_t)stream, p);
     else if (parts == 2 && narrow && w8 && sln_knob("SLN_CONV_EPI64", 1) != 0) {

@@ -1238,6 +1238,88 @@ def test_tap_row_stages_equal_the_plain_k_loop(shape, kind, tile_mode):
         _taprow_env(None)
 
 
+@pytest.mark.parametrize("shape", [
+    # N, H, W, Cin, Cout, dil.  conv_fwd_kernel's ROW3 instances take 3-wide kernels on maps whose rows are whole
+    # 128-pixel tiles: the C2 / C3 layers (64 -> 64 at 256 columns, 128 -> 128 at 128), both tile widths, dilations up
+    # to the 8-pixel halo, ragged channel counts, one chunk of K, three tiles per row; the last two are NOT admitted
+    # (64 columns; 130 columns) and stay on the per-tap loop
+    (2, 8, 256, 64, 64, 1), (1, 16, 128, 128, 128, 1), (1, 4, 128, 72, 40, 2), (1, 3, 384, 32, 128, 8),
+    (2, 5, 128, 136, 96, 4), (1, 4, 128, 8, 64, 1), (1, 1, 128, 64, 64, 1), (3, 2, 256, 40, 168, 3),
+    (3, 20, 64, 64, 64, 1), (1, 6, 130, 64, 64, 1)])
+@pytest.mark.parametrize("kind", ["plain", "parts", "res16", "res32", "res32+mask16", "mask16+colsum"])
+def test_row3_k_steps_equal_the_per_tap_loop(shape, kind, tile_mode):
+    """conv_fwd_kernel<2, BNT, EPI, ROW3 = true> stages a kernel ROW's 128 + 2 d input pixels once and reads its three
+    taps from shifted LDS rows (pixels outside the image row are staged as zeros).  Same products as the per-tap loop in
+    another summation order: every output within 4e-6 of the output scale, the fp64 reference within 5e-6, and 30
+    launches reproduce themselves bit for bit."""
+    import os
+    from sln_amodal_amd import conv_hip
+    N, H, W, Cin, Cout, dil = shape
+    k = 3
+    g = torch.Generator(device="cuda").manual_seed(H * 23 + Cin + len(kind))
+    x = torch.randn(N, Cin, H, W, device="cuda", generator=g).contiguous(memory_format=torch.channels_last)
+    w = torch.randn(Cout, Cin, k, k, device="cuda", generator=g) / (Cin * k * k) ** 0.5
+    res = torch.randn(N, Cout, H, W, device="cuda", generator=g).contiguous(memory_format=torch.channels_last)
+    sc = torch.rand(Cout, device="cuda", generator=g) + 0.5
+    sf = torch.randn(Cout, device="cuda", generator=g)
+    xp, xq = conv_hip.act_parts(x, 2)
+    rp, rq = conv_hip.act_parts(res, 2)
+    slot = conv_hip._slot(w, ("yrow3", H, W, kind))
+    A = (xp, N, H, W, conv_hip.wsrc(w, 2), Cout, k, k, (1, 1), (dil, dil), dil, dil, H, W)
+    tile_mode(0)
+    os.environ["SLN_CONV_ROW3"] = "0"
+    try:
+        for _ in range(2):       # bootstrap the output's scale slot with a per-tap launch
+            conv_hip._fwd(*A, sc, sf, None, True, cin=Cin, out_parts=True, yslot=slot, xq=xq)
+        run = {
+            "plain": lambda: conv_hip._fwd(*A, sc, sf, None, True, cin=Cin, out_parts=True, yslot=slot, xq=xq),
+            "parts": lambda: conv_hip._fwd(*A, sc, sf, None, True, cin=Cin, out_parts=True, want_y=False, yslot=slot, xq=xq),
+            "res16": lambda: conv_hip._fwd(*A, sc, sf, None, True, cin=Cin, out_parts=True, want_y=False, yslot=slot, xq=xq,
+                                           res_parts=(rp, rq)),
+            "res32": lambda: conv_hip._fwd(*A, sc, sf, res, True, cin=Cin, out_parts=True, yslot=slot, xq=xq),
+            "res32+mask16": lambda: conv_hip._fwd(*A, None, None, res, False, cin=Cin, out_parts=True, want_y=True,
+                                                  want_colsum=True, post_scale=sc, yslot=slot, xq=xq, mask_parts=rp),
+            "mask16+colsum": lambda: conv_hip._fwd(*A, sc, None, None, False, cin=Cin, out_parts=True, want_y=False,
+                                                   want_colsum=True, yslot=slot, xq=xq, mask_parts=rp),
+        }[kind]
+
+        def outputs():
+            r = run()
+            r = r if isinstance(r, tuple) else (r, getattr(r, "_sln_parts", (None, None))[1], None)
+            return [None if t is None else t.clone() for t in r]
+
+        want = outputs()
+        assert conv_hip._lib.lib().sln_conv_fwd_last_kernel() == 0
+        os.environ["SLN_CONV_ROW3"] = "1"
+        got = outputs()
+        assert conv_hip._lib.lib().sln_conv_fwd_last_kernel() == (5 if W % 128 == 0 else 0)
+
+        def decode(t):
+            if t is None:
+                return None
+            if t.dtype == torch.bfloat16:                                # the two fp16 parts (scale: the slot's)
+                return t.view(torch.float16).double().sum(dim=0)
+            return t.double()
+        for a, b in zip(got, want):
+            assert (a is None) == (b is None)
+            if a is None:
+                continue
+            da, db = decode(a), decode(b)
+            tol = (2e-5 if a.dim() == 1 else 4e-6) * float(db.abs().max()) + 1e-30
+            assert float((da - db).abs().max()) <= tol, (kind, float((da - db).abs().max()), tol)
+        if kind == "plain":
+            ref = F.relu(F.conv2d(x.double(), w.double(), None, 1, dil, dil) * sc.double().view(1, -1, 1, 1)
+                         + sf.double().view(1, -1, 1, 1))
+            assert float((got[0].double() - ref).abs().max()) / float(ref.abs().max()) < 5e-6
+        for _ in range(30):
+            again = outputs()
+            for a, b in zip(again, got):
+                if a is not None and a.dim() != 1:       # (the column sums are atomics: order-dependent rounding)
+                    assert torch.equal(a, b)
+    finally:
+        os.environ.pop("SLN_CONV_ROW3", None)
+
+
 @pytest.mark.parametrize("route", ["128x256", "256", "taprow"])
 @pytest.mark.parametrize("shape", [
     # N, H, W, Cin, Cout, k, dil
