@@ -516,9 +516,14 @@ int sln_conv2d_fwd_ms_f32(const uint16_t *x_parts, int nseg, const int32_t *seg_
 int sln_conv_fwd_tile(int64_t M, int Cout, int64_t K, int parts);
 /* Which forward kernel the calling thread's last sln_conv2d_fwd*_f32 call launched: 0 conv_fwd_kernel (128 x 128),
  * 1 conv_fwd256_kernel, 2 conv_fwd256h_kernel, 3 conv_fwd128x256h_kernel (pointwise layers: two blocks per CU),
- * 4 conv_fwd256h_kernel's tap-row instances (3-wide kernels, stride 1, maps of 32 ... 256 columns).
+ * 4 conv_fwd256h_kernel's tap-row instances (3-wide kernels, stride 1, maps of 32 ... 256 columns),
+ * 5 conv_fwd_kernel's ROW3 instances (3-wide kernels, stride 1, rows of whole 128-pixel tiles: k-steps per kernel row).
  * Profiling labels only. */
 int sln_conv_fwd_last_kernel(void);
+/* The same for the PROCESS's last sln_conv2d_wgrad_f32 call (autograd launches weight gradients from its own thread):
+ * 0 conv_wgrad_kernel (a block per tap), 1 the 256 x 256 kernels, 2 conv_wgrad_kernel's
+ * ROW3 instances (3-wide kernels, stride 1, rows of whole 32-pixel k-steps: a block per kernel row). */
+int sln_conv_wgrad_last_kernel(void);
 /* Tile edge (128 or 256) of the weight-gradient kernel sln_conv2d_wgrad_f32 uses (host-side rule). */
 int sln_conv_wgrad_tile(int64_t M, int Cout, int Cin, int taps, int parts);
 /* workspace (optional): sln_conv_wgrad_workspace_bytes() bytes lent by the caller make the split-K

@@ -67,6 +67,7 @@ SIGNATURES = {
                                    _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "sln_conv_fwd_tile": (_i, [C.c_int64, _i, C.c_int64, _i]),
     "sln_conv_fwd_last_kernel": (_i, []),
+    "sln_conv_wgrad_last_kernel": (_i, []),
     "sln_conv_wgrad_tile": (_i, [C.c_int64, _i, _i, _i, _i]),
     "sln_conv_wgrad_workspace_bytes": (C.c_size_t, [C.c_int64, _i, _i, _i, _i]),
     "sln_grouped_conv3x3_f32": (_i, [_p, _i, _i, _i, _i, _i, _p, _i, _p, _p, _i, _p, _p]),

@@ -39,6 +39,7 @@
 // (64 B) with the 16-B chunk index XOR-swizzled by row bits 2..3 (48 KB per block, 3
 // blocks per CU): the ds_read_b128 fragment reads of a 16-lane group hit 16 distinct
 // 4-bank groups (conflict-free).  Register prefetch of the next k-step.
+#include <atomic>
 #include <cstdlib>
 #include "common.h"
 
@@ -3102,17 +3103,25 @@ __device__ __forceinline__ bf16x8 tr_frag(const __bf16 *tile, int k0, int m0, in
 
 // TM x TN output tile (Cout x Cin of one tap), 128 or 64 each: 2x2 waves of (TM/2) x (TN/2); the 64-wide
 // sides serve the 64-channel C2 stage, where a 128-wide tile would be half (or three quarters) empty.
-template <int P, int TM, int TN>
+// ROW3 (round 5, the 3-wide layers of C2 / C3): a block owns the THREE taps of one kernel row.  A k-step's 32 output
+// pixels are consecutive pixels of one image row (the launcher asks for stride 1, OW == W, OW % 32 == 0), so the three
+// taps read the same 32 + 2 dil_w input pixels shifted by 0 / d / 2d: the gradient rows and the input rows are
+// staged once per k-step for three accumulator sets -- a third of the loads and barriers per product, a third of the
+// blocks.  The plan (pixel ranges, slabs) is the per-tap kernel's; TN is 64 (three accumulator sets of a 128-wide
+// tile would leave one wave per SIMD).
+template <int P, int TM, int TN, bool ROW3 = false>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     constexpr int LDA = TM + 32, LDB = TN + 32;    // +32 bf16 (64 B): the four k-rows of a tr read 16 banks apart
     constexpr int NA = TM / 64, NB = TN / 64;      // 32-wide MFMA tiles per wave along M / N
+    constexpr int XR = ROW3 ? BK + 16 : BK;        // input rows of a stage (ROW3: + the halo of 2 x 8 pixels at most)
+    constexpr int NKW = ROW3 ? 3 : 1, NXI = ROW3 ? 3 : 2;
     __shared__ __attribute__((aligned(16))) __bf16 sA[P][BK][LDA];  // [k=pix][m=co]
-    __shared__ __attribute__((aligned(16))) __bf16 sB[P][BK][LDB];  // [k=pix][n=ci]
+    __shared__ __attribute__((aligned(16))) __bf16 sB[P][XR][LDB];  // [k=pix][n=ci]
 
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const int wr = wave >> 1, wc = wave & 1;
-    const int ntile = p.gm * p.gn_per_tap * p.KH * p.KW;
+    const int ntile = p.gm * p.gn_per_tap * (ROW3 ? p.KH : p.KH * p.KW);
     // all (Cout tile, Cin tile, tap) blocks of one pixel range on the SAME XCD, next to each other in dispatch
     // order: the range's gz and x rows come from HBM once and from that L2 for the other ntile - 1 readers
     int bid = (p.xcd_wgrad & 2) ? xcd_remap(blockIdx.x, ntile * p.ksplit) : (int)blockIdx.x;
@@ -3121,8 +3130,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     const int mt = bid % p.gm;
     int rest = bid / p.gm;
     const int nt = rest % p.gn_per_tap;
-    const int tap = rest / p.gn_per_tap;
-    const int kh = tap / p.KW, kw = tap - kh * p.KW;
+    const int tap = rest / p.gn_per_tap;           // ROW3: the kernel row
+    const int kh = ROW3 ? tap : tap / p.KW, kw = ROW3 ? 0 : tap - kh * p.KW;
     const int m0 = mt * TM, n0 = nt * TN;
 
     // staging: a tile part is 32 rows x 128 bf16 = 32 x 16 chunks of 16 B; thread t
@@ -3134,9 +3143,39 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     const int pix_end = min(p.M, pix_begin + p.pix_per_split);
     const int nk = (pix_end - pix_begin + BK - 1) / BK;
     const bf16x8 zero8 = {};
-    bf16x8 ra[P][2], rb[P][2];
+    bf16x8 ra[P][2], rb[P][NXI];
 
     auto load_tile = [&](int ks) {
+        if constexpr (ROW3) {
+            // the k-step's image row (block-uniform): its 32 pixels start at (n, oh, ow0)
+            const int pix0 = pix_begin + ks * BK;
+            const int n = pix0 / (p.OH * p.OW);
+            const int rem = pix0 - n * (p.OH * p.OW);
+            const int oh = rem / p.OW, ow0 = rem - oh * p.OW;
+            const int ih = oh - p.pt + kh * p.dh;
+            const bool rok = pix0 < pix_end && b_cok && ih >= 0 && ih < p.H;
+            const long rbase = ((long)n * p.H + ih) * p.W;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int pix = pix0 + (t >> 4) + 16 * i;
+                const bool pok = pix < pix_end && a_cok;
+                const long aoff = (long)pix * p.Cop + m0 + ch;
+#pragma unroll
+                for (int pp = 0; pp < P; ++pp)
+                    ra[pp][i] = pok ? *(const bf16x8 *)(p.gz + pp * p.gz_part_stride + aoff) : zero8;
+            }
+#pragma unroll
+            for (int i = 0; i < NXI; ++i) {
+                const int r = (t >> 4) + 16 * i;
+                const int iw = ow0 - p.pl + r;
+                const bool xok = rok && r < BK + 2 * p.dw && iw >= 0 && iw < p.W;
+                const long boff = (rbase + iw) * p.Cip + n0 + ch;
+#pragma unroll
+                for (int pp = 0; pp < P; ++pp)
+                    rb[pp][i] = xok ? *(const bf16x8 *)(p.x + pp * p.x_part_stride + boff) : zero8;
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int pix = pix_begin + ks * BK + (t >> 4) + 16 * i;
@@ -3159,23 +3198,25 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     };
     auto store_tile = [&]() {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NXI; ++i) {
             const int row = (t >> 4) + 16 * i;
 #pragma unroll
             for (int pp = 0; pp < P; ++pp) {
-                if (ch < TM) *(bf16x8 *)&sA[pp][row][ch] = ra[pp][i];
+                if (i < 2 && ch < TM) *(bf16x8 *)&sA[pp][row < BK ? row : 0][ch] = ra[pp][i < 2 ? i : 0];
                 if (ch < TN) *(bf16x8 *)&sB[pp][row][ch] = rb[pp][i];
             }
         }
     };
 
-    f32x16 acc[NA][NB];
+    f32x16 acc[NKW][NA][NB];
 #pragma unroll
-    for (int i = 0; i < NA; ++i)
+    for (int q = 0; q < NKW; ++q)
 #pragma unroll
-        for (int j = 0; j < NB; ++j)
+        for (int i = 0; i < NA; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int j = 0; j < NB; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[q][i][j][r] = 0.f;
 
     if (nk > 0) {
         load_tile(0);
@@ -3195,14 +3236,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
                 for (int pp = 0; pp < P; ++pp)
                     a[i][pp] = tr_frag<LDA>(&sA[pp][0][0], k0, wr * (TM / 2) + i * 32 + 16 * (g & 1), lane);
 #pragma unroll
-            for (int j = 0; j < NB; ++j)
+            for (int q = 0; q < NKW; ++q) {
+                const int xs = ROW3 ? q * p.dw : 0;        // tap kw = q reads the input rows shifted by q dil_w pixels
 #pragma unroll
-                for (int pp = 0; pp < P; ++pp)
-                    b[j][pp] = tr_frag<LDB>(&sB[pp][0][0], k0, wc * (TN / 2) + j * 32 + 16 * (g & 1), lane);
+                for (int j = 0; j < NB; ++j)
 #pragma unroll
-            for (int i = 0; i < NA; ++i)
+                    for (int pp = 0; pp < P; ++pp)
+                        b[j][pp] = tr_frag<LDB>(&sB[pp][0][0], k0 + xs, wc * (TN / 2) + j * 32 + 16 * (g & 1), lane);
 #pragma unroll
-                for (int j = 0; j < NB; ++j) mfma_products<P>(a[i], b[j], acc[i][j]);
+                for (int i = 0; i < NA; ++i)
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) mfma_products<P>(a[i], b[j], acc[q][i][j]);
+            }
         }
         __syncthreads();
         if (ks + 1 < nk) {
@@ -3213,20 +3258,24 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     // epilogue: row = co, col = ci; atomics (split-K partial sums)
     const float alpha = P <= 2 ? operand_unscale(p.gz_scale, p.x_scale) : 1.f;
 #pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        const int ci = n0 + wc * (TN / 2) + j * 32 + (lane & 31);
-        if (ci >= p.Cin) continue;
+    for (int q = 0; q < NKW; ++q) {
+        const int tapq = ROW3 ? kh * 3 + q : tap;
 #pragma unroll
-        for (int i = 0; i < NA; ++i)
+        for (int j = 0; j < NB; ++j) {
+            const int ci = n0 + wc * (TN / 2) + j * 32 + (lane & 31);
+            if (ci >= p.Cin) continue;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = m0 + wr * (TM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (co >= p.Cout) continue;
-                const float v = acc[i][j][r] * alpha;
-                const long e = ((long)co * p.KH * p.KW + tap) * p.Cin + ci;
-                if (p.partial) p.partial[(long)split * ((long)p.Cout * p.KH * p.KW * p.Cin) + e] = v;
-                else if (v != 0.f) atomicAdd(p.gw + e, v);
-            }
+            for (int i = 0; i < NA; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = m0 + wr * (TM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (co >= p.Cout) continue;
+                    const float v = acc[q][i][j][r] * alpha;
+                    const long e = ((long)co * p.KH * p.KW + tapq) * p.Cin + ci;
+                    if (p.partial) p.partial[(long)split * ((long)p.Cout * p.KH * p.KW * p.Cin) + e] = v;
+                    else if (v != 0.f) atomicAdd(p.gw + e, v);
+                }
+        }
     }
 }
 
@@ -4281,6 +4330,12 @@ extern "C" int sln_conv2d_fwd_f32(const uint16_t *x_parts, int N, int H, int W, 
 // x 256 Cin) tile per block, LDS-DMA pipeline, split-K sized to one round of the 256 CUs) when both
 // channel counts fill >= 176 (>= 160 of the last 256) columns, the tap tiles fit one round and there
 // are enough pixels; else 128.  SLN_WGRAD_TILE256 = 0 never, 1 (default) by this rule, 2 always.
+// Which weight-gradient kernel the PROCESS's last sln_conv2d_wgrad_f32 call launched (weight gradients are launched from
+// autograd's worker thread, the label is read from the caller's): 0 conv_wgrad_kernel (a block per tap), 1 the 256 x 256
+// kernels, 2 conv_wgrad_kernel's ROW3 instances (a block per kernel row).
+static std::atomic<int> sln_last_wgrad_kernel{0};
+extern "C" int sln_conv_wgrad_last_kernel(void) { return sln_last_wgrad_kernel.load(); }
+
 extern "C" int sln_conv_wgrad_tile(int64_t M, int Cout, int Cin, int taps, int parts) {
     const int mode = sln_knob("SLN_WGRAD_TILE256", 1);
     if (M < 1 || Cout < 1 || Cin < 1 || taps < 1 || parts == 1) return BM;      // (single fp16 part: the generic kernel)
@@ -4346,6 +4401,7 @@ extern "C" int sln_conv2d_wgrad_f32(const uint16_t *gz_parts, int Cout, int Cout
     p.xcd_wgrad = sln_knob("SLN_WGRAD_XCD", 3);      // bit 0: the 256^2 kernels, bit 1: the 128^2 kernel
     const long nblk = (long)w.gm * w.gn * KH * KW * w.ksplit;
     if (nblk > 2147483647L) return SLN_ERR_UNSUPPORTED;
+    sln_last_wgrad_kernel = w.tile == T2 ? 1 : 0;
     if (w.tile == T2) {
         // the fp16 kernel addresses with 32-bit byte offsets and divides pixel indices in fp32
         const bool h = parts == 2 && sln_knob("SLN_WGRAD_F16_KERNEL", 1) && M < (1L << 24) &&
@@ -4360,6 +4416,22 @@ extern "C" int sln_conv2d_wgrad_f32(const uint16_t *gz_parts, int Cout, int Cout
         else
             hipLaunchKernelGGL(conv_wgrad256_kernel<3>, dim3((unsigned)nblk), dim3(512), 0, st, p);
     } else {
+        // (round 5) 3-wide kernels, stride 1, rows of whole 32-pixel k-steps: a block per kernel ROW (conv_wgrad_kernel's
+        // ROW3 instances, 64-wide Cin tiles; the pixel ranges and slabs are the plan's; SLN_WGRAD_ROW3=0: per tap, A/B)
+        const bool row3 = parts == 2 && KW == 3 && stride_h == 1 && stride_w == 1 && OW == W && OW % BK == 0 &&
+                          pad_left == dil_w && dil_w <= 8 && w.pps % BK == 0 && sln_knob("SLN_WGRAD_ROW3", 1) != 0;
+        if (row3) {
+            sln_last_wgrad_kernel = 2;
+            p.gn_per_tap = sln_div_up(Cin, 64);
+            const long nb3 = (long)w.gm * p.gn_per_tap * KH * w.ksplit;
+            const dim3 g3((unsigned)nb3), b3(256);
+            if (w.tm == 64) hipLaunchKernelGGL((conv_wgrad_kernel<2, 64, 64, true>), g3, b3, 0, st, p);
+            else hipLaunchKernelGGL((conv_wgrad_kernel<2, 128, 64, true>), g3, b3, 0, st, p);
+            if (two_phase && !defer)
+                hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((gw_elems + 127) / 128)), dim3(256), 0, st,
+                                   (const float *)workspace, w.ksplit, (long)gw_elems, gw, transpose ? KH * KW : 0, Cin);
+            return sln_launch_status();
+        }
         const dim3 g((unsigned)nblk), b(256);
         const int TMs = w.tm, TNs = w.tn;
 #define SLN_WG(PP, A, B) hipLaunchKernelGGL((conv_wgrad_kernel<PP, A, B>), g, b, 0, st, p)

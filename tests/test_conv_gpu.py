@@ -661,6 +661,60 @@ def test_weight_gradient_is_bit_reproducible(parts, shape, monkeypatch):
     assert torch.allclose(atomic, first, rtol=1e-4, atol=1e-5 * float(first.abs().max()))
 
 
+@pytest.mark.parametrize("shape", [
+    # N, Cin, Cout, H, W, dil.  conv_wgrad_kernel's ROW3 instances (a block per kernel ROW, three accumulator sets) take
+    # 3-wide kernels with stride 1 whose rows are whole 32-pixel k-steps: C2 (64 -> 64 at 256 columns), C3 (128 -> 128 at
+    # 128), ragged channel counts on both tile heights, 32 columns, dilations up to the 8-pixel halo, a pixel count
+    # that leaves the last range short; the last shape (48 columns) is NOT admitted and stays on the per-tap kernel
+    (2, 64, 64, 12, 256, 1), (1, 128, 128, 24, 128, 1), (3, 72, 40, 7, 64, 2), (2, 40, 136, 9, 32, 8),
+    (1, 136, 72, 40, 96, 4), (5, 64, 64, 11, 32, 3), (2, 64, 64, 10, 48, 1)])
+def test_row3_weight_gradient_equals_the_per_tap_kernel(shape, monkeypatch):
+    """Same products as the per-tap blocks, summed over the same pixel ranges in the same order inside a range (k-steps
+    of 32 pixels): the two-phase result within 2e-6 of the per-tap kernel's (MFMA accumulation order inside a k-step
+    differs by tap only in its zero rows), fp64 within 2e-5, bit-reproducible, and the atomic path agrees."""
+    import os
+    from sln_amodal_amd import conv_hip
+    monkeypatch.setattr(conv_hip, "PARTS", 2)
+    N, Cin, Cout, H, W, dil = shape
+    k = 3
+    g = torch.Generator(device="cuda").manual_seed(Cin + Cout + W)
+    x = torch.randn(N, Cin, H, W, device="cuda", generator=g).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(Cout, Cin, k, k, device="cuda", generator=g) / (Cin * k * k) ** 0.5).requires_grad_(True)
+    up = torch.randn(N, Cout, H, W, device="cuda", generator=g).contiguous(memory_format=torch.channels_last)
+    last = conv_hip._lib.lib().sln_conv_wgrad_last_kernel
+
+    def grad():
+        w.grad = None
+        y = conv_hip._ConvFn.apply(x, w, None, None, None, None, False, (1, 1), (dil, dil), (dil,) * 4)
+        y.backward(up)
+        return w.grad.clone()
+
+    try:
+        os.environ["SLN_WGRAD_ROW3"] = "0"
+        grad()                                   # (scale bootstrap)
+        monkeypatch.setattr(conv_hip, "DETERMINISTIC_WGRAD", True)
+        want = grad()
+        if last() == 1:
+            pytest.skip("the shape runs on the 256 x 256 weight-gradient kernel")
+        assert last() == 0
+        os.environ["SLN_WGRAD_ROW3"] = "1"
+        got = grad()
+        assert last() == (2 if W % 32 == 0 else 0)
+        scale = float(want.abs().max())
+        assert float((got - want).abs().max()) <= 2e-6 * scale, float((got - want).abs().max()) / scale
+        xr = x.double()
+        wr = w.detach().double().requires_grad_(True)
+        F.conv2d(xr, wr, None, 1, dil, dil).backward(up.double())
+        assert float((got.double() - wr.grad).norm() / wr.grad.norm()) < 2e-5
+        for _ in range(10):
+            assert torch.equal(grad(), got)
+        monkeypatch.setattr(conv_hip, "DETERMINISTIC_WGRAD", False)
+        atomic = grad()
+        assert torch.allclose(atomic, got, rtol=1e-4, atol=1e-5 * scale)
+    finally:
+        os.environ.pop("SLN_WGRAD_ROW3", None)
+
+
 def test_deferred_reduce_and_side_stream_weight_gradients_equal_the_plain_ones(monkeypatch):
     """conv_hip.BATCH_WGRAD_REDUCE (the reduce passes of up to 16 layers in one launch) and conv_hip.WGRAD_STREAM: weight gradients launched on a second stream next to the data gradients.  A stack of
     three bottlenecks plus ONE convolution applied twice (the RPN's shared weights: its second gradient is added by
