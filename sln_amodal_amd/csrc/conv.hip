@@ -4269,8 +4269,13 @@ extern "C" int sln_conv2d_fwd_ms_f32(const uint16_t *x_parts, int nseg, const in
                       dil_w <= 8 && p.segOW[0] == p.segW[0] && p.segW[0] % BM == 0 && sln_knob("SLN_CONV_ROW3", 1) != 0;
     if (row3) {
         sln_last_fwd_kernel = 5;
-#define SLN_LR3(E) do { if (narrow) hipLaunchKernelGGL((conv_fwd_kernel<2, 64, E, true>), g, b, 0, (hipStream_t)stream, p); \
-                        else hipLaunchKernelGGL((conv_fwd_kernel<2, 128, E, true>), g, b, 0, (hipStream_t)stream, p); } while (0)
+        // SLN_CONV_ROW3_NARROW=1 (A/B): 64-wide tiles for 128 output channels as well (43 KB of LDS: three blocks per CU
+        // instead of two, the activation rows staged by both column tiles)
+        const bool narrow3 = narrow || (Cout <= 128 && sln_knob("SLN_CONV_ROW3_NARROW", 0) != 0);
+        p.gn = sln_div_up(Cout, narrow3 ? 64 : BN);
+        const dim3 g3((unsigned)((long)p.gm * p.gn));
+#define SLN_LR3(E) do { if (narrow3) hipLaunchKernelGGL((conv_fwd_kernel<2, 64, E, true>), g3, b, 0, (hipStream_t)stream, p); \
+                        else hipLaunchKernelGGL((conv_fwd_kernel<2, 128, E, true>), g3, b, 0, (hipStream_t)stream, p); } while (0)
         if (p.res_parts) SLN_LR3(2);
         else if (p.residual && p.mask_part0) SLN_LR3(4);
         else if (p.residual) SLN_LR3(5);
@@ -4423,9 +4428,12 @@ extern "C" int sln_conv2d_wgrad_f32(const uint16_t *gz_parts, int Cout, int Cout
         if (row3) {
             sln_last_wgrad_kernel = 2;
             p.gn_per_tap = sln_div_up(Cin, 64);
-            const long nb3 = (long)w.gm * p.gn_per_tap * KH * w.ksplit;
+            // SLN_WGRAD_ROW3_TM64=1 (A/B): 64 x 64 tiles whatever Cout (more, lighter blocks)
+            const bool tm64 = w.tm == 64 || sln_knob("SLN_WGRAD_ROW3_TM64", 0) != 0;
+            if (tm64) p.gm = sln_div_up(Cout, 64);
+            const long nb3 = (long)p.gm * p.gn_per_tap * KH * w.ksplit;
             const dim3 g3((unsigned)nb3), b3(256);
-            if (w.tm == 64) hipLaunchKernelGGL((conv_wgrad_kernel<2, 64, 64, true>), g3, b3, 0, st, p);
+            if (tm64) hipLaunchKernelGGL((conv_wgrad_kernel<2, 64, 64, true>), g3, b3, 0, st, p);
             else hipLaunchKernelGGL((conv_wgrad_kernel<2, 128, 64, true>), g3, b3, 0, st, p);
             if (two_phase && !defer)
                 hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((gw_elems + 127) / 128)), dim3(256), 0, st,
