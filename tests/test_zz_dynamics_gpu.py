@@ -91,14 +91,14 @@ def test_train_step_learns_one_fixed_batch_like_the_aten_path():
     # another roi, so not the 1e-4 of test_loss_parity_hip_conv_vs_aten_conv_same_proposals)
     assert abs(hip[0]["total"] - aten[0]["total"]) <= 0.05, msg       # (measured 3e-3 .. 1.5e-2 over seven runs)
     # it learns: the total and the detector's own four losses fall (observed: total -0.33, both backends)
-    assert hip[-1]["total"] < hip[0]["total"] - 0.15, msg        # (recorded runs: -0.26 ... -0.35)
-    assert det(hip[-1]) < det(hip[0]) - 0.1, msg                 # (-0.26 ... -0.35)
+    assert hip[-1]["total"] < hip[0]["total"] - 0.1, msg         # (recorded: -0.26 ... -0.43 over nineteen runs, sd 0.06)
+    assert det(hip[-1]) < det(hip[0]) - 0.07, msg                # (-0.25 ... -0.43)
     # ... and as well as aten does (the runs are not step-wise comparable: aten's own trajectory is not monotone
     # -- 2.81, 2.92, 2.68 at steps 20 / 40 / 79 in the recorded run -- and the two part ways like any two fp32
     # implementations would, tests/test_multistep_gpu.py's control)
-    # (recorded: HIP - aten at step 79 between -0.04 and +0.09 over seven runs)
-    assert hip[-1]["total"] <= aten[-1]["total"] + 0.25, msg
-    assert det(hip[-1]) <= det(aten[-1]) + 0.25, msg
+    # (recorded: HIP - aten at step 79 between -0.12 and +0.11 over nineteen runs, sd 0.08: both are draws)
+    assert hip[-1]["total"] <= aten[-1]["total"] + 0.35, msg
+    assert det(hip[-1]) <= det(aten[-1]) + 0.35, msg
 
 
 def test_train_step_at_the_reference_learning_rate_stays_finite_and_fits_the_masks():
