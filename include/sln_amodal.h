@@ -430,6 +430,8 @@ int64_t sln_rle_from_string(const char *s, int64_t len, uint32_t *counts, int64_
  *     of every tensor, cursor [n] its write positions: amax[i] is stored, a = max over the ring (a = amax[i]
  *     without a history); scale[i] <- 2^k with a*2^k in [2^(t-1), 2^t), t = target_log2 (11 on the path);
  *     amax[i] == 0 (tensor not produced since the last call) changes nothing; amax[i] <- 0.
+ * sln_scale_update_headroom_f32   the same with headroom[i] (0 ... 8, NULL = 0) extra bits of head room per tensor:
+ *     t = target_log2 - headroom[i].  The path gives its GRADIENT tensors 3 (2^8 below fp16's 65504 instead of 2^5).
  * ------------------------------------------------------------------------- */
 /* Weight-part layouts.  ROWS: [parts][O][KH][KW][I_pad] (the 128x128 forward kernel).  TILED256: the
  * LDS image of the 256x256 forward kernel -- for each 256-row Cout tile, each 16-channel K stage (in
@@ -495,6 +497,8 @@ int sln_conv_grad_prep_pooled_f32(const float *g_pool, const uint8_t *argmax, in
                                   float *q_amax, int32_t *q_saturated, sln_stream_t stream);
 int sln_scale_update_f32(float *amax, float *scale, float *history, int32_t *cursor, int n,
                          int64_t history_stride, int window, int target_log2, sln_stream_t stream);
+int sln_scale_update_headroom_f32(float *amax, float *scale, float *history, int32_t *cursor, const int8_t *headroom,
+                                  int n, int64_t history_stride, int window, int target_log2, sln_stream_t stream);
 int sln_conv2d_fwd_f32(const uint16_t *x_parts, int N, int H, int W, int Cin,
                        const uint16_t *w_parts, int w_layout, int parts, int Cout, int KH, int KW, int stride_h,
                        int stride_w, int dil_h, int dil_w, int pad_top, int pad_left, int OH, int OW,

@@ -61,6 +61,7 @@ SIGNATURES = {
     "sln_im2col_split_f32": (_i, [_p] + [_i] * 14 + [_p, C.c_int64, C.c_int64, _p, _p, _p, _p]),
     "sln_conv_grad_prep_f32": (_i, [_p, _p, _p, _p, C.c_int64, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
     "sln_scale_update_f32": (_i, [_p, _p, _p, _p, _i, C.c_int64, _i, _i, _p]),
+    "sln_scale_update_headroom_f32": (_i, [_p, _p, _p, _p, _p, _i, C.c_int64, _i, _i, _p]),
     "sln_conv2d_fwd_f32": (_i, [_p, _i, _i, _i, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
                                 _i, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
     "sln_conv2d_fwd_ms_f32": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,

@@ -146,12 +146,17 @@ def flush_wgrad_reduces(end_of_pass=False):
 # ------------------------------------------------------------------ per-tensor scales (PARTS = 2)
 SCALE_TARGET_LOG2 = 11      # max|v| * s lands in [2^10, 2^11): 2^5 of head room below fp16's 65504
 SCALE_WINDOW = 16           # the scale follows the maximum over this many recent steps of the tensor
+# Extra head room (bits) of the GRADIENT roles ("gz"): a gradient spikes by more than an activation grows -- the RPN
+# class-logit gradient of a pyramid level depends on which anchors the step drew -- and its absolute precision floor
+# (2^-25 of the scaled range) is far below what a weight-gradient sum over 10^5 pixels resolves.  Round 5: one block of
+# that tensor clamped in one timed step of one bench run in three with the activations' 2^5 (profiles/HISTORY_r5.md).
+GRAD_HEADROOM_LOG2 = 3
 
 
 class _Slot(object):
     """One tensor role of one layer: views of its device-side scale / running amax.  The table entry goes
     back to the book when the slot dies (with its layer)."""
-    __slots__ = ("scale", "amax", "hist", "cursor", "fresh", "book", "idx", "sat")
+    __slots__ = ("scale", "amax", "hist", "cursor", "fresh", "book", "idx", "sat", "headroom")
 
     def __del__(self):
         try:
@@ -167,6 +172,7 @@ class _Slot(object):
         self.hist = book.hist[0, idx:idx + 1]      # column idx of the ring (row stride = capacity)
         self.cursor = book.cursor[idx:idx + 1]
         self.sat = book.saturated[idx:idx + 1]     # this role's own clamp counter (blocks that clamped to +-65504)
+        self.headroom = book.headroom[idx:idx + 1]
         self.fresh = True            # no scale yet: the first producer bootstraps it from an amax pass
 
 
@@ -179,6 +185,7 @@ class ScaleBook(object):
         self.cursor = torch.zeros(capacity, dtype=torch.int32, device=device)
         # one clamp counter PER SLOT (round 5: the bench line says which tensor role clamped, and in which step)
         self.saturated = torch.zeros(capacity, dtype=torch.int32, device=device)
+        self.headroom = torch.zeros(capacity, dtype=torch.int8, device=device)     # extra bits below SCALE_TARGET_LOG2
         self.n = 0
         self._n_written, self._n_reduced = None, False
         self.free = []               # indices of dead slots (a heap: the lowest index is reused first, so
@@ -195,6 +202,7 @@ class ScaleBook(object):
             self.scale[idx] = 1.0
             self.hist[:, idx] = 0.0
             self.cursor[idx] = 0
+            self.headroom[idx] = 0
             # (the tables are only ever written by kernels; autograd has saved views of `scale` whose version
             # check must not trip over the reset of an unrelated, dead entry)
             torch._C._autograd._unsafe_set_version_counter(tables, versions)
@@ -225,15 +233,17 @@ class ScaleBook(object):
                     self._n_written = self.n
                 dist.all_reduce(self.amax, op=dist.ReduceOp.MAX)
                 self._n_reduced = True
-            _lib.check(_lib.lib().sln_scale_update_f32(ops._ptr(self.amax), ops._ptr(self.scale), ops._ptr(self.hist),
-                                                       ops._ptr(self.cursor), self.n, self.hist.shape[1], SCALE_WINDOW,
-                                                       SCALE_TARGET_LOG2, ops._stream()), "sln_scale_update_f32")
+            _lib.check(_lib.lib().sln_scale_update_headroom_f32(
+                ops._ptr(self.amax), ops._ptr(self.scale), ops._ptr(self.hist), ops._ptr(self.cursor),
+                ops._ptr(self.headroom), self.n, self.hist.shape[1], SCALE_WINDOW, SCALE_TARGET_LOG2, ops._stream()),
+                "sln_scale_update_headroom_f32")
 
     def settle(self, slot):
         """Bootstrap: slot.amax holds an exact amax pass -> its scale; clears the fresh flag."""
-        _lib.check(_lib.lib().sln_scale_update_f32(ops._ptr(slot.amax), ops._ptr(slot.scale), ops._ptr(slot.hist),
-                                                   ops._ptr(slot.cursor), 1, slot.book.hist.shape[1], SCALE_WINDOW,
-                                                   SCALE_TARGET_LOG2, ops._stream()), "sln_scale_update_f32")
+        _lib.check(_lib.lib().sln_scale_update_headroom_f32(
+            ops._ptr(slot.amax), ops._ptr(slot.scale), ops._ptr(slot.hist), ops._ptr(slot.cursor),
+            ops._ptr(slot.headroom), 1, slot.book.hist.shape[1], SCALE_WINDOW, SCALE_TARGET_LOG2, ops._stream()),
+            "sln_scale_update_headroom_f32")
         slot.fresh = False
 
 
@@ -311,6 +321,8 @@ def _slot(owner, key):
     if sl is None:
         sl = slots[key] = book(owner.device).new_slot()
         sl.book.names[sl.idx] = (key, tuple(owner.shape))
+        if key and key[0] == "gz" and GRAD_HEADROOM_LOG2:
+            sl.headroom.fill_(GRAD_HEADROOM_LOG2)
     return sl
 
 

@@ -722,7 +722,8 @@ __global__ __launch_bounds__(256) void split_weights_batch_kernel(const sln_spli
 // amax[i] <- 0.  One launch per step over every tensor slot (delayed scaling).
 __global__ __launch_bounds__(256) void scale_update_kernel(float *__restrict__ amax, float *__restrict__ scale,
                                                            float *__restrict__ hist, int32_t *__restrict__ cursor,
-                                                           int n, long stride, int window, int target_log2) {
+                                                           int n, long stride, int window, int target_log2,
+                                                           const signed char *__restrict__ headroom) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     float a = amax[i];
@@ -741,6 +742,7 @@ __global__ __launch_bounds__(256) void scale_update_kernel(float *__restrict__ a
         int e;
         (void)frexpf(a, &e);                 // a = f * 2^e, f in [0.5, 1)
         int k = target_log2 - e;             // a * 2^k in [2^(target-1), 2^target)
+        if (headroom) k -= headroom[i];      // (per-slot extra head room, in bits: gradient roles)
         k = k < -120 ? -120 : (k > 120 ? 120 : k);
         scale[i] = ldexpf(1.f, k);
     }
@@ -4061,7 +4063,24 @@ extern "C" int sln_scale_update_f32(float *amax, float *scale, float *history, i
     if (n == 0) return SLN_OK;
     if (!amax || !scale) return SLN_ERR_INVALID_ARG;
     hipLaunchKernelGGL(scale_update_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, amax, scale,
-                       history, cursor, n, (long)history_stride, window, target_log2);
+                       history, cursor, n, (long)history_stride, window, target_log2, (const signed char *)nullptr);
+    return sln_launch_status();
+}
+
+// The same with a per-slot table of EXTRA head room (bits, 0 ... 8) below target_log2: gradient tensors spike by more
+// than the 2^5 an activation's scale leaves (the RPN class-logit gradient of a level whose anchors were hardly drawn in
+// the window), and their absolute precision floor, 2^-25 of the scaled range, is far below what a weight-gradient sum
+// resolves.
+extern "C" int sln_scale_update_headroom_f32(float *amax, float *scale, float *history, int32_t *cursor,
+                                             const int8_t *headroom, int n, int64_t history_stride, int window,
+                                             int target_log2, sln_stream_t stream) {
+    sln_enter();
+    if (n < 0 || target_log2 < -14 || target_log2 > 15) return SLN_ERR_INVALID_ARG;
+    if (history && (!cursor || window < 1 || window > 1024 || history_stride < n)) return SLN_ERR_INVALID_ARG;
+    if (n == 0) return SLN_OK;
+    if (!amax || !scale) return SLN_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(scale_update_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, amax, scale,
+                       history, cursor, n, (long)history_stride, window, target_log2, (const signed char *)headroom);
     return sln_launch_status();
 }
 

@@ -715,6 +715,41 @@ def test_row3_weight_gradient_equals_the_per_tap_kernel(shape, monkeypatch):
         os.environ.pop("SLN_WGRAD_ROW3", None)
 
 
+def test_gradient_roles_carry_extra_head_room(monkeypatch):
+    """conv_hip.GRAD_HEADROOM_LOG2: the delayed scale of a GRADIENT tensor leaves 2^8 below fp16's 65504 (activations:
+    2^5) -- a gradient that comes back 100 x larger than anything in its 16-step window is split without a clamp, and
+    the weight gradient of that step is still fp32-class."""
+    from sln_amodal_amd import conv_hip
+    monkeypatch.setattr(conv_hip, "PARTS", 2)
+    g = torch.Generator(device="cuda").manual_seed(7)
+    x = torch.randn(2, 64, 32, 32, device="cuda", generator=g).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(64, 64, 3, 3, device="cuda", generator=g) / 24.0).requires_grad_(True)
+    up = torch.randn(2, 64, 32, 32, device="cuda", generator=g).contiguous(memory_format=torch.channels_last)
+
+    def step(gy):
+        conv_hip.update_scales(sync=False)
+        w.grad = None
+        y = conv_hip._ConvFn.apply(x, w, None, None, None, None, False, (1, 1), (1, 1), (1,) * 4)
+        y.backward(gy)
+        return w.grad.clone()
+
+    step(up)
+    step(up)                                        # (the second step runs on the delayed scale)
+    slot = w._sln_slots[("gz", 32, 32)]
+    assert int(slot.headroom) == conv_hip.GRAD_HEADROOM_LOG2 == 3
+    conv_hip.update_scales(sync=False)
+    a = float(up.abs().max()) * float(slot.scale)
+    assert 2.0 ** 7 <= a < 2.0 ** 8, a              # activations: [2^10, 2^11)
+    sat0 = conv_hip.saturation_count()
+    got = step(up * 100.0)
+    assert conv_hip.saturation_count() == sat0
+    wr = w.detach().double().requires_grad_(True)
+    F.conv2d(x.double(), wr, None, 1, 1).backward(up.double() * 100.0)
+    assert float((got.double() - wr.grad).norm() / wr.grad.norm()) < 2e-5
+    got = step(up * 1e5)                            # ... 1000 x the window's maximum: beyond the head room it clamps and counts, without inf
+    assert conv_hip.saturation_count() > sat0 and bool(torch.isfinite(got).all())
+
+
 def test_deferred_reduce_and_side_stream_weight_gradients_equal_the_plain_ones(monkeypatch):
     """conv_hip.BATCH_WGRAD_REDUCE (the reduce passes of up to 16 layers in one launch) and conv_hip.WGRAD_STREAM: weight gradients launched on a second stream next to the data gradients.  A stack of
     three bottlenecks plus ONE convolution applied twice (the RPN's shared weights: its second gradient is added by
