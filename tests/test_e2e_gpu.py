@@ -107,9 +107,11 @@ def _check_forward(out, g, b=0):
         assert e.max() < 1e-4, (key, "rows off", np.nonzero(e >= 1e-4)[0].tolist(), e.max())
 
 
-# (name of the fixture, image size): two 128^2 scenes and scene 0 at 256^2 -- maps of 64^2 .. 4^2, i.e. whole 256-row
-# tiles of the convolution kernels with their predicate-free epilogue (tools/gen_golden_e2e.py --dim 256)
-TRAIN_FIXTURES = [("e2e_train_0", 128), ("e2e_train_1", 128), ("e2e_train_256_0", 256)]
+# (name of the fixture, image size): two 128^2 scenes, scene 0 at 256^2 -- maps of 64^2 .. 4^2, i.e. whole 256-row
+# tiles of the convolution kernels with their predicate-free epilogue (tools/gen_golden_e2e.py --dim 256) -- and at
+# 512^2 (round 5, --dim 512: C2 at 128 columns, where the small-K 3x3 layers run per kernel ROW -- conv_fwd_kernel's /
+# conv_wgrad_kernel's ROW3 instances -- and C3 / C4 at 64 / 32 columns on the tap-row instances of the 256^2 kernel)
+TRAIN_FIXTURES = [("e2e_train_0", 128), ("e2e_train_1", 128), ("e2e_train_256_0", 256), ("e2e_train_512_0", 512)]
 
 
 @pytest.mark.parametrize("name,dim", TRAIN_FIXTURES)
@@ -182,7 +184,10 @@ def test_one_train_step_matches_the_reference_optimizer_step(name, dim):
         err = np.linalg.norm(d_got - d_ref) / np.linalg.norm(d_ref)
         worst[n] = err
         deep = n.startswith(("fpn.C1", "fpn.C2", "fpn.C3", "fpn.C4"))
-        assert err <= (2e-2 if deep else 2e-3), (n, err)
+        # (512^2: the two clip norms differ by 2.3e-4, which scales EVERY update -- the heads' whole error there -- and
+        # C5 sits under four times the ReLU units of the 256^2 scene: measured 1.5e-3 on fpn.C5.2.conv3.weight, the
+        # same in six runs)
+        assert err <= (2e-2 if deep else 4e-3 if dim >= 512 else 2e-3), (n, err)
     print("relative update errors", {k: "%.1e" % v for k, v in worst.items()}, "grad norm", got_norm, want_norm)
 
 
