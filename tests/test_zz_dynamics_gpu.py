@@ -208,6 +208,31 @@ def test_config3_full_size_train_step_resnet101_16x1024():
         assert tuple(got.shape) == tuple(want.shape), name
         assert err <= 1e-5, (name, err)
         del x, got, want
+    # ---- the small-K 3x3 layers at size, forward + data gradient + weight gradient (round 5: the per-kernel-row
+    # instances of the 128-family kernels take exactly these launches), HIP vs aten fp32, no ReLU in between ----
+    from sln_amodal_amd import conv_hip
+    lib = conv_hip._lib.lib()
+    for name, conv, bn, shape in (("C2 3x3 64->64 @256^2", m.fpn.C2[2].conv2, m.fpn.C2[2].bn2, (16, 64, 256, 256)),
+                                  ("C3 3x3 128->128 @128^2", m.fpn.C3[2].conv2, m.fpn.C3[2].bn2, (16, 128, 128, 128))):
+        x0 = torch.randn(shape, device="cuda", generator=gen).contiguous(memory_format=torch.channels_last)
+        up = torch.randn(shape, device="cuda", generator=gen).contiguous(memory_format=torch.channels_last)
+        res = {}
+        for be in ("hip", "hip", "torch"):           # (the first pass bootstraps the gradient's scale slot)
+            nn_ops.BACKEND = be
+            conv_hip.update_scales(sync=False)
+            x = x0.clone().requires_grad_(True)
+            conv.weight.grad = None
+            y = nn_ops.conv_bn_act(x, conv, bn, relu=False, same=True)
+            y.backward(up)
+            res[be] = (y.detach(), x.grad.detach(), conv.weight.grad.detach().clone())
+            if be == "hip":
+                assert lib.sln_conv_fwd_last_kernel() == 5 and lib.sln_conv_wgrad_last_kernel() == 2, name
+        nn_ops.BACKEND = "hip"
+        for what, a, b in zip(("forward", "data gradient", "weight gradient"), res["hip"], res["torch"]):
+            err = float((a.double() - b.double()).norm() / b.double().norm())
+            assert err <= 2e-5, (name, what, err)
+        conv.weight.grad = None
+        del x0, up, res, x, y
 
 
 def test_config5_resnext101_msc_train_step_full_depth():
