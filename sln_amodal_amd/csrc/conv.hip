@@ -2463,7 +2463,9 @@ __global__ __launch_bounds__(512) void conv_fwd256h_kernel(const ConvParams p) {
 #pragma unroll
             for (int ph = 0; ph < 2; ++ph) {
                 bf16x8 a[4][P];
-                if (ph == 0) {
+                // (dbg bit 16: ablation -- the weight fragments of stage 0 for every stage, no weight pieces: what the
+                // k-loop would cost if the weights did not pass through LDS; results wrong)
+                if (ph == 0 && (s == 0 || !(p.dbg & 65536))) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -2476,7 +2478,7 @@ __global__ __launch_bounds__(512) void conv_fwd256h_kernel(const ConvParams p) {
                     for (int pp = 0; pp < P; ++pp)
                         a[i][pp] = *(const bf16x8 *)(smem + pp * RREG + (vb + s_off[4 * ph + i]));
                 __builtin_amdgcn_sched_barrier(0);
-                if (ph == 0 && moreB) issue_w((s + 1) & 1);
+                if (ph == 0 && moreB && !(p.dbg & 65536)) issue_w((s + 1) & 1);
                 if (ph == 1 && fillA) issue_a(a_rd ^ 1);
                 if (ph == 1) {
                     // in order: the weight pieces of stage s + 1 are older than this stage's activation pieces
@@ -2550,7 +2552,7 @@ __global__ __launch_bounds__(512) void conv_fwd256h_kernel(const ConvParams p) {
             SLN_STAMP(t0);
             if (MS == 16) {
                 // phase 0: the four B tiles (kept for phase 1) and A tiles 0..3; phase 1: A tiles 4..7
-                if (ph == 0) {
+                if (ph == 0 && (s == 0 || !(p.dbg & 65536))) {       // (dbg bit 16: as in the tap-row loop)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -2587,7 +2589,7 @@ __global__ __launch_bounds__(512) void conv_fwd256h_kernel(const ConvParams p) {
                     if (ph == 1 && moreA) { issue_piece(0, 0); issue_piece(1, 0); }
                     if (ph == 2 && moreA) { issue_piece(2, 0); issue_piece(3, 0); }
                 } else if (ph == 0) {
-                    if (moreB && !(p.dbg & 268435456)) {          // (dbg bit 28: no weight pieces in the loop)
+                    if (moreB && !(p.dbg & (268435456 | 65536))) {          // (dbg bit 28: no weight pieces in the loop)
 #pragma unroll
                         for (int g = 4; g < 8; ++g) issue_piece(g, s + 1);
                     }
@@ -4230,12 +4232,12 @@ extern "C" int sln_conv2d_fwd_ms_f32(const uint16_t *x_parts, int nseg, const in
                 const int Wr = p.segW[0];
                 const bool row = nseg == 1 && KW == 3 && stride_h == 1 && stride_w == 1 && pad_left == dil_w && dil_w <= 8 &&
                                  p.segOW[0] == Wr && (Wr == 32 || Wr == 64 || Wr == 128 || Wr == 256) && M % T2 == 0 &&
-                                 !(p.dbg & ~(8 | 16 | 256 | 8192 | 16384 | 32768 | 131072)) &&
+                                 !(p.dbg & ~(8 | 16 | 256 | 8192 | 16384 | 32768 | 65536 | 131072)) &&
                                  sln_knob("SLN_CONV_TAPROW", 1) != 0;
                 // ... and on maps of exactly one tile with at most 40 columns x dilation (the mask head's 16 x 16 rois): per kernel COLUMN
                 const bool colm = !row && nseg == 1 && KH == 3 && stride_h == 1 && stride_w == 1 && pad_top == dil_h &&
                                   p.segOH[0] == p.segH[0] && p.segOW[0] == Wr && (long)p.segH[0] * Wr == T2 && dil_h * Wr <= 40 &&
-                                  !(p.dbg & ~(8 | 16 | 256 | 8192 | 16384 | 32768 | 131072)) &&
+                                  !(p.dbg & ~(8 | 16 | 256 | 8192 | 16384 | 32768 | 65536 | 131072)) &&
                                   sln_knob("SLN_CONV_TAPROW", 1) != 0;
                 p.tapmode = row ? 1 : colm ? 2 : 0;
                 // the register epilogue (epilogue_direct): SLN_CONV_DIRECT bit 0 the 128 x 256 kernel (above), bit 1 the
