@@ -150,6 +150,9 @@ SCALE_WINDOW = 16           # the scale follows the maximum over this many recen
 # class-logit gradient of a pyramid level depends on which anchors the step drew -- and its absolute precision floor
 # (2^-25 of the scaled range) is far below what a weight-gradient sum over 10^5 pixels resolves.  Round 5: one block of
 # that tensor clamped in one timed step of one bench run in three with the activations' 2^5 (profiles/HISTORY_r5.md).
+# (More head room is not free: an element keeps its 22 bits only down to 2^-(19 - 5 - this) of the tensor's maximum.
+# What head room cannot absorb -- a pyramid level that sees the heads' gradients once in thirty steps -- is handled by
+# link_gradient_scales below.)
 GRAD_HEADROOM_LOG2 = 3
 
 
@@ -188,6 +191,9 @@ class ScaleBook(object):
         self.headroom = torch.zeros(capacity, dtype=torch.int8, device=device)     # extra bits below SCALE_TARGET_LOG2
         self.n = 0
         self._n_written, self._n_reduced = None, False
+        # groups of GRADIENT slots that share one scale (link_gradient_scales): {sorted index tuple}; the padded
+        # [G, K] index tensor is rebuilt when a group is added
+        self.groups, self._gidx = set(), None
         self.free = []               # indices of dead slots (a heap: the lowest index is reused first, so
         #                              ranks that free the same layers reuse the same entries whatever the
         #                              order their garbage collectors ran in)
@@ -203,6 +209,9 @@ class ScaleBook(object):
             self.hist[:, idx] = 0.0
             self.cursor[idx] = 0
             self.headroom[idx] = 0
+            if any(idx in g for g in self.groups):
+                self.groups = {g for g in self.groups if idx not in g}
+                self._gidx = None
             # (the tables are only ever written by kernels; autograd has saved views of `scale` whose version
             # check must not trip over the reset of an unrelated, dead entry)
             torch._C._autograd._unsafe_set_version_counter(tables, versions)
@@ -237,6 +246,26 @@ class ScaleBook(object):
                 ops._ptr(self.amax), ops._ptr(self.scale), ops._ptr(self.hist), ops._ptr(self.cursor),
                 ops._ptr(self.headroom), self.n, self.hist.shape[1], SCALE_WINDOW, SCALE_TARGET_LOG2, ops._stream()),
                 "sln_scale_update_headroom_f32")
+            if self.groups:
+                # linked gradient slots take the SMALLEST scale of their group (the most head room): three small
+                # device-side ops, no host sync; like the kernel above they must not advance autograd's version
+                if self._gidx is None:
+                    k = max(len(g) for g in self.groups)
+                    self._gidx = torch.tensor([list(g) + [g[0]] * (k - len(g)) for g in sorted(self.groups)],
+                                              dtype=torch.int64, device=self.device)
+                v = self.scale._version
+                with torch.no_grad():
+                    m = self.scale[self._gidx].min(dim=1, keepdim=True).values.expand(self._gidx.shape)
+                    self.scale.index_put_((self._gidx,), m)
+                torch._C._autograd._unsafe_set_version_counter([self.scale], [v])
+
+    def link(self, idxs):
+        g = tuple(sorted(set(idxs)))
+        if len(g) > 1 and not any(set(g) <= set(h) for h in self.groups):
+            # (a group that grew -- a new resolution of a shared weight -- replaces its subsets)
+            self.groups = {h for h in self.groups if not set(h) <= set(g)}
+            self.groups.add(g)
+            self._gidx = None
 
     def settle(self, slot):
         """Bootstrap: slot.amax holds an exact amax pass -> its scale; clears the fresh flag."""
@@ -324,6 +353,24 @@ def _slot(owner, key):
         if key and key[0] == "gz" and GRAD_HEADROOM_LOG2:
             sl.headroom.fill_(GRAD_HEADROOM_LOG2)
     return sl
+
+
+def link_gradient_scales(owners):
+    """The GRADIENT roles ("gz") of the given layers (their weight objects) share one scale from now on: the smallest
+    of the group after every update.  For tensors whose maxima come and go TOGETHER -- the same weights applied to every
+    pyramid level (the RPN), the FPN's per-level output / lateral convolutions: whichever level a step's positive rois
+    fall on carries the mask and class gradients, thousands of times the RPN-only gradient of the other levels, so a
+    single level's own 16-step window can miss them (one bench run in five clamped 19 blocks of the finest level's
+    gradient even with 2^11 of head room) while the maximum over the levels is there in every step.  Cheap: a set
+    lookup per call once the group exists."""
+    idxs, bk = [], None
+    for o in owners:
+        for key, sl in (getattr(o, "_sln_slots", None) or {}).items():
+            if key and key[0] == "gz":
+                idxs.append(sl.idx)
+                bk = sl.book
+    if bk is not None:
+        bk.link(idxs)
 
 
 def _q3(slot):

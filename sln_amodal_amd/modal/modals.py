@@ -47,6 +47,7 @@ def roi_levels(boxes, image_shape):
 
 import os
 CHAIN_TWO_READERS = os.environ.get("SLN_CHAIN_TWO_READERS", "1") != "0"   # RPN heads (A/B switch)
+FUSE_RPN_HEADS = os.environ.get("SLN_FUSE_RPN_HEADS", "1") != "0"          # the two heads as one layer (round 5; A/B switch)
 
 class CropGradPool(object):
     """One set of P2..P5 gradient maps shared by several pyramid crops of the same maps (classifier
@@ -364,6 +365,15 @@ class FPN(nn.Module):
                     pass
         p6 = p5[:, :, ::2, ::2]  # MaxPool2d(kernel 1, stride 2) == strided subsample
         p6 = p6.contiguous(memory_format=torch.channels_last)
+        if x.is_cuda and torch.is_grad_enabled():
+            hip = nn_ops._hip_conv() if nn_ops.BACKEND in ("auto", "hip") else None
+            if hip is not None:
+                # the levels' gradients rise and fall together (whichever level the positive rois fall on): one
+                # scale per family (conv_hip.link_gradient_scales)
+                hip.link_gradient_scales([self.P5_conv2[1].weight, self.P4_conv2[1].weight, self.P3_conv2[1].weight,
+                                          self.P2_conv2[1].weight])
+                hip.link_gradient_scales([self.P5_conv1.weight, self.P4_conv1.weight, self.P3_conv1.weight,
+                                          self.P2_conv1.weight])
         return [p2, p3, p4, p5, p6]
 
 
@@ -499,6 +509,25 @@ class RPN(nn.Module):
 
     def forward(self, x, grad_inbox=None, chain_in=None):
         B = x.shape[0]
+        if FUSE_RPN_HEADS and nn_ops.conv_pair_supported(x, self.conv_class, self.conv_bbox):
+            # (round 5) the two heads as ONE pointwise layer over the concatenated weights: the 512-channel map is read
+            # once per pass instead of twice, and its gradient is ONE data gradient that the shared convolution's
+            # chained preparation takes as it stands -- at the 256^2 level the two-launch form moved 2 GB of fp32
+            # partial gradient out and back in (profiles/HISTORY_r5.md)
+            ch = {}
+            x = nn_ops.conv_bn_act(x, self.conv_shared, relu=True, same=True, chain_in=chain_in, chain_out=ch,
+                                   parts_only=True, grad_inbox=grad_inbox)
+            y = nn_ops.conv_pair(x, self.conv_class, self.conv_bbox, chain_in=ch)
+            if torch.is_grad_enabled():
+                # the same weights on every pyramid level: their gradient roles share a scale (a level that draws no
+                # anchors in a step has a gradient of ~1e-13)
+                hip = nn_ops._hip_conv()
+                hip.link_gradient_scales([nn_ops.pair_owner(self.conv_class)])
+                hip.link_gradient_scales([self.conv_shared.weight])
+            na = self.conv_class.out_channels
+            logits = y[:, :na].permute(0, 2, 3, 1).reshape(B, -1, 2)
+            bbox = y[:, na:].permute(0, 2, 3, 1).reshape(B, -1, 4)
+            return [logits, self.softmax(logits), bbox]
         # the shared map has exactly two readers (the two 1x1 heads): whichever data gradient runs second
         # adds the first one, applies the ReLU mask and hands conv_shared its prepared gradient
         ch = {"readers": 2} if CHAIN_TWO_READERS else None

@@ -15,6 +15,8 @@ Backends
 """
 import os
 
+import weakref
+
 import torch
 import torch.nn.functional as F
 
@@ -291,6 +293,53 @@ class _FpnMerge(torch.autograd.Function):
             _lib.check(_lib.lib().sln_sumpool2x2_f32(ops._ptr(gc), N, h, w, C, ops._ptr(gtop), ops._stream()),
                        "sln_sumpool2x2_f32")
         return (g if ctx.needs_input_grad[0] else None), gtop
+
+
+_PAIRS = weakref.WeakKeyDictionary()      # first head module -> (key, second head, concatenated weight, _PairConv)
+
+
+class _PairConv(object):
+    """What conv_hip.conv_bn_act reads of a convolution, for two sibling 1x1 heads run as ONE layer (conv_pair)."""
+    __slots__ = ("weight", "bias", "stride", "dilation")
+
+    def __init__(self, owner, bias):
+        self.weight, self.bias, self.stride, self.dilation = owner, bias, (1, 1), (1, 1)
+
+
+def pair_owner(a):
+    """The tensor the fused layer's scale slots live on (after conv_pair ran), else None."""
+    c = _PAIRS.get(a)
+    return None if c is None else c[3].weight
+
+
+def conv_pair_supported(x, a, b):
+    hip = _hip_conv() if BACKEND in ("auto", "hip") else None
+    return (hip is not None and x.is_cuda and CALIBRATING is None and hip.PARTS == 2 and
+            a.kernel_size == (1, 1) and b.kernel_size == (1, 1) and a.stride == (1, 1) and b.stride == (1, 1) and
+            a.padding == (0, 0) and b.padding == (0, 0) and a.groups == 1 and b.groups == 1 and
+            a.in_channels == b.in_channels and a.in_channels % 8 == 0 and (a.bias is None) == (b.bias is None))
+
+
+def conv_pair(x, a, b, chain_in=None):
+    """Two pointwise convolutions that read the same x (the RPN's class and box heads, modals.py:361-412), as ONE
+    layer with the concatenated weights: x's parts are read once instead of twice forward and in the weight gradient,
+    and ONE data gradient w.r.t. x is produced (no fp32 partial gradient written by one head and re-read by the
+    other).  Returns [B, Ca + Cb, H, W]; the caller slices.  The concatenation is an autograd op: each parameter
+    receives its rows of the weight gradient.  HIP backend, fp16 x 2 operands (conv_pair_supported)."""
+    hip = _hip_conv()
+    key = (hip.SCALE_EPOCH[0], a.weight._version, b.weight._version, torch.is_grad_enabled(), x.device,
+           None if a.bias is None else (a.bias._version, b.bias._version))
+    c = _PAIRS.get(a)
+    if c is None or c[0] != key or c[1]() is not b:
+        w = torch.cat([a.weight, b.weight], 0)
+        bias = None if a.bias is None else torch.cat([a.bias, b.bias], 0)
+        own = None if c is None else c[3].weight
+        if own is None or own.device != x.device or tuple(own.shape) != tuple(w.shape):
+            # the fused layer's scale slots live on a tensor of its own (never on a head's weight: the heads may also
+            # run alone, with other tensor roles)
+            own = torch.empty(w.shape, device=x.device)
+        c = _PAIRS[a] = (key, weakref.ref(b), w, _PairConv(own, bias))      # (outside the module: it stays deep-copyable)
+    return hip.conv_bn_act(x, c[3], None, False, None, (0, 0, 0, 0), weight=c[2], chain_in=chain_in)
 
 
 def upsample2x_add(lateral, top):

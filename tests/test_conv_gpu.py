@@ -393,15 +393,17 @@ def test_tile256_kernel_is_deterministic_and_agrees_with_tile128(shape, tile_mod
     assert err < 2e-6, err
 
 
-def test_two_reader_chain_of_the_rpn_heads_matches_autograd_accumulation():
+def test_two_reader_chain_of_the_rpn_heads_matches_autograd_accumulation(monkeypatch):
     """RPN: the shared 3x3 map is read by the class and the box head.  Whichever data gradient runs
     second adds the first (as the epilogue's residual), applies the shared conv's ReLU mask and hands it
     its prepared gradient; both heads return None to autograd.  One fp32 addition per element either
     way: the gradient reaching the RPN's input is bit-identical, bias / weight gradients differ by
     summation order only."""
     from sln_amodal_amd import conv_hip
+    from sln_amodal_amd.modal import modals
     from sln_amodal_amd.modal.modals import RPN
     from tests._util import key_init_
+    monkeypatch.setattr(modals, "FUSE_RPN_HEADS", False)        # (the two heads as two layers: the path this test pins)
     rpn = RPN(3, 1, 64).cuda()
     key_init_(rpn)
     g = torch.Generator().manual_seed(21)
@@ -431,6 +433,61 @@ def test_two_reader_chain_of_the_rpn_heads_matches_autograd_accumulation():
     for k in res[True][3]:
         a, b = res[True][3][k], res[False][3][k]
         assert torch.allclose(a, b, rtol=1e-4, atol=1e-5 * float(b.abs().max()) + 1e-7), k
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 19, 23), (1, 256, 128, 128), (3, 72, 16, 40)])
+def test_rpn_heads_as_one_layer_equal_the_two_layer_form(shape, monkeypatch):
+    """modals.FUSE_RPN_HEADS: the class and the box head run as ONE pointwise layer over the concatenated weights
+    (nn_ops.conv_pair).  Every output channel is the same dot product in the same order: logits and deltas are
+    bit-identical to the two-layer form; the gradient w.r.t. the RPN's input and the shared convolution's parameters sum
+    the two heads' contributions inside one GEMM instead of two GEMMs and an addition (2e-6 of their scale), the heads'
+    own parameter gradients are the rows of one weight gradient (same sums: 1e-6), and fp64 autograd of the unfused
+    module bounds both forms at the file's 2e-5.  One gradient preparation is chained in either form."""
+    from sln_amodal_amd import conv_hip
+    from sln_amodal_amd.modal import modals
+    from sln_amodal_amd.modal.modals import RPN
+    from tests._util import key_init_
+    B, C, H, W = shape
+    rpn = RPN(3, 1, C).cuda()
+    key_init_(rpn)
+    g = torch.Generator().manual_seed(C + H)
+    x0 = torch.randn(B, C, H, W, generator=g).cuda().contiguous(memory_format=torch.channels_last)
+    up_l = torch.randn(B, H * W * 3, 2, generator=g).cuda()
+    up_b = torch.randn(B, H * W * 3, 4, generator=g).cuda()
+    res = {}
+    for fused in (False, True):
+        monkeypatch.setattr(modals, "FUSE_RPN_HEADS", fused)
+        for it in range(2):                          # (the first pass of a form bootstraps its scale slots)
+            conv_hip.update_scales(sync=False)
+            conv_hip.CHAIN_STATS[:] = [0, 0]
+            x = x0.clone().requires_grad_(True)
+            rpn.zero_grad(set_to_none=True)
+            logits, probs, bbox = rpn(x)
+            ((logits * up_l).sum() + (bbox * up_b).sum()).backward()
+        assert conv_hip.CHAIN_STATS == [1, 1], (fused, conv_hip.CHAIN_STATS)
+        res[fused] = (logits.detach().clone(), bbox.detach().clone(), probs.detach().clone(), x.grad.clone(),
+                      {k: p.grad.clone() for k, p in rpn.named_parameters()})
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+    assert torch.equal(res[True][2], res[False][2])
+    rel = lambda a, b: float((a.double() - b.double()).abs().max() / b.double().abs().max())
+    assert rel(res[True][3], res[False][3]) <= 2e-6, rel(res[True][3], res[False][3])
+    assert set(res[True][4]) == set(res[False][4]) and len(res[True][4]) == 6
+    for k in res[True][4]:
+        tol = 2e-6 if k.startswith("conv_shared") else 1e-6
+        assert rel(res[True][4][k], res[False][4][k]) <= tol, (k, rel(res[True][4][k], res[False][4][k]))
+    # fp64 autograd of the module's arithmetic
+    import copy
+    ref = copy.deepcopy(rpn).double()
+    from sln_amodal_amd import nn_ops
+    monkeypatch.setattr(nn_ops, "BACKEND", "torch")
+    xd = x0.double().requires_grad_(True)
+    ref.zero_grad(set_to_none=True)
+    lg, _, bb = ref(xd)
+    ((lg * up_l.double()).sum() + (bb * up_b.double()).sum()).backward()
+    l2 = lambda a, b: float((a.double() - b).norm() / b.norm())
+    assert l2(res[True][3], xd.grad) < 2e-5
+    for k, p in ref.named_parameters():
+        assert l2(res[True][4][k], p.grad) < 2e-5, (k, l2(res[True][4][k], p.grad))
 
 
 # ------------------------------------------------- scaled split-fp16 operands (PARTS = 2)
@@ -748,6 +805,56 @@ def test_gradient_roles_carry_extra_head_room(monkeypatch):
     assert float((got.double() - wr.grad).norm() / wr.grad.norm()) < 2e-5
     got = step(up * 1e5)                            # ... 1000 x the window's maximum: beyond the head room it clamps and counts, without inf
     assert conv_hip.saturation_count() > sat0 and bool(torch.isfinite(got).all())
+
+
+def test_linked_gradient_scales_follow_the_largest_member(monkeypatch):
+    """conv_hip.link_gradient_scales: the gradient roles of sibling layers (the FPN's per-level convolutions, the RPN's
+    weights on every level) share the smallest scale of the group.  Two layers, one fed gradients 10^4 x the other's:
+    after linking both scales are the large one's; when the small layer then receives the large gradient for the first
+    time it is split without a clamp (alone it would have been 10^4 x above its own window) and its weight gradient is
+    fp32-class; activations' scales are untouched."""
+    from sln_amodal_amd import conv_hip
+    monkeypatch.setattr(conv_hip, "PARTS", 2)
+    g = torch.Generator(device="cuda").manual_seed(9)
+    x = torch.randn(2, 64, 32, 32, device="cuda", generator=g).contiguous(memory_format=torch.channels_last)
+    ws = [(torch.randn(64, 64, 3, 3, device="cuda", generator=g) / 24.0).requires_grad_(True) for _ in range(2)]
+    up = torch.randn(2, 64, 32, 32, device="cuda", generator=g).contiguous(memory_format=torch.channels_last)
+
+    def step(gains):
+        conv_hip.update_scales(sync=False)
+        out = []
+        for w, gain in zip(ws, gains):
+            w.grad = None
+            y = conv_hip._ConvFn.apply(x, w, None, None, None, None, False, (1, 1), (1, 1), (1,) * 4)
+            y.backward(up * gain)
+            out.append(w.grad.clone())
+        return out
+
+    step((1e4, 1.0))
+    step((1e4, 1.0))
+    gz = [w._sln_slots[("gz", 32, 32)] for w in ws]
+    conv_hip.update_scales(sync=False)
+    assert float(gz[1].scale) > 1000 * float(gz[0].scale)
+    xs = [float(w._sln_slots[("x", 32, 32)].scale) if ("x", 32, 32) in w._sln_slots else None for w in ws]
+    conv_hip.link_gradient_scales(ws)
+    conv_hip.update_scales(sync=False)
+    assert float(gz[1].scale) == float(gz[0].scale)
+    assert xs == [float(w._sln_slots[("x", 32, 32)].scale) if ("x", 32, 32) in w._sln_slots else None for w in ws]
+    sat0 = conv_hip.saturation_count()
+    got = step((1e4, 1e4))[1]
+    assert conv_hip.saturation_count() == sat0
+    wr = ws[1].detach().double().requires_grad_(True)
+    F.conv2d(x.double(), wr, None, 1, 1).backward(up.double() * 1e4)
+    assert float((got.double() - wr.grad).norm() / wr.grad.norm()) < 2e-5
+    # a member that dies takes its group along (its table entry is recycled for another tensor)
+    bk, dead = gz[0].book, gz[1].idx
+    assert any(dead in h for h in bk.groups)
+    del gz, got, wr
+    ws.pop()
+    import gc
+    gc.collect()
+    fresh = [conv_hip._slot(torch.zeros(1, device="cuda"), ("probe", i)) for i in range(8)]      # reuses freed entries
+    assert dead in [f.idx for f in fresh] and not any(dead in h for h in bk.groups)
 
 
 def test_deferred_reduce_and_side_stream_weight_gradients_equal_the_plain_ones(monkeypatch):
