@@ -86,7 +86,7 @@ def measure(dev, B=16, replay_traffic=True):
         import json
         import os
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-        rel = os.path.join("profiles", "r5_v_pmc_roialign.json")
+        rel = os.path.join("profiles", "r5_ai_pmc_roialign.json")
         pk = json.load(open(os.path.join(root, rel)))["pyr_bwd_patch_kernel"]
         by_meas = pk["fetch_bytes_per_launch_x2"] + pk["write_bytes_per_launch"]
         gbs = by_meas / (0.5 * (tk + tk7)) / 1e9
