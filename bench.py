@@ -786,15 +786,15 @@ def main():
             from tools import kernel_roofline
             out["roofline_kernels"] = kernel_roofline.measure(dev, replay_traffic=headline)
             rk = out["roofline_kernels"]
-            # RoIAlign next to the dominant kernel, as scalars: the fraction of the 20 / 36 B-per-element MODEL the
-            # survey defines, and the bandwidth the op really moved (measured FETCH_SIZE + WRITE_SIZE of the
-            # committed counter pass over the live duration): a model fraction above 1 is cache-absorbed atomics
+            # RoIAlign next to the dominant kernel, as scalars.  The backward's leading figure is the MEASURED
+            # fraction of the HBM roof (FETCH_SIZE x 2 + WRITE_SIZE of the committed counter pass over the live
+            # duration; null outside the problem the pass was collected on); the 36 B / element model over-counts
+            # (cache-absorbed atomics: above 1 for the scatter kernel alone) and is named as a model.
             out["roofline"].update({
                 "roialign_fwd_frac_of_20B_model": rk["roialign_fwd"]["frac"],
-                "roialign_bwd_frac_of_36B_model": rk["roialign_bwd"]["frac"],
-                "roialign_bwd_scatter_only_frac_of_36B_model": rk["roialign_bwd"]["scatter_kernel_only_frac"],
-                "roialign_bwd_measured_hbm_gbs": rk["roialign_bwd"].get("measured_hbm_gbs"),
-                "roialign_bwd_measured_hbm_frac": rk["roialign_bwd"].get("measured_hbm_frac"),
+                "roialign_bwd_measured_hbm_frac": rk["roialign_bwd"]["measured_hbm_frac"],
+                "roialign_bwd_measured_hbm_gbs": rk["roialign_bwd"]["measured_hbm_gbs"],
+                "roialign_bwd_whole_op_frac_of_36B_model": rk["roialign_bwd"]["model_frac_whole_op"],
                 "nms_us_per_image": rk["nms"]["us_per_image"]})
         except Exception as e:  # pragma: no cover
             out["roofline_kernels"] = {"error": str(e)[:200]}

@@ -188,6 +188,7 @@ class ScaleBook(object):
         self.cursor = torch.zeros(capacity, dtype=torch.int32, device=device)
         # one clamp counter PER SLOT (round 5: the bench line says which tensor role clamped, and in which step)
         self.saturated = torch.zeros(capacity, dtype=torch.int32, device=device)
+        self.retired_saturated = torch.zeros((), dtype=torch.int64, device=device)    # clamp counts of dead slots
         self.headroom = torch.zeros(capacity, dtype=torch.int8, device=device)     # extra bits below SCALE_TARGET_LOG2
         self.n = 0
         self._n_written, self._n_reduced = None, False
@@ -202,8 +203,13 @@ class ScaleBook(object):
     def new_slot(self):
         if self.free:                        # an entry whose layer has died: back to the initial state
             idx = heapq.heappop(self.free)
-            tables = [self.amax, self.scale, self.hist, self.cursor]
+            tables = [self.amax, self.scale, self.hist, self.cursor, self.saturated, self.retired_saturated]
             versions = [t._version for t in tables]
+            #  the dead role's clamp count moves to the book's retired total: the recycled slot starts at
+            # zero (saturation_report attributes nothing of the old role to the new one), the process total stays
+            self.retired_saturated += self.saturated[idx]
+            self.saturated[idx] = 0
+            self.names.pop(idx, None)
             self.amax[idx] = 0.0
             self.scale[idx] = 1.0
             self.hist[:, idx] = 0.0
@@ -228,36 +234,53 @@ class ScaleBook(object):
         function bit for bit (a rank-local power of two would round the fp16 parts differently).
         sync=False (inference / validation forwards, which one rank may run alone): no collective."""
         if self.n:
-            import torch.distributed as dist
-            if sync and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-                # ONE fixed-size collective over the whole table (128 KB), whatever the ranks' slot counts: its
-                # last two entries carry (n, -n), so that ranks which built different graphs -- whose
-                # element-wise MAX would mix unrelated tensors -- are found by check_ranks() instead of
-                # hanging in a collective of mismatched sizes
-                if self._n_written != self.n:
-                    v = self.amax._version
-                    self.amax[-2] = float(self.n)
-                    self.amax[-1] = -float(self.n)
-                    torch._C._autograd._unsafe_set_version_counter([self.amax], [v])
-                    self._n_written = self.n
-                dist.all_reduce(self.amax, op=dist.ReduceOp.MAX)
-                self._n_reduced = True
+            if sync:
+                self.exchange_amax()
             _lib.check(_lib.lib().sln_scale_update_headroom_f32(
                 ops._ptr(self.amax), ops._ptr(self.scale), ops._ptr(self.hist), ops._ptr(self.cursor),
                 ops._ptr(self.headroom), self.n, self.hist.shape[1], SCALE_WINDOW, SCALE_TARGET_LOG2, ops._stream()),
                 "sln_scale_update_headroom_f32")
-            if self.groups:
-                # linked gradient slots take the SMALLEST scale of their group (the most head room): three small
-                # device-side ops, no host sync; like the kernel above they must not advance autograd's version
-                if self._gidx is None:
-                    k = max(len(g) for g in self.groups)
-                    self._gidx = torch.tensor([list(g) + [g[0]] * (k - len(g)) for g in sorted(self.groups)],
-                                              dtype=torch.int64, device=self.device)
-                v = self.scale._version
-                with torch.no_grad():
-                    m = self.scale[self._gidx].min(dim=1, keepdim=True).values.expand(self._gidx.shape)
-                    self.scale.index_put_((self._gidx,), m)
-                torch._C._autograd._unsafe_set_version_counter([self.scale], [v])
+            self.apply_groups()
+
+    def apply_groups(self):
+        """Linked gradient slots take the SMALLEST scale of their group (the most head room): three small device-side
+        ops, no host sync; like the update kernel they must not advance autograd's version.  Pure torch."""
+        if not self.groups:
+            return
+        if self._gidx is None:
+            k = max(len(g) for g in self.groups)
+            self._gidx = torch.tensor([list(g) + [g[0]] * (k - len(g)) for g in sorted(self.groups)],
+                                      dtype=torch.int64, device=self.device)
+        v = self.scale._version
+        with torch.no_grad():
+            # (ADVICE r5) only members WITH A HISTORY take part: a slot created and linked by a forward whose
+            # backward never ran (a loss evaluation, a predict(mode='training') without backward) still holds
+            # the table default 1.0 -- taken into the minimum it would drag every linked gradient scale down
+            # to 1.0, where gradients of ~1e-6 underflow, for the life of the model (its amax stays 0, so it
+            # never settles by itself).  Such members neither contribute nor are overwritten.
+            sc = self.scale[self._gidx]
+            settled = self.hist[:, self._gidx.flatten()].amax(dim=0).view_as(sc) > 0
+            m = torch.where(settled, sc, torch.full_like(sc, float("inf"))).min(dim=1, keepdim=True).values
+            self.scale.index_put_((self._gidx,), torch.where(settled, m.expand_as(sc), sc))
+        torch._C._autograd._unsafe_set_version_counter([self.scale], [v])
+
+    def exchange_amax(self):
+        """Data-parallel half of update(): the MAX all-reduce of the amax table (pure torch: the world-8 gloo test
+        on CPU runs exactly this).  ONE fixed-size collective over the whole table (128 KB), whatever the ranks'
+        slot counts: its last two entries carry (n, -n), so that ranks which built different graphs -- whose
+        element-wise MAX would mix unrelated tensors -- are found by check_ranks() instead of hanging in a
+        collective of mismatched sizes."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            return
+        if self._n_written != self.n:
+            v = self.amax._version
+            self.amax[-2] = float(self.n)
+            self.amax[-1] = -float(self.n)
+            torch._C._autograd._unsafe_set_version_counter([self.amax], [v])
+            self._n_written = self.n
+        dist.all_reduce(self.amax, op=dist.ReduceOp.MAX)
+        self._n_reduced = True
 
     def link(self, idxs):
         g = tuple(sorted(set(idxs)))
@@ -316,7 +339,7 @@ def check_ranks():
 
 def saturation_count():
     """Blocks that clamped a value to +-65504 since the start (host sync; tests / monitoring)."""
-    return sum(int(b.saturated.sum().item()) for b in _books.values())
+    return sum(int(b.saturated.sum().item()) + int(b.retired_saturated.item()) for b in _books.values())
 
 
 def saturation_snapshot():
@@ -333,7 +356,7 @@ def saturation_report(before=None, after=None):
         cur = (after[i] if after is not None else b.saturated).cpu()
         if before is not None and i in before:
             cur = cur - before[i].cpu()
-        for idx in torch.nonzero(cur).flatten().tolist():
+        for idx in torch.nonzero(cur > 0).flatten().tolist():      # (a slot recycled in between reads negative)
             key, shape = b.names.get(idx, (("?",), ()))
             out.append(("/".join(str(k) for k in key), list(shape), int(cur[idx])))
     return out

@@ -79,12 +79,11 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 // production body (round 4; SQ_LDS_BANK_CONFLICT in profiles/).  Bits 1..2 are conflict-free for the 16x16x32 read at
 // any row offset and 2-way for the diagnostic 32x32x16 body.
 #define SLN_SWZH(r) (((r) >> 1) & 3)
-// The WEIGHT stage images take row bits 1 and 3 instead (round 5).  The register epilogue (epilogue_direct) reads the
-// rows of a weight tile in the order 0-3, 8-11, 16-19, 24-27 (+4): with bits 1..2 those rows repeat the same two
-// swizzle values and every ds_read_b128 group is 2-way conflicted; bits 1 and 3 are conflict-free for that order AND
-// for the plain 16 consecutive rows of the LDS-staged epilogues (simulated with the guide's four 16-lane groups;
-// tools/lds_swizzle_sim.py).  Written by split_weights_tiledh_kernel / split_weights_batch_kernel, read by every
-// B-fragment address of conv_fwd256h_kernel and conv_fwd128x256h_kernel.
+// The WEIGHT stage images take row bits 1 and 3 instead (round 5): conflict-free for the plain 16 consecutive rows of a
+// fragment read (and for the permuted row order of round 5's register epilogue, measured not faster and removed in
+// round 6: profiles/HISTORY_r5.md; simulated with the guide's four 16-lane groups, tools/lds_swizzle_sim.py).  Written
+// by split_weights_tiledh_kernel / split_weights_batch_kernel, read by every B-fragment address of conv_fwd256h_kernel
+// and conv_fwd128x256h_kernel.
 #define SLN_SWZW(r) ((((r) >> 1) & 1) | ((((r) >> 3) & 1) << 1))
 #ifndef SLN_W8_DEPTH
 #define SLN_W8_DEPTH 2      // half slabs of residual / mask rows in flight ahead, single-epilogue instances of the 256^2 kernel
@@ -1936,193 +1935,6 @@ __device__ __forceinline__ void mfma16_products(const bf16x8 (&a)[2], const bf16
     c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b0, c, 0, 0, 0);
 }
 
-// The same three products with the WEIGHTS as the A operand: D = [output channel][pixel], the transposed tile -- a
-// lane then holds four consecutive output CHANNELS of one pixel (epilogue_direct).  Same products in the same
-// order: the accumulators hold the same bits as mfma16_products', transposed.
-__device__ __forceinline__ void mfma16_products_t(const bf16x8 (&x)[2], const bf16x8 (&w)[2], f32x4v &c) {
-    const h16x8 x0 = __builtin_bit_cast(h16x8, x[0]), x1 = __builtin_bit_cast(h16x8, x[1]);
-    const h16x8 w0 = __builtin_bit_cast(h16x8, w[0]), w1 = __builtin_bit_cast(h16x8, w[1]);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0, x1, c, 0, 0, 0);      // smallest terms first
-    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1, x0, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0, x0, c, 0, 0, 0);
-}
-
-// MEASURED AND SWITCHED OFF (profiles/r5_e_ab_register_epilogue.txt, same box, 16 x 1024^2 train step): bit-identical
-// to the LDS-staged slabs on all three kernels (tests/test_conv_gpu.py, 288 cases) but not faster -- the plain 256^2
-// instances +0.04 %, the tap-row instances -0.7 %, the 128 x 256 kernel -14 % on its own launches (204 -> 175 TFLOP/s,
-// -1.6 % on the step): a store or load instruction of this layout touches 16 pixels x 64 B (a part) or 16 half-filled
-// lines (fp32) where the staged slabs touch 8 whole 128-B lines per instruction, which costs what the eight barriers
-// and the LDS round trip cost; and the 128 x 256 kernel already hides its staged epilogue under the other resident
-// block's k-loop.  The instances are compiled only with -DSLN_BUILD_DIRECT=1 (then SLN_CONV_DIRECT = 1 | 2 | 4 selects
-// the 128 x 256 / plain / tap-row instances).
-#ifndef SLN_BUILD_DIRECT
-#define SLN_BUILD_DIRECT 0
-#endif
-// Register epilogue (round 5): the eight-channel tile epilogue WITHOUT the LDS staging.  The LDS-staged epilogues
-// exist because the C layout of v_mfma_f32_16x16x32_f16 hands a lane four consecutive ROWS of one column; staging a
-// 256 x 256 tile through LDS behind eight barriers is 26 % of a K = 256 pointwise launch (profiles/
-// r4_f_epilogue_ablation.txt: 0.042 of 0.163 ms).  With the operands swapped (mfma16_products_t) a lane of tile
-// (pixel tile i, channel tile j) holds pixel 16 i + lane % 16 and channels 4 (lane / 16) + r of the tile, and with
-// the weight rows of each 32-row group read in the order 8 (m / 4) + 4 (j % 2) + m % 4 (b_off16) the tiles 2 jj and
-// 2 jj + 1 give the lane EIGHT consecutive channels c = 32 jj + 8 (lane / 16) + e: the same 16-B part stores and
-// 2 x 16-B fp32 stores per eight outputs as epilogue_tile_w8, straight from the accumulators, wave by wave, no barrier.
-// Per instruction the four lanes of a pixel cover 32 consecutive channels (128 B of fp32, 64 B of a part) and the 16
-// pixels of the tile lie one output row apart.  Same arithmetic per element as w8_compute (bit-identical y and parts).
-// acc[i][j]: the wave's NI pixel tiles x 4 channel tiles; m_wave / n_wave: its first pixel / channel.
-template <int NI, int RES, int MASK, bool FULL>
-__device__ __forceinline__ void epilogue_direct(const ConvParams &p, const f32x4v (&acc)[NI][4], int m_wave,
-                                                int n_wave, int lane, float *s_colsum_wave, float alpha, float yqs,
-                                                float &amx) {
-    const int q = lane >> 4, r16 = lane & 15;
-    float sc[2][8], sf[2][8];
-    bool cok[2];
-#pragma unroll
-    for (int jj = 0; jj < 2; ++jj) {
-        const int c = n_wave + 32 * jj + 8 * q;
-        cok[jj] = FULL || c < p.Cout;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { sc[jj][e] = alpha; sf[jj][e] = 0.f; }
-        if (cok[jj] && p.scale) {
-            const float4 s0 = *(const float4 *)(p.scale + c), s1 = *(const float4 *)(p.scale + c + 4);
-            sc[jj][0] = s0.x * alpha; sc[jj][1] = s0.y * alpha; sc[jj][2] = s0.z * alpha; sc[jj][3] = s0.w * alpha;
-            sc[jj][4] = s1.x * alpha; sc[jj][5] = s1.y * alpha; sc[jj][6] = s1.z * alpha; sc[jj][7] = s1.w * alpha;
-        }
-        if (cok[jj] && p.shift) {
-            const float4 s0 = *(const float4 *)(p.shift + c), s1 = *(const float4 *)(p.shift + c + 4);
-            sf[jj][0] = s0.x; sf[jj][1] = s0.y; sf[jj][2] = s0.z; sf[jj][3] = s0.w;
-            sf[jj][4] = s1.x; sf[jj][5] = s1.y; sf[jj][6] = s1.z; sf[jj][7] = s1.w;
-        }
-    }
-    const float rinv = (RES == 2) ? 1.0f / (p.res_scale ? *p.res_scale : 1.f) : 1.f;
-    const bool relu = p.relu != 0;
-    float csum[2][8];
-#pragma unroll
-    for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) csum[jj][e] = 0.f;
-    // what an (i, jj) step reads besides its accumulators, requested one step ahead
-    struct Pre { float4 ra, rb; h16x8_t rp0, rp1, m16; };
-    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    const h16x8_t z8 = {};
-    auto fetch = [&](int step, Pre &pre) {
-        const int i = step >> 1, jj = step & 1;
-        const int m = m_wave + 16 * i + r16;
-        const bool ok = cok[jj] && (FULL || m < p.M);
-        const long o = (long)m * p.Cout + n_wave + 32 * jj + 8 * q;
-        if (RES == 1) {
-            pre.ra = ok ? *(const float4 *)(p.residual + o) : z4;
-            pre.rb = ok ? *(const float4 *)(p.residual + o + 4) : z4;
-        }
-        if (RES == 2) {
-            pre.rp0 = ok ? *(const h16x8_t *)(p.res_parts + o) : z8;
-            pre.rp1 = ok ? *(const h16x8_t *)(p.res_parts + p.y_part_stride + o) : z8;
-        }
-        if (MASK == 2) pre.m16 = ok ? *(const h16x8_t *)(p.mask_part0 + o) : z8;
-    };
-    constexpr bool HAS_PRE = RES != 0 || MASK != 0;
-    Pre pre[2];
-    if (HAS_PRE) fetch(0, pre[0]);
-#pragma unroll
-    for (int step = 0; step < 2 * NI; ++step) {
-        const int i = step >> 1, jj = step & 1;
-        if (HAS_PRE && step + 1 < 2 * NI) fetch(step + 1, pre[(step + 1) & 1]);
-        const Pre &pr = pre[step & 1];
-        const int m = m_wave + 16 * i + r16;
-        const bool ok = cok[jj] && (FULL || m < p.M);
-        const long o = (long)m * p.Cout + n_wave + 32 * jj + 8 * q;
-        const f32x4v a0 = acc[i][2 * jj], a1 = acc[i][2 * jj + 1];
-        float v[8] = {a0[0] * sc[jj][0] + sf[jj][0], a0[1] * sc[jj][1] + sf[jj][1], a0[2] * sc[jj][2] + sf[jj][2],
-                      a0[3] * sc[jj][3] + sf[jj][3], a1[0] * sc[jj][4] + sf[jj][4], a1[1] * sc[jj][5] + sf[jj][5],
-                      a1[2] * sc[jj][6] + sf[jj][6], a1[3] * sc[jj][7] + sf[jj][7]};
-        if (RES == 1) {
-            v[0] += pr.ra.x; v[1] += pr.ra.y; v[2] += pr.ra.z; v[3] += pr.ra.w;
-            v[4] += pr.rb.x; v[5] += pr.rb.y; v[6] += pr.rb.z; v[7] += pr.rb.w;
-        }
-        if (RES == 2) {
-            const h16x8_t b0 = pr.rp0, b1 = pr.rp1;
-            v[0] += ((float)b0.s0 + (float)b1.s0) * rinv; v[1] += ((float)b0.s1 + (float)b1.s1) * rinv;
-            v[2] += ((float)b0.s2 + (float)b1.s2) * rinv; v[3] += ((float)b0.s3 + (float)b1.s3) * rinv;
-            v[4] += ((float)b0.s4 + (float)b1.s4) * rinv; v[5] += ((float)b0.s5 + (float)b1.s5) * rinv;
-            v[6] += ((float)b0.s6 + (float)b1.s6) * rinv; v[7] += ((float)b0.s7 + (float)b1.s7) * rinv;
-        }
-        if (relu) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-        }
-        if (MASK == 2) {
-            const h16x8_t k8 = pr.m16;
-            if (!(k8.s0 > (_Float16)0)) v[0] = 0.f;
-            if (!(k8.s1 > (_Float16)0)) v[1] = 0.f;
-            if (!(k8.s2 > (_Float16)0)) v[2] = 0.f;
-            if (!(k8.s3 > (_Float16)0)) v[3] = 0.f;
-            if (!(k8.s4 > (_Float16)0)) v[4] = 0.f;
-            if (!(k8.s5 > (_Float16)0)) v[5] = 0.f;
-            if (!(k8.s6 > (_Float16)0)) v[6] = 0.f;
-            if (!(k8.s7 > (_Float16)0)) v[7] = 0.f;
-        }
-        if (p.y && ok) {
-            *(float4 *)(p.y + o) = make_float4(v[0], v[1], v[2], v[3]);
-            *(float4 *)(p.y + o + 4) = make_float4(v[4], v[5], v[6], v[7]);
-        }
-        if (p.post_scale) {
-            // rounded to fp32 before the split (no contraction into split4's subtraction): the same value
-            // sln_conv_grad_prep_f32 would split
-            const int c = n_wave + 32 * jj + 8 * q;
-            float ps8[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
-            if (cok[jj]) {
-                const float4 s0 = *(const float4 *)(p.post_scale + c), s1 = *(const float4 *)(p.post_scale + c + 4);
-                ps8[0] = s0.x; ps8[1] = s0.y; ps8[2] = s0.z; ps8[3] = s0.w;
-                ps8[4] = s1.x; ps8[5] = s1.y; ps8[6] = s1.z; ps8[7] = s1.w;
-            }
-            {
-#pragma clang fp contract(off)
-                v[0] = v[0] * ps8[0]; v[1] = v[1] * ps8[1]; v[2] = v[2] * ps8[2]; v[3] = v[3] * ps8[3];
-                v[4] = v[4] * ps8[4]; v[5] = v[5] * ps8[5]; v[6] = v[6] * ps8[6]; v[7] = v[7] * ps8[7];
-            }
-        }
-        if (!ok) {          // (rows / columns outside the output take no part in sums, maxima or stores)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = 0.f;
-        }
-        if (p.colsum) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) csum[jj][e] += v[e];
-        }
-        if (p.yparts) {
-            const float rmax = amax8(v);
-            amx = fmaxf(amx, rmax);
-            bf16x4 lo[2], hi[2];
-            if (__builtin_amdgcn_ballot_w64(rmax * yqs > SLN_F16_MAX) == 0) {      // the wave's values in range
-                split4_inrange(make_float4(v[0], v[1], v[2], v[3]), lo, yqs);
-                split4_inrange(make_float4(v[4], v[5], v[6], v[7]), hi, yqs);
-            } else {
-                (void)split4<2>(make_float4(v[0], v[1], v[2], v[3]), lo, yqs);
-                (void)split4<2>(make_float4(v[4], v[5], v[6], v[7]), hi, yqs);
-            }
-            bf16x8 w0, w1;
-            w0.s0 = lo[0].x; w0.s1 = lo[0].y; w0.s2 = lo[0].z; w0.s3 = lo[0].w;
-            w0.s4 = hi[0].x; w0.s5 = hi[0].y; w0.s6 = hi[0].z; w0.s7 = hi[0].w;
-            w1.s0 = lo[1].x; w1.s1 = lo[1].y; w1.s2 = lo[1].z; w1.s3 = lo[1].w;
-            w1.s4 = hi[1].x; w1.s5 = hi[1].y; w1.s6 = hi[1].z; w1.s7 = hi[1].w;
-            if (ok) {
-                *(bf16x8 *)(p.yparts + o) = w0;
-                *(bf16x8 *)(p.yparts + p.y_part_stride + o) = w1;
-            }
-        }
-    }
-    if (p.colsum) {      // the 16 lanes of a quarter hold the same channels for different pixels: combine, then LDS
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float a = csum[jj][e];
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) a += __shfl_xor(a, o);
-                if (r16 == 0 && a != 0.f) atomicAdd(&s_colsum_wave[32 * jj + 8 * q + e], a);
-            }
-    }
-}
-
 // EPI: which epilogue the instance carries.  0 = all of them, chosen at run time (diagnostic builds, odd shapes);
 // 1 / 2 / 3 / 4 / 5 = ONLY the eight-channel tile epilogue without operands / with the shortcut from its parts / with
 // the ReLU pattern from part 0 / fp32 residual + that pattern / fp32 residual -- the launcher knows which a launch needs.  One variant per instance instead of
@@ -2140,10 +1952,9 @@ __device__ __forceinline__ void epilogue_direct(const ConvParams &p, const f32x4
 // Stage order (64-channel group, kh, half, kw) instead of (group, tap, half): same products, another fp32 summation
 // order.  Launcher: one image group, KW == 3, stride 1, pad_left == dil_w <= 8, OW == W in {32, 64, 128, 256},
 // M % 256 == 0.
-template <bool STAMP, int NPH, int MS = 32, int EPI = 0, bool ROW = false, bool DIRECT = false>
+template <bool STAMP, int NPH, int MS = 32, int EPI = 0, bool ROW = false>
 __global__ __launch_bounds__(512) void conv_fwd256h_kernel(const ConvParams p) {
     constexpr int P = 2;
-    static_assert(!DIRECT || (MS == 16 && EPI > 0 && !STAMP), "register epilogue: the 16x16x32 body, one epilogue kind");
     static_assert(MS == 32 || (MS == 16 && NPH == 2), "the 16x16x32 body is written for two phases per stage");
     static_assert(!ROW || (MS == 16 && !STAMP), "tap-row stages: the 16x16x32 body, no stamps");
     unsigned long long sums[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -2307,10 +2118,7 @@ __global__ __launch_bounds__(512) void conv_fwd256h_kernel(const ConvParams p) {
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            // (DIRECT: the rows of a 32-row group in the order that gives a lane 8 consecutive output channels from
-            // tiles 2jj and 2jj + 1, see epilogue_direct)
-            const int row = DIRECT ? 64 * wc + 32 * (j >> 1) + 8 * (r16 >> 2) + 4 * (j & 1) + (r16 & 3)
-                                   : 64 * wc + 16 * j + r16;
+            const int row = 64 * wc + 16 * j + r16;
             b_off16[j] = row * 64 + ((c16 ^ SLN_SWZW(row)) * 16);
         }
     }
@@ -2501,10 +2309,8 @@ __global__ __launch_bounds__(512) void conv_fwd256h_kernel(const ConvParams p) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        if (DIRECT) mfma16_products_t(a[i], b16[j], acc16[4 * ph + i][j]);
-                        else mfma16_products(a[i], b16[j], acc16[4 * ph + i][j]);
-                    }
+                    for (int j = 0; j < 4; ++j) 
+                        mfma16_products(a[i], b16[j], acc16[4 * ph + i][j]);
                 __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
@@ -2640,10 +2446,8 @@ __global__ __launch_bounds__(512) void conv_fwd256h_kernel(const ConvParams p) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        if (DIRECT) mfma16_products_t(a[i], b16[j], acc16[4 * ph + i][j]);
-                        else mfma16_products(a[i], b16[j], acc16[4 * ph + i][j]);
-                    }
+                    for (int j = 0; j < 4; ++j) 
+                        mfma16_products(a[i], b16[j], acc16[4 * ph + i][j]);
             } else if (!(p.dbg & 2)) {
 #pragma unroll
                 for (int i = 0; i < NA; ++i)
@@ -2710,21 +2514,6 @@ __global__ __launch_bounds__(512) void conv_fwd256h_kernel(const ConvParams p) {
             }
         }
     };
-    if constexpr (DIRECT) {
-        // ---- register epilogue: no staging, no slab barriers (epilogue_direct); s_colsum was zeroed above ----
-        if (p.colsum) __syncthreads();
-        const bool fullt = m0 + T2 <= p.M && n0 + T2 <= p.Cout;          // block-uniform
-#define SLN_DE(R, K, F) epilogue_direct<8, R, K, F>(p, acc16, m0 + 128 * wr, n0 + 64 * wc, lane, s_colsum + 64 * wc, alpha, yqs, amx)
-        if (fullt) {
-            if (EPI == 2) SLN_DE(2, 0, true); else if (EPI == 3) SLN_DE(0, 2, true);
-            else if (EPI == 4) SLN_DE(1, 2, true); else if (EPI == 5) SLN_DE(1, 0, true); else SLN_DE(0, 0, true);
-        } else {
-            if (EPI == 2) SLN_DE(2, 0, false); else if (EPI == 3) SLN_DE(0, 2, false);
-            else if (EPI == 4) SLN_DE(1, 2, false); else if (EPI == 5) SLN_DE(1, 0, false); else SLN_DE(0, 0, false);
-        }
-#undef SLN_DE
-        __syncthreads();
-    } else
     if (EPI > 0) {
         const bool full = m0 + T2 <= p.M && n0 + T2 <= p.Cout;          // block-uniform
 #define SLN_W8E(R, K, F) epilogue_tile_w8<32, 260, 512, 4, R, K, F, decltype(stage_slab), SLN_W8_DEPTH, 64, SLN_W8_DOUBLE_STAGE * SLAB_FLOATS>(p, stage, m0, n0, t, s_colsum, alpha, yqs, amx, stage_slab)
@@ -2794,7 +2583,7 @@ __global__ __launch_bounds__(512) void conv_fwd256h_kernel(const ConvParams p) {
 #ifndef SLN_128H_DEPTH
 #define SLN_128H_DEPTH 1
 #endif
-template <int EPI, bool DIRECT = false>
+template <int EPI>
 __global__ __launch_bounds__(256, 2) void conv_fwd128x256h_kernel(const ConvParams p) {
     constexpr int P = 2;
     constexpr int TM = 128;                    // rows of the tile
@@ -2919,8 +2708,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd128x256h_kernel(const ConvPara
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int row = DIRECT ? 64 * wave + 32 * (j >> 1) + 8 * (r16 >> 2) + 4 * (j & 1) + (r16 & 3)
-                               : 64 * wave + 16 * j + r16;
+        const int row = 64 * wave + 16 * j + r16;
         b_off16[j] = row * 64 + ((c16 ^ SLN_SWZW(row)) * 16);
     }
 
@@ -2998,10 +2786,8 @@ __global__ __launch_bounds__(256, 2) void conv_fwd128x256h_kernel(const ConvPara
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (DIRECT) mfma16_products_t(a[i], b16[j], acc16[4 * ph + i][j]);
-                    else mfma16_products(a[i], b16[j], acc16[4 * ph + i][j]);
-                }
+                for (int j = 0; j < 4; ++j) 
+                    mfma16_products(a[i], b16[j], acc16[4 * ph + i][j]);
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             if (ph == 1) {
@@ -3020,27 +2806,6 @@ __global__ __launch_bounds__(256, 2) void conv_fwd128x256h_kernel(const ConvPara
         }
     }
 
-    if constexpr (DIRECT) {
-        // ---- register epilogue: no staging, no slab barriers (epilogue_direct) ----
-        if (p.colsum) {
-            if (t < T2) s_colsum[t] = 0.f;
-            __syncthreads();
-        }
-        const bool fullt = m0 + TM <= p.M && n0 + T2 <= p.Cout;          // block-uniform
-#define SLN_DE(R, K, F) epilogue_direct<8, R, K, F>(p, acc16, m0, n0 + 64 * wave, lane, s_colsum + 64 * wave, alpha, yqs, amx)
-        if (fullt) {
-            if (EPI == 2) SLN_DE(2, 0, true); else if (EPI == 3) SLN_DE(0, 2, true);
-            else if (EPI == 4) SLN_DE(1, 2, true); else if (EPI == 5) SLN_DE(1, 0, true); else SLN_DE(0, 0, true);
-        } else {
-            if (EPI == 2) SLN_DE(2, 0, false); else if (EPI == 3) SLN_DE(0, 2, false);
-            else if (EPI == 4) SLN_DE(1, 2, false); else if (EPI == 5) SLN_DE(1, 0, false); else SLN_DE(0, 0, false);
-        }
-#undef SLN_DE
-        __syncthreads();
-        if (p.colsum && t < T2 && n0 + t < p.Cout && s_colsum[t] != 0.f) atomicAdd(p.colsum + n0 + t, s_colsum[t]);
-        if (p.yparts) amax_commit(amx, amx * yqs > SLN_F16_MAX, p.yq, s_word);
-        return;
-    }
     // ---- epilogue: four 32-row slabs through LDS ([32][260] floats), eight channels per thread ----
     float *stage = (float *)smem;
     if (t < T2) s_colsum[t] = 0.f;            // (ordered by the first slab's barrier)
@@ -4212,14 +3977,7 @@ extern "C" int sln_conv2d_fwd_ms_f32(const uint16_t *x_parts, int nseg, const in
                     p.gm = (int)gm1;
                     const dim3 g1((unsigned)(gm1 * gn2)), b1(256);
                     sln_last_fwd_kernel = 3;
-                    // the register epilogue (epilogue_direct; SLN_CONV_DIRECT=0: the LDS-staged slabs, A/B)
-                    const bool direct = (sln_knob("SLN_CONV_DIRECT", 0) & 1) != 0 && !(p.dbg & (8192 | 16384 | 131072));
-#if SLN_BUILD_DIRECT
-#define SLN_L128(E) do { if (direct) hipLaunchKernelGGL((conv_fwd128x256h_kernel<E, true>), g1, b1, 0, (hipStream_t)stream, p); \
-                         else hipLaunchKernelGGL((conv_fwd128x256h_kernel<E, false>), g1, b1, 0, (hipStream_t)stream, p); } while (0)
-#else
-#define SLN_L128(E) do { (void)direct; hipLaunchKernelGGL((conv_fwd128x256h_kernel<E, false>), g1, b1, 0, (hipStream_t)stream, p); } while (0)
-#endif
+#define SLN_L128(E) hipLaunchKernelGGL((conv_fwd128x256h_kernel<E>), g1, b1, 0, (hipStream_t)stream, p)
                     if (p.res_parts) SLN_L128(2);
                     else if (p.residual && p.mask_part0) SLN_L128(4);
                     else if (p.residual) SLN_L128(5);
@@ -4240,15 +3998,7 @@ extern "C" int sln_conv2d_fwd_ms_f32(const uint16_t *x_parts, int nseg, const in
                                   !(p.dbg & ~(8 | 16 | 256 | 8192 | 16384 | 32768 | 65536 | 131072)) &&
                                   sln_knob("SLN_CONV_TAPROW", 1) != 0;
                 p.tapmode = row ? 1 : colm ? 2 : 0;
-                // the register epilogue (epilogue_direct): SLN_CONV_DIRECT bit 0 the 128 x 256 kernel (above), bit 1 the
-                // plain 256^2 instances, bit 2 the tap-row instances (default 7: all; 0: the LDS-staged slabs, A/B)
-                const int dk = (p.dbg & (8192 | 16384 | 131072)) ? 0 : sln_knob("SLN_CONV_DIRECT", 0);
-#if SLN_BUILD_DIRECT
-#define SLN_L256(E, R) do { if (dk & ((R) ? 4 : 2)) hipLaunchKernelGGL((conv_fwd256h_kernel<false, 2, 16, E, R, true>), g2, b2, 0, (hipStream_t)stream, p); \
-                            else hipLaunchKernelGGL((conv_fwd256h_kernel<false, 2, 16, E, R, false>), g2, b2, 0, (hipStream_t)stream, p); } while (0)
-#else
-#define SLN_L256(E, R) do { (void)dk; hipLaunchKernelGGL((conv_fwd256h_kernel<false, 2, 16, E, R, false>), g2, b2, 0, (hipStream_t)stream, p); } while (0)
-#endif
+#define SLN_L256(E, R) hipLaunchKernelGGL((conv_fwd256h_kernel<false, 2, 16, E, R>), g2, b2, 0, (hipStream_t)stream, p)
                 if (row || colm) {
                     sln_last_fwd_kernel = 4;
                     if (!w8) hipLaunchKernelGGL((conv_fwd256h_kernel<false, 2, 16, 0, true>), g2, b2, 0, (hipStream_t)stream, p);

@@ -175,8 +175,11 @@ __global__ __launch_bounds__(256) void label_zoom_kernel(const u64 *__restrict__
     const int32_t *xb = xs + (long)b * OW;
     for (int ox = (blockIdx.x * 256 + threadIdx.x) * 2; ox < OW; ox += gridDim.x * 512) {
         const int x0 = xb[ox], x1 = ox + 1 < OW ? xb[ox + 1] : -1;
-        const u64 v0 = (sy >= 0 && x0 >= 0) ? row[x0] : 0ull;
-        const u64 v1 = (sy >= 0 && x1 >= 0) ? row[x1] : 0ull;
+        //  src_hw is device-side metadata: a row that disagrees with the packed stride (a worker's error
+        // path, another batch's sizes) must read the constant fill, not the next image's label or past the buffer
+        const long i0 = (long)(sy < 0 ? 0 : sy) * W0 + x0, i1 = (long)(sy < 0 ? 0 : sy) * W0 + x1;
+        const u64 v0 = (sy >= 0 && x0 >= 0 && x0 < W0 && i0 < src_stride) ? row[x0] : 0ull;
+        const u64 v1 = (sy >= 0 && x1 >= 0 && x1 < W0 && i1 < src_stride) ? row[x1] : 0ull;
         if (ox + 1 < OW && (OW & 1) == 0) {
             *(ulonglong2 *)(dst + ox) = make_ulonglong2(v0, v1);
         } else {
@@ -205,7 +208,9 @@ __global__ __launch_bounds__(256) void label_tops_ragged_kernel(const u64 *__res
                                                                 unsigned *__restrict__ tops) {
     const int b = blockIdx.y;
     const u64 *lab = label + (size_t)b * stride;
-    const long npix = (long)src_hw[2 * b] * src_hw[2 * b + 1];
+    long npix = (long)src_hw[2 * b] * src_hw[2 * b + 1];
+    if (npix > stride) npix = stride;          // (never past this image's slot of the packed batch)
+    if (npix < 0) npix = 0;
     unsigned acc = 0;
     for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < npix; p += (long)gridDim.x * 256) {
         const unsigned vis = (unsigned)lab[p];

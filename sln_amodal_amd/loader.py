@@ -138,6 +138,14 @@ def _worker_main(names, nslots, dim, cap, infos, task_q, done_q):
 
 
 # ---------------------------------------------------------------------------------------------- training-process side
+def capped_workers(requested, cores=None):
+    """Worker processes a rank may start: at most its core share minus two (the training thread and the feeder
+    thread keep a core each); at least one.  cores=None: the mask this process is pinned to."""
+    if cores is None:
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return max(1, min(int(requested), cores - 2))
+
+
 class PrefetchLoader(object):
     """Ring of shared-memory slots filled by worker processes, drained by a feeder thread into pinned staging
     buffers and copied to the device on a copy stream.  Iterating yields, per step, a dict of DEVICE tensors
@@ -149,7 +157,8 @@ class PrefetchLoader(object):
 
     def __init__(self, infos, dim, batch, sampler, workers=8, depth=3, cap_pixels=None, device=None, start_epoch=0):
         self.infos, self.dim, self.batch, self.sampler = list(infos), int(dim), int(batch), sampler
-        self.workers, self.depth = max(1, int(workers)), max(1, int(depth))
+        self.workers_requested = max(1, int(workers))
+        self.workers, self.depth = self.workers_requested, max(1, int(depth))
         self.cap = int(cap_pixels or max(dim * dim, 640 * 640))     # label pixels a slot holds (larger ones: zoomed by the worker)
         self.device = device
         self.nslots = (self.depth + 1) * self.batch
@@ -165,6 +174,10 @@ class PrefetchLoader(object):
     def start(self):
         if self._procs:
             return self
+        # capped to this rank's share of the host cores (parallel.set_cpu_affinity pinned the process before this
+        # call; the workers inherit the mask): eight ranks x eight workers on one host must not queue behind each
+        # other's training threads
+        self.workers = capped_workers(self.workers_requested)
         import multiprocessing as mp
         from multiprocessing import shared_memory
         ctx = mp.get_context("spawn")
@@ -282,6 +295,10 @@ class PrefetchLoader(object):
                     st_evt[j].synchronize()          # the copy that last read this staging buffer has finished
                 meta = self._meta[slots].copy()
                 npix = meta[:, 0].astype(np.int64) * meta[:, 1]
+                if npix.min() < 0 or npix.max() > self.cap:
+                    # (a worker's metadata that disagrees with what a slot can hold: fail here, on the host, instead
+                    # of handing the device kernels a row pitch that walks out of the packed buffer)
+                    raise RuntimeError("loader: a label of %d pixels in a slot of %d" % (int(npix.max()), self.cap))
                 stride = int((npix.max() + 7) // 8 * 8)
                 img_t, lab_t = st_img[j], st_lab[j][:B * stride].view(B, stride)
                 img_np, lab_np = img_t.numpy(), lab_t.numpy()
@@ -360,7 +377,8 @@ class PrefetchLoader(object):
         n = max(st["batches"], 1)
         return {"batches": st["batches"], "queue_depth_mean": round(st["depth_sum"] / n, 2),
                 "queue_depth_min": st["depth_min"], "consumer_wait_ms_per_batch": round(1e3 * st["wait_s"] / n, 3),
-                "labels_zoomed_on_host": st["host_zoomed"], "workers": self.workers, "prefetch_batches": self.depth}
+                "labels_zoomed_on_host": st["host_zoomed"], "workers": self.workers, "workers_requested": self.workers_requested,
+                "prefetch_batches": self.depth}
 
 
 # ---------------------------------------------------------------------------------------------- synthetic file sets

@@ -42,22 +42,34 @@ def init_distributed(backend=None, timeout_s=None):
 
 
 AFFINITY = {}
+_HOST_CORES = []      # the mask this process STARTED with (remembered by the first call: the shares are slices of it)
+
+
+def core_share(cores, local_rank, local_world):
+    """Rank `local_rank`'s contiguous share of a sorted core list (pure: the world-8 test calls it for all ranks)."""
+    per = len(cores) // local_world
+    return list(cores[local_rank * per:(local_rank + 1) * per]) if per >= 1 else []
 
 
 def set_cpu_affinity(local_rank, local_world):
     """One process per GPU: pin this rank (and the loader workers it will start) to its own contiguous share of the
     host cores, so that eight ranks' Python threads and input workers do not migrate over each other
     (SLN_CPU_AFFINITY=0 leaves the scheduler alone).  Called before any GPU call; a no-op for a single rank.
-    The result is kept in AFFINITY for the bench line (`gradient_exchange.cpu_affinity`)."""
+    The result is kept in AFFINITY for the bench line (`gradient_exchange.cpu_affinity`).
+    IDEMPOTENT: entry points pin before they start their loader workers and init_distributed() pins
+    again -- the share is always cut from the mask the process started with, never from an already narrowed one
+    (a second call used to leave a rank on 1 / local_world^2 of the host)."""
     AFFINITY.clear()
     if local_world <= 1 or os.environ.get("SLN_CPU_AFFINITY", "1") == "0" or not hasattr(os, "sched_setaffinity"):
         return None
     try:
-        cores = sorted(os.sched_getaffinity(0))
+        if not _HOST_CORES:
+            _HOST_CORES.extend(sorted(os.sched_getaffinity(0)))
+        cores = _HOST_CORES
         per = len(cores) // local_world
         if per < 1:
             return None
-        mine = cores[local_rank * per:(local_rank + 1) * per]
+        mine = core_share(cores, local_rank, local_world)
         os.sched_setaffinity(0, mine)
         AFFINITY.update(cores=len(mine), first=mine[0], last=mine[-1])
         return mine
@@ -78,6 +90,15 @@ def broadcast_parameters(module, src=0):
             t.mul_(1)
 
 
+def derive_bucket_bytes(total_bytes, want=4, lo=4 << 20, hi=64 << 20):
+    """Bucket size for a training stage with `total_bytes` of trainable gradients (round 6): a
+    quarter of the stage's gradient bytes, between 4 and 64 MiB.  The exchange overlaps backward bucket by bucket,
+    so a stage needs SEVERAL buckets whatever its size: stage 'all' (255.7 MB) keeps its four 64-MiB buckets, stage
+    'heads' (~88 MB: one 64-MiB bucket and a remainder before) gets ~22-MiB ones, '4+' / '3+' in between.  Below
+    ~4 MiB a collective's launch latency (~20 us per hop over xGMI) is no longer hidden by its own transfer."""
+    return int(min(hi, max(lo, -(-total_bytes // want))))
+
+
 class GradientAllReducer(object):
     """Bucketed, backward-overlapped gradient averaging over persistent flat buckets.
 
@@ -93,9 +114,12 @@ class GradientAllReducer(object):
     bytes were already in place and how many had to be copied.
     Calling the object with a parameter list does the same without hooks."""
 
-    def __init__(self, params, bucket_bytes=64 << 20):
+    def __init__(self, params, bucket_bytes=None):
         self.params = [p for p in params if p.requires_grad]
         self.world = dist.get_world_size() if dist.is_initialized() else 1
+        if bucket_bytes is None:
+            bucket_bytes = derive_bucket_bytes(sum(p.numel() * p.element_size() for p in self.params))
+        self.bucket_bytes = bucket_bytes
         self.buckets = []
         cur, size = [], 0
         for p in reversed(self.params):  # backward produces grads roughly in reverse order

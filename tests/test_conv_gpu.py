@@ -1516,86 +1516,3 @@ def test_row3_k_steps_equal_the_per_tap_loop(shape, kind, tile_mode):
                     assert torch.equal(a, b)
     finally:
         os.environ.pop("SLN_CONV_ROW3", None)
-
-
-@pytest.mark.parametrize("route", ["128x256", "256", "taprow"])
-@pytest.mark.parametrize("shape", [
-    # N, H, W, Cin, Cout, k, dil
-    (4, 64, 64, 256, 1024, 1, 1), (3, 37, 41, 256, 256, 1, 1), (2, 33, 33, 1024, 200, 1, 1), (2, 64, 64, 64, 256, 3, 1),
-    (5, 16, 16, 32, 256, 1, 1), (1, 32, 32, 256, 512, 3, 2)])
-@pytest.mark.parametrize("kind", ["parts", "y+parts", "res16", "res32", "res32+mask16", "mask16+colsum", "y only"])
-def test_register_epilogue_equals_the_lds_staged_epilogue_bit_for_bit(route, shape, kind, tile_mode):
-    """epilogue_direct (round 5: weights as the MFMA's A operand, so that a lane holds eight consecutive output channels
-    of a pixel and the tile goes from the accumulators to memory without LDS staging) computes the same products in the
-    same order as the LDS-staged eight-channel slabs: every output -- fp32, both parts, the recorded amax -- must be
-    BIT-identical between SLN_CONV_DIRECT=0 and 7 on all three kernels that carry it (the 128 x 256 kernel, the plain
-    256^2 instances, the tap-row instances), for every epilogue kind, on whole and ragged tiles (the column sums to
-    fp32 rounding: another summation order); and repeated launches must reproduce themselves."""
-    import os
-    from sln_amodal_amd import conv_hip
-    if os.environ.get("SLN_TEST_DIRECT_EPILOGUE") != "1":
-        pytest.skip("the register-epilogue instances are compiled only with -DSLN_BUILD_DIRECT=1 (measured, not faster: "
-                    "profiles/r5_e_ab_register_epilogue.txt); SLN_TEST_DIRECT_EPILOGUE=1 runs this test against such a build")
-    N, H, W, Cin, Cout, k, dil = shape
-    if route == "taprow" and (k != 3 or (N * H * W) % 256 or W not in (32, 64, 128, 256)):
-        pytest.skip("tap-row instances: 3-wide kernels on maps of 32 ... 256 columns in whole tiles")
-    g = torch.Generator(device="cuda").manual_seed(H * 13 + Cout + len(kind))
-    x = torch.randn(N, Cin, H, W, device="cuda", generator=g).contiguous(memory_format=torch.channels_last)
-    w = torch.randn(Cout, Cin, k, k, device="cuda", generator=g) / (Cin * k * k) ** 0.5
-    res = torch.randn(N, Cout, H, W, device="cuda", generator=g).contiguous(memory_format=torch.channels_last)
-    sc = torch.rand(Cout, device="cuda", generator=g) + 0.5
-    sf = torch.randn(Cout, device="cuda", generator=g)
-    pad = dil * (k - 1) // 2
-    xp, xq = conv_hip.act_parts(x, 2)
-    rp, rq = conv_hip.act_parts(res, 2)
-    slot = conv_hip._slot(w, ("ydirect", H, W, kind, route))
-    A = (xp, N, H, W, conv_hip.wsrc(w, 2), Cout, k, k, (1, 1), (dil, dil), pad, pad, H, W)
-    tile_mode(2)
-    for _ in range(2):       # bootstrap the output's scale slot with a plain launch
-        conv_hip._fwd(*A, sc, sf, None, True, cin=Cin, out_parts=True, yslot=slot, xq=xq)
-    run = {
-        "parts": lambda: conv_hip._fwd(*A, sc, sf, None, True, cin=Cin, out_parts=True, want_y=False, yslot=slot, xq=xq),
-        "y+parts": lambda: conv_hip._fwd(*A, sc, sf, None, True, cin=Cin, out_parts=True, yslot=slot, xq=xq),
-        "y only": lambda: conv_hip._fwd(*A, None, None, None, False, cin=Cin, xq=xq),
-        "res16": lambda: conv_hip._fwd(*A, sc, sf, None, True, cin=Cin, out_parts=True, want_y=False, yslot=slot, xq=xq,
-                                       res_parts=(rp, rq)),
-        "res32": lambda: conv_hip._fwd(*A, sc, sf, res, True, cin=Cin, out_parts=True, yslot=slot, xq=xq),
-        "res32+mask16": lambda: conv_hip._fwd(*A, None, None, res, False, cin=Cin, out_parts=True, want_y=True,
-                                              want_colsum=True, post_scale=sc, yslot=slot, xq=xq, mask_parts=rp),
-        "mask16+colsum": lambda: conv_hip._fwd(*A, sc, None, None, False, cin=Cin, out_parts=True, want_y=False,
-                                               want_colsum=True, yslot=slot, xq=xq, mask_parts=rp),
-    }[kind]
-
-    def outputs():
-        slot.amax.zero_()
-        r = run()
-        r = r if isinstance(r, tuple) else (r, getattr(r, "_sln_parts", (None, None))[1], None)
-        return [t.clone() for t in r if t is not None] + [slot.amax.clone()]
-
-    keys = ("SLN_CONV_TILE128H", "SLN_CONV_TAPROW", "SLN_CONV_DIRECT")
-    saved = {k_: os.environ.get(k_) for k_ in keys}
-    try:
-        os.environ["SLN_CONV_TILE128H"] = "2" if route == "128x256" else "0"
-        os.environ["SLN_CONV_TAPROW"] = "1" if route == "taprow" else "0"
-        os.environ["SLN_CONV_DIRECT"] = "0"
-        want = outputs()
-        assert conv_hip._lib.lib().sln_conv_fwd_last_kernel() == {"128x256": 3, "256": 2, "taprow": 4}[route]
-        os.environ["SLN_CONV_DIRECT"] = "7"
-        got = outputs()
-        assert len(got) == len(want)
-
-        def same(a, b):
-            if a.dim() == 1 and a.numel() > 1:        # column sums: another summation order
-                return bool(torch.allclose(a, b, rtol=2e-5, atol=2e-5 * float(b.abs().max())))
-            return torch.equal(a, b)
-        for i, (a, b) in enumerate(zip(got, want)):
-            assert same(a, b), (i, a.shape, float((a.float() - b.float()).abs().max()))
-        for _ in range(10):
-            again = outputs()
-            assert all(same(a, b) for a, b in zip(again, got))
-    finally:
-        for k_, v_ in saved.items():
-            if v_ is None:
-                os.environ.pop(k_, None)
-            else:
-                os.environ[k_] = v_

@@ -147,136 +147,3 @@ def test_train_step_at_the_reference_learning_rate_stays_finite_and_fits_the_mas
     assert rows[-1]["total"] < rows[0]["total"], msg
     # no worse than aten beyond one build's own spread (x 1.2)
     assert rows[-1]["total"] <= aten[-1]["total"] + 0.8, msg
-
-
-def test_config3_full_size_train_step_resnet101_16x1024():
-    """BASELINE configs[2] at size: ResNet-101 + DeepLab-v2 SLN, 16 x 1024x1024, stage 'all', ONE
-    train step through the product path (the conv kernels' int-index paths: M = 16*256*256 output
-    rows, ~70 GB resident).  Finite losses, every trainable parameter updated, and the three largest
-    layer shapes of the step against aten fp32 at 1e-5 of the output scale."""
-    import torch.nn.functional as F
-    from sln_amodal_amd import nn_ops, synthetic
-    from sln_amodal_amd.config import Config
-    from sln_amodal_amd.model import MaskRCNN
-
-    class C(Config):
-        NAME = "full"
-        IMAGE_MAX_DIM = 1024
-        IMAGE_MIN_DIM = 1024
-        ARCHITECTURE = "resnet101"
-        BATCH_SIZE = 16
-
-    torch.manual_seed(0)
-    cfg = C()
-    m = MaskRCNN(cfg, "/tmp/sln_logs").apply_amodal_heads().cuda()
-    m.set_trainable(".*", exclusive_off=False)
-    for p in m.GLM_modual.parameters():
-        p.requires_grad = False
-    batch = synthetic.make_batch(cfg, 16, 1024, 1024, seed=1234, anchors_f64=m.anchors_f64)
-    synthetic.calibrate_batchnorm(m, batch["images"][:4])
-    synthetic.calibrate_glm(m, batch["images"][:2])
-    synthetic.warm_start_rpn(m, [batch], iters=10)
-    opt = m.make_optimizer(cfg.LEARNING_RATE)
-    before = {n: p.detach().clone() for n, p in m.named_parameters() if p.requires_grad}
-    loss, parts = m.train_step(batch, opt)
-    assert bool(torch.isfinite(loss)) and float(loss) > 0
-    assert all(bool(torch.isfinite(v)) for v in parts.values())
-    assert float(m.last_grad_norm) > 0 and np.isfinite(float(m.last_grad_norm))
-    assert opt.skipped_steps() == 0
-    same = [n for n, p in m.named_parameters() if p.requires_grad and torch.equal(p.detach(), before[n])]
-    assert not same, same[:10]
-    # it really was the full-size step (58 GB with fp32 copies of every activation, 37 GB since the
-    # bottleneck / RPN / mask-head activations are kept as parts only)
-    assert torch.cuda.max_memory_allocated() > 25 * 2 ** 30
-    del before, batch, opt
-    m.zero_grad(set_to_none=True)
-    # ---- the step's largest layer shapes, HIP vs aten fp32 ----
-    gen = torch.Generator(device="cuda").manual_seed(1)
-    shapes = [("C2 3x3 64->64 @256^2", m.fpn.C2[1].conv2, m.fpn.C2[1].bn2, (16, 64, 256, 256), True),
-              ("C2 1x1 64->256 @256^2", m.fpn.C2[1].conv3, m.fpn.C2[1].bn3, (16, 64, 256, 256), False),
-              ("C4 1x1 256->1024 @64^2", m.fpn.C4[3].conv3, m.fpn.C4[3].bn3, (16, 256, 64, 64), False),
-              ("RPN 3x3 256->512 @256^2", m.rpn.conv_shared, None, (16, 256, 256, 256), True)]
-    for name, conv, bn, shape, same in shapes:
-        x = (torch.randn(shape, device="cuda", generator=gen)).contiguous(memory_format=torch.channels_last)
-        with torch.no_grad():
-            nn_ops.BACKEND = "hip"
-            got = nn_ops.conv_bn_act(x, conv, bn, relu=True, same=same)
-            nn_ops.BACKEND = "torch"
-            want = nn_ops.conv_bn_act(x, conv, bn, relu=True, same=same)
-            nn_ops.BACKEND = "hip"
-        err = float((got - want).abs().max()) / max(float(want.abs().max()), 1e-12)
-        assert tuple(got.shape) == tuple(want.shape), name
-        assert err <= 1e-5, (name, err)
-        del x, got, want
-    # ---- the small-K 3x3 layers at size, forward + data gradient + weight gradient (round 5: the per-kernel-row
-    # instances of the 128-family kernels take exactly these launches), HIP vs aten fp32, no ReLU in between ----
-    from sln_amodal_amd import conv_hip
-    lib = conv_hip._lib.lib()
-    for name, conv, bn, shape in (("C2 3x3 64->64 @256^2", m.fpn.C2[2].conv2, m.fpn.C2[2].bn2, (16, 64, 256, 256)),
-                                  ("C3 3x3 128->128 @128^2", m.fpn.C3[2].conv2, m.fpn.C3[2].bn2, (16, 128, 128, 128))):
-        x0 = torch.randn(shape, device="cuda", generator=gen).contiguous(memory_format=torch.channels_last)
-        up = torch.randn(shape, device="cuda", generator=gen).contiguous(memory_format=torch.channels_last)
-        res = {}
-        for be in ("hip", "hip", "torch"):           # (the first pass bootstraps the gradient's scale slot)
-            nn_ops.BACKEND = be
-            conv_hip.update_scales(sync=False)
-            x = x0.clone().requires_grad_(True)
-            conv.weight.grad = None
-            y = nn_ops.conv_bn_act(x, conv, bn, relu=False, same=True)
-            y.backward(up)
-            res[be] = (y.detach(), x.grad.detach(), conv.weight.grad.detach().clone())
-            if be == "hip":
-                assert lib.sln_conv_fwd_last_kernel() == 5 and lib.sln_conv_wgrad_last_kernel() == 2, name
-        nn_ops.BACKEND = "hip"
-        for what, a, b in zip(("forward", "data gradient", "weight gradient"), res["hip"], res["torch"]):
-            err = float((a.double() - b.double()).norm() / b.double().norm())
-            assert err <= 2e-5, (name, what, err)
-        conv.weight.grad = None
-        del x0, up, res, x, y
-
-
-def test_config5_resnext101_msc_train_step_full_depth():
-    """configs[4] differentiated end to end on the HIP path: ResNeXt-101 (32 groups) + ASPP under the multi-scale
-    wrapper in training mode (logits of every scale + their maximum, modal/msc_deeplab.py:45-46), frozen BN,
-    cross-entropy on all four outputs, at the configuration's own size (32 x 321^2 images per GPU): finite loss, a gradient for every trainable tensor, SGD
-    steps reduce the loss; prints the step time."""
-    import time
-    from sln_amodal_amd import conv_hip
-    from sln_amodal_amd.modal.resnext import DeepLabV2_ResNeXt101_MSC
-    from tests._util import key_init_
-    from tests.test_resnext_cpu import damp_
-    net = DeepLabV2_ResNeXt101_MSC(21)
-    key_init_(net)
-    damp_(net)
-    net = net.cuda().train()
-    for m in net.modules():
-        if isinstance(m, torch.nn.BatchNorm2d):
-            m.eval()
-            m.weight.requires_grad = m.bias.requires_grad = False
-    B = 32
-    g = torch.Generator(device="cuda").manual_seed(2)
-    x = torch.randn(B, 3, 321, 321, device="cuda", generator=g).contiguous(memory_format=torch.channels_last)
-    params = [p for p in net.parameters() if p.requires_grad]
-    opt = torch.optim.SGD(params, lr=0.02, momentum=0.9)
-    losses, dt = [], 0.0
-    target = None
-    for it in range(6):
-        conv_hip.update_scales()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        outs = net(x)
-        assert len(outs) == 4 and tuple(outs[0].shape) == (B, 21, 11, 11)
-        if target is None:
-            target = torch.randint(0, 21, (B, 11, 11), device="cuda", generator=g)
-        loss = sum(F.cross_entropy(F.interpolate(o, size=(11, 11), mode="bilinear", align_corners=False), target)
-                   for o in outs)
-        opt.zero_grad(set_to_none=True)
-        loss.backward()
-        if it == 0:
-            assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in params)
-        opt.step()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        losses.append(float(loss))
-    assert all(l == l for l in losses) and losses[-1] < losses[0], losses
-    print("ResNeXt-101 MSC train step, %d x 321^2, three scales: %.1f ms (%.1f img/s); loss %.3f -> %.3f" % (B, dt * 1e3, B / dt, losses[0], losses[-1]))

@@ -409,14 +409,14 @@ def train_scenes(env, prefix):
         del model
 
 
-def run_mask_scene(env):
+def run_mask_scene(env, scene=0):
     """Scene 0's reference train step once more, with the observers of --masks (module docstring)."""
     import torch.nn.functional as F
     ref_model, ref_config, ref_dl, nn = env["ref_model"], env["ref_config"], env["ref_dl"], env["nn"]
     ref_train, scenes, tmp, loss_names = env["ref_train"], env["scenes"], env["tmp"], env["loss_names"]
     real = {k: env[k] for k in ("real_loader", "real_randperm", "real_clip", "real_step", "real_save",
                                 "real_predict", "real_losses")}
-    image, label = scenes[0]
+    image, label = scenes[scene]
     model, cfg = build_reference_model(ref_model, ref_config, ref_dl, nn)
     params = dict(model.named_parameters())
     ds = StubDataset(ref_train, [image], [label], tmp)
