@@ -3,6 +3,7 @@ so model/dataset code written against it keeps working.  Values are the
 reference defaults; sub-class and override class attributes, derived fields are
 filled in __init__.  MI355X-specific knobs are grouped at the end."""
 import math
+import os
 
 import numpy as np
 
@@ -80,6 +81,9 @@ class Config(object):
     GLM_CLASSES = 182                     # amodal_train.py:613
     GLM_SIZE = 513                        # model.py:535
     STRICT_IMAGE_DIVISIBILITY = False     # reference raises unless H,W % 64 == 0 (model.py:153-157)
+    # convolutions (regular expression on the weight's name) that run in the strict 3 x bf16 operand format instead of
+    # the default 2 x scaled fp16 (MaskRCNN.set_strict_layers)
+    STRICT_LAYERS = os.environ.get("SLN_STRICT_LAYERS", "")
 
     def __init__(self):
         self.IMAGE_SHAPE = np.array([self.IMAGE_MAX_DIM, self.IMAGE_MAX_DIM, 3])

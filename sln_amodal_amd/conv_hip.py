@@ -30,6 +30,17 @@ from . import _lib, ops
 PARTS = int(os.environ.get("SLN_CONV_PARTS", "2"))
 # parts used while autograd is disabled (the frozen GLM, inference): None = same as PARTS
 PARTS_NOGRAD = int(os.environ["SLN_CONV_PARTS_NOGRAD"]) if os.environ.get("SLN_CONV_PARTS_NOGRAD") else None
+# Per-layer operand format (round 6): callable(owner weight) -> 2 | 3 | None, consulted by every autograd convolution
+# (forward, data and weight gradient of the layer run in the returned format; None = PARTS).  The strict 3 x bf16
+# format (>= fp32 per element, no exponent floor) for the layers that need it -- MaskRCNN.set_strict_layers() maps a
+# name pattern to this hook; tests/test_precision_gpu.py and tools/precision_control.py hold the evidence for WHICH.
+PARTS_FOR = None
+
+
+def parts_for_tagged(own):
+    """The PARTS_FOR hook MaskRCNN.set_strict_layers installs: 3 for weights tagged `_sln_strict` (the tag lives on
+    the Parameter object and dies with it)."""
+    return 3 if (PARTS == 2 and getattr(own, "_sln_strict", False)) else None
 class _NoCache(dict):
     pass
 
@@ -1081,6 +1092,8 @@ class _ConvFn(torch.autograd.Function):
         # scale slots (PARTS = 2) live on the layer's persistent weight object: `owner` when the weight
         # passed in is a temporary view of it (Linear / deconv reshapes)
         own = owner if owner is not None else weight
+        if PARTS_FOR is not None and parts == PARTS:
+            parts = PARTS_FOR(own) or parts
         xp, xq = act_parts(x, parts, owner=own)
         x_po = getattr(x, "_sln_po", None) is not None
         yslot = _slot(own, ("y", OH, OW)) if (parts <= 2 and FUSE_OUTPUT_SPLIT) else None
@@ -1462,6 +1475,8 @@ class _StemFn(torch.autograd.Function):
         parts = PARTS
         if PARTS_NOGRAD and not any(ctx.needs_input_grad):
             parts = PARTS_NOGRAD
+        elif PARTS_FOR is not None:
+            parts = PARTS_FOR(weight) or parts
         Co, Ci, KH, KW = weight.shape
         # the max-pool that is this output's ONLY reader leaves its incoming gradient here instead of scattering it
         # into a full-size map (nn_ops._MaxPoolFn.backward): the gradient preparation gathers from it

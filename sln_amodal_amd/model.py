@@ -119,6 +119,24 @@ class MaskRCNN(nn.Module):
         # with it the train step computes the same losses and gradients without the mask branch of the negative rois
         # (_training_heads; opt-in, bench.py reports it as a second number).
         self.mask_train_slots = None
+        self.set_strict_layers(getattr(config, "STRICT_LAYERS", ""))
+
+    def set_strict_layers(self, pattern):
+        """Convolutions whose weight's name matches the regular expression `pattern` (fullmatch, like set_trainable)
+        run in the STRICT operand format -- three bf16 parts, six MFMA products per multiply-add, >= fp32 per element
+        with no exponent floor -- forward and backward; all others in conv_hip.PARTS (two scaled fp16 parts).
+        Config.STRICT_LAYERS is the default ("" = none); what the choice buys and costs: tests/test_precision_gpu.py,
+        tools/precision_control.py, DESIGN.md section 4.  Returns the number of tagged weights."""
+        n = 0
+        for name, p in self.named_parameters():
+            strict = bool(pattern) and p.dim() == 4 and bool(re.fullmatch(pattern, name))
+            p._sln_strict = strict
+            n += strict
+        if n:
+            from . import conv_hip
+            conv_hip.PARTS_FOR = conv_hip.parts_for_tagged
+        self.strict_layers = pattern
+        return n
 
     def positive_slots(self):
         return int(self.config.TRAIN_ROIS_PER_IMAGE * self.config.ROI_POSITIVE_RATIO)
@@ -177,6 +195,7 @@ class MaskRCNN(nn.Module):
         self.mask.num_classes = self.classifier.num_classes = cfg.NUM_CLASSES
         if glm:
             self.GLM_modual = DeepLabV2_ResNet101_MSC(cfg.GLM_CLASSES)
+        self.set_strict_layers(getattr(self, "strict_layers", ""))     # (the replaced layers are new Parameters)
         return self
 
     def set_trainable(self, layer_regex, model=None, indent=0, verbose=1, exclusive_off=True):
