@@ -398,20 +398,20 @@ def main_detect(args, rank, world, dev):
     molded, metas, windows = model.mold_inputs(imgs)
     x = torch.from_numpy(molded.transpose(0, 3, 1, 2)).float().to(dev).contiguous(memory_format=torch.channels_last)
 
+    # --tail: the evaluation hand-off of the whole batch on a side stream / worker thread (round 6,
+    # sln_amodal_amd/tail.py): submit() records an event and returns; the timed region ends with tail.results()
+    tail = None
+    if args.tail:
+        from sln_amodal_amd.tail import InferenceTail
+        tail = InferenceTail(dev)
+    shapes = [im.shape for im in imgs]
+
     def step():
         with torch.no_grad():
             detections, mrcnn_mask = model.predict([x, metas], mode="inference")
-        n_rle = 0
-        if args.tail:
-            counts = model.last_num_detections.cpu().numpy()          # the one host read of the hand-off
-            for b in range(batch):
-                n = int(counts[b])
-                if n:
-                    out = model.unmold_detections_device(detections[b, :n], mrcnn_mask[b, :n], imgs[b].shape, windows[b],
-                                                         keep_device=True)
-                    if out["rois"].shape[0]:
-                        n_rle += len(mask_rle.encode(out["masks_device"]))
-        return detections, n_rle
+        if tail is not None:
+            tail.submit(detections, mrcnn_mask, model.last_num_detections, shapes, windows)
+        return detections, 0
 
     def barrier():
         if world > 1:
@@ -420,6 +420,8 @@ def main_detect(args, rank, world, dev):
 
     for _ in range(max(args.warmup, 2)):
         step()
+    if tail is not None:
+        tail.results()
     if rank == 0:
         conv_hip.PROFILE = []
     barrier()
@@ -427,9 +429,12 @@ def main_detect(args, rank, world, dev):
     n_rle = 0
     for _ in range(args.steps):
         detections, k = step()
-        n_rle += k
+    if tail is not None:              # every RLE string of every timed batch is on the host when the clock stops
+        n_rle = sum(len(r["rles"]) for r in tail.results().values())
     barrier()
     elapsed = time.perf_counter() - t0
+    if tail is not None:
+        tail.close()
     prof, conv_hip.PROFILE = conv_hip.PROFILE, None
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
@@ -484,6 +489,10 @@ def main():
     ap.add_argument("--workers", type=int, default=None, help="--data files: loader worker processes per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-strict", action="store_true", help="skip the 5 extra steps in the 3 x bf16 format")
+    ap.add_argument("--cold-start", action="store_true",
+                    help="the reference's start of a run: after the set-up the weights go through a checkpoint in the "
+                         "reference's state-dict layout into a NEW model object (no operand-scale history; reference "
+                         "model.py:287-302, amodal_train.py:642-663); use with --settle 0")
     ap.add_argument("--conv-backend", default="auto", choices=["auto", "hip", "torch"])
     ap.add_argument("--config", default="sln", choices=["sln", "resnext", "detect"],
                     help="sln: BASELINE.json's headline (configs[2] / [3]); resnext: configs[4], ResNeXt-101 + multi-scale "
@@ -569,6 +578,22 @@ def main():
     synthetic.calibrate_glm(model, batches[0]["images"][: min(2, args.batch)])
     synthetic.warm_start_rpn(model, [dict(b, images=b["images"]) for b in batches], iters=40)
     parallel.broadcast_parameters(model)
+    if args.cold_start:
+        # what the reference's loop starts from: a checkpoint file in its state-dict layout, loaded into a freshly
+        # built model (model.py:287-302 load_weights; amodal_train.py:642-663) -- here: no scale slot of the new model
+        # has a history, every tensor role bootstraps in the first step and follows from there
+        ck = os.path.join(os.environ.get("TMPDIR", "/tmp"), "sln_bench_cold_start_%d.pth" % rank)
+        torch.save(model.state_dict(), ck)
+        del model
+        torch.manual_seed(1)          # (another initialisation: everything must come from the file)
+        model = MaskRCNN(cfg, "/tmp/sln_bench_logs").apply_amodal_heads().to(dev)
+        model.load_weights(ck)
+        os.remove(ck)
+        model.set_trainable(LAYER_REGEX[args.stage], exclusive_off=False)
+        for p in model.GLM_modual.parameters():
+            p.requires_grad = False
+        conv_hip_ = __import__("sln_amodal_amd.conv_hip", fromlist=["x"])
+        conv_hip_.update_scales()     # (the old model's slots died with it: their table entries are recycled)
 
     if file_data is not None:
         file_data.bind(model, dev)
@@ -578,7 +603,7 @@ def main():
         next_batch = lambda i: batches[i % 2]
     opt = model.make_optimizer(cfg.LEARNING_RATE)
     reducer = parallel.GradientAllReducer([p for p in model.parameters() if p.requires_grad]).attach()
-    sync = (lambda params: reducer.finish()) if world > 1 else None
+    sync = reducer if world > 1 else None      # (callable: finish(); train_step reads the step's all-reduced clamp veto from it)
 
     def barrier():
         if world > 1:
@@ -591,33 +616,54 @@ def main():
     # per tensor role) is seeded with real train steps on both batches, so that the timed region starts from settled
     # scales like a run that has been training for a while (the reference always starts from checkpoints).  These
     # steps are ordinary optimiser steps; `config.setup_scale_settle_steps` reports them.
+    clamped_skips = lambda: opt.skipped_clamped_steps() if hasattr(opt, "skipped_clamped_steps") else 0
     for i in range(args.settle):
         model.train_step(next_batch(i), opt, sync)
     sat_setup = conv_hip.saturation_count()        # (host syncs outside the timed region)
+    skipc_setup = clamped_skips()
     snap_w = conv_hip.saturation_snapshot()
     for i in range(args.warmup):
         loss, _ = model.train_step(next_batch(i), opt, sync)
     sat_warmup = conv_hip.saturation_count()
+    skipc_warmup = clamped_skips()
     sat_events_warmup = [{"role": r_, "layer_weight_shape": s_, "blocks": b_}
                          for r_, s_, b_ in conv_hip.saturation_report(snap_w, None)]
-    sat_snaps = [conv_hip.saturation_snapshot()]   # device-side copies, one per timed step: no host sync
-    if rank == 0:
-        conv_hip.PROFILE = []          # HIP-event pairs around every conv launch (launch stream)
-    barrier()
-    t0 = time.perf_counter()
-    step_marks = [torch.cuda.Event(enable_timing=True)]
-    step_marks[0].record()
-    depth_seen = []
-    for i in range(args.steps):
-        if file_data is not None:
-            depth_seen.append(file_data.queue_depth())
-        loss, _ = model.train_step(next_batch(i), opt, sync)
-        losses.append(loss)
-        sat_snaps.append(conv_hip.saturation_snapshot())
-        step_marks.append(torch.cuda.Event(enable_timing=True))
-        step_marks[-1].record()                    # (an event record: no sync)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    # The timed region.  A step in which an operand block clamped is vetoed on the device (round 6: not applied,
+    # counted); such a step did everything but the 0.2-ms update kernel, but "work skipped inside the timed region"
+    # is not a line to print: the region is then timed AGAIN (the clamped tensor's scale has followed by then), at
+    # most twice, and `config.timed_region_reruns` says so.
+    reruns = 0
+    while True:
+        skipc_before = clamped_skips()
+        sat_snaps = [conv_hip.saturation_snapshot()]   # device-side copies, one per timed step: no host sync
+        if rank == 0:
+            conv_hip.PROFILE = []          # HIP-event pairs around every conv launch (launch stream)
+        barrier()
+        t0 = time.perf_counter()
+        step_marks = [torch.cuda.Event(enable_timing=True)]
+        step_marks[0].record()
+        depth_seen = []
+        for i in range(args.steps):
+            if file_data is not None:
+                depth_seen.append(file_data.queue_depth())
+            loss, _ = model.train_step(next_batch(i), opt, sync)
+            losses.append(loss)
+            sat_snaps.append(conv_hip.saturation_snapshot())
+            step_marks.append(torch.cuda.Event(enable_timing=True))
+            step_marks[-1].record()                    # (an event record: no sync)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        skipc_timed = clamped_skips() - skipc_before
+        if world > 1:
+            tt = torch.tensor([skipc_timed], dtype=torch.int64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            skipc_timed = int(tt.item())
+        if skipc_timed == 0 or reruns == 2:
+            break
+        reruns += 1
+        losses = []
+        if rank == 0:
+            conv_hip.PROFILE = []
     # this rank's own step times (GPU clock between the marks): a scaling run shows a straggler rank here
     step_ms = [a.elapsed_time(b) for a, b in zip(step_marks[:-1], step_marks[1:])]
     rank_diag = {"rank": rank, "step_ms_min": round(min(step_ms), 3), "step_ms_max": round(max(step_ms), 3),
@@ -680,9 +726,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     final_loss = float(losses[-1]) if losses else float("nan")
-    skipped = opt.skipped_steps() if hasattr(opt, "skipped_steps") else 0
+    skipped_all = opt.skipped_steps() if hasattr(opt, "skipped_steps") else 0
+    skipped = skipped_all - clamped_skips()          # non-finite gradient norms (the clamp vetoes are accounted below)
     if skipped:        # a skipped step is work left out of the timed region: the line would be invalid
         raise SystemExit("bench.py: %d optimiser step(s) were skipped for a non-finite gradient norm" % skipped)
+    if skipc_timed:
+        raise SystemExit("bench.py: %d timed step(s) were vetoed for clamped operand blocks in each of %d timings of "
+                         "the region" % (skipc_timed, reruns + 1))
 
     if rank == 0:
         images = args.batch * world * args.steps
@@ -714,6 +764,12 @@ def main():
                        "conv_saturated_blocks": [sat_setup, sat_warmup - sat_setup, sat_timed],
                        "conv_saturated_events_timed": sat_events,
                        "conv_saturated_events_warmup": sat_events_warmup,
+                       # steps NOT applied because an operand block clamped in them (set-up, warm-up, timed region as
+                       # printed); with the guard on (default) no clamped block reaches the weights
+                       "clamped_and_skipped_steps": [skipc_setup, skipc_warmup - skipc_setup, skipc_timed],
+                       "clamped_and_applied_blocks": 0 if conv_hip.SKIP_CLAMPED_STEPS and hasattr(opt, "skipped_clamped_steps")
+                       else sat_setup + (sat_warmup - sat_setup) + sat_timed,
+                       "timed_region_reruns": reruns, "cold_start": bool(args.cold_start),
                        "setup_scale_settle_steps": args.settle},
             "step_roofline": {"bound": "mfma", "kernel": "whole train step (all kernels)",
                               "achieved": round(achieved, 3), "peak": round(split_peak(conv_hip.PARTS), 1),

@@ -349,6 +349,11 @@ int sln_rle_encode_u8(const uint8_t *masks, int N, int64_t a, int max_runs, uint
                       int32_t *num_runs, sln_stream_t stream);
 int64_t sln_rle_to_string(const uint32_t *counts, int64_t m, char *out, int64_t cap);
 int64_t sln_rle_from_string(const char *s, int64_t len, uint32_t *counts, int64_t cap);
+/* sln_rle_to_strings: rleToString (maskApi.c:204-216) for the N masks of a batch in one call (ABI 12): row n of
+ * counts (row pitch row_stride words) holds num_runs[n] counts; strings back to back in out, string n =
+ * out[offsets[n] .. offsets[n + 1]) (offsets: N + 1 entries).  Returns the total length or -SLN_ERR_INVALID_ARG. */
+int64_t sln_rle_to_strings(const uint32_t *counts, int64_t row_stride, const int32_t *num_runs, int N, char *out,
+                           int64_t cap, int64_t *offsets);
 
 /* ---------------------------------------------------------------------------
  * Convolution stacks (modal/modals.py:203-499 backbone / FPN / RPN / heads,

@@ -41,6 +41,7 @@ SIGNATURES = {
     "sln_rle_encode_u8": (_i, [_p, _i, C.c_int64, _i, _p, _p, _p]),
     "sln_rle_to_string": (C.c_int64, [_p, C.c_int64, _p, C.c_int64]),
     "sln_rle_from_string": (C.c_int64, [_p, C.c_int64, _p, C.c_int64]),
+    "sln_rle_to_strings": (C.c_int64, [_p, C.c_int64, _p, _i, _p, C.c_int64, _p]),
     "sln_gather_rois_f32": (_i, [_p, _p, _p, _i, _i, _i, _f, _f, _p, _p]),
     "sln_pyramid_crop_fwd_f32": (_i, [C.POINTER(_p), C.POINTER(_i), _i, _i, _p, _p, _p, _i, _i, _i,
                                       _f, _p, _i, _i, _p]),

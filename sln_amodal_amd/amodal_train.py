@@ -264,19 +264,21 @@ class AmodalDataset(object):
             step += 1
 
 
-def build_coco_results(dataset, image_ids, rois, class_ids, scores, masks):
+def build_coco_results(dataset, image_ids, rois, class_ids, scores, masks, rles=None):
     """Detections of one image in COCO result format (amodal_train.py:370-400): bbox rounded to one
     decimal and reordered to (x, y, w, h), class ids folded to {0, 1}, masks as COCO RLE dicts.
     masks: device uint8 [N,W,H] (detect(..., keep_device=True)["masks_device"]) or the host array
     [H,W,N] detect() returns by default (uploaded once); either way the run-length encoding happens
-    on the GPU (mask_rle.encode replaces maskUtils.encode(np.asfortranarray(mask)))."""
+    on the GPU (mask_rle.encode replaces maskUtils.encode(np.asfortranarray(mask))).  rles: the RLE dicts
+    themselves, when the batched hand-off (tail.InferenceTail) already encoded them."""
     from . import mask_rle
     if rois is None:
         return []
-    if not torch.is_tensor(masks):
-        masks = torch.from_numpy(np.ascontiguousarray(np.transpose(masks, (2, 1, 0)))).to(
-            torch.uint8).cuda()
-    rles = mask_rle.encode(masks)
+    if rles is None:
+        if not torch.is_tensor(masks):
+            masks = torch.from_numpy(np.ascontiguousarray(np.transpose(masks, (2, 1, 0)))).to(
+                torch.uint8).cuda()
+        rles = mask_rle.encode(masks)
     results = []
     for image_id in image_ids:
         for i in range(rois.shape[0]):
@@ -402,27 +404,32 @@ def main(argv=None):
                 reducer.detach()     # the previous stage's hooks must not fire next to the new reducer's
             reducer = parallel.GradientAllReducer(params()).attach()
             model.train_model(data, None, learning_rate=lr, epochs=epochs, layers=layers,
-                              grad_sync=(lambda ps: reducer.finish()) if world > 1 else None)
+                              grad_sync=reducer if world > 1 else None)      # (the reducer is callable: finish())
     elif args.command == "evaluate":
         # one batched predict(mode='inference') per BATCH_SIZE images (the reference: one image at a time,
         # amodal_train.py:403-466); the per-image loop is only the hand-off to the COCO result list
+        # (round 6) the hand-off runs on a worker thread and a side stream (tail.InferenceTail): the whole batch
+        # through one unmold and one run-length launch while the next batch's forward is already enqueued
+        from .tail import InferenceTail
+        tail = InferenceTail(model.anchors.device)
         n, limit = 0, max(1, min(args.limit, 2 if args.synthetic else args.limit))
         for batch in data:
             k_img = min(batch["images"].shape[0], limit - n)
             imgs = [(batch["images"][b].permute(1, 2, 0).cpu().numpy() + config.MEAN_PIXEL).clip(0, 255)
                     .astype(np.uint8) for b in range(k_img)]
-            res = {r["image_index"]: r for r in model.detect(imgs, keep_device=True, batch_size=k_img)}
-            for b in range(k_img):
-                r = res.get(b)
-                k = r["rois"].shape[0] if r is not None else 0
-                coco = build_coco_results(None, [n], r["rois"], r["class_ids"], r["scores"],
-                                          r["masks_device"]) if k else []
-                if rank == 0:
-                    print("image %d: %d detections, %d RLE bytes" % (
-                        n, k, sum(len(c["segmentation"]["counts"]) for c in coco)))
-                n += 1
+            model.detect_submit(imgs, tail, keys=list(range(n, n + k_img)))
+            n += k_img
             if n >= limit:
                 break
+        res = tail.results()
+        tail.close()
+        for i in range(n):
+            r = res.get(i)
+            k = r["rois"].shape[0] if r is not None else 0
+            coco = build_coco_results(None, [i], r["rois"], r["class_ids"], r["scores"], None, rles=r["rles"]) if k else []
+            if rank == 0:
+                print("image %d: %d detections, %d RLE bytes" % (
+                    i, k, sum(len(c["segmentation"]["counts"]) for c in coco)))
     data.close()
 
 

@@ -353,6 +353,46 @@ def saturation_count():
     return sum(int(b.saturated.sum().item()) + int(b.retired_saturated.item()) for b in _books.values())
 
 
+# ------------------------------------------------------------------ no silently applied clamped step (round 6)
+# A train step in which ANY operand block had to clamp a value to +-65504 computed with under-estimated operands
+# (38 k such blocks in the 16 set-up steps of a cold file-fed run, every one of those steps APPLIED).
+# The step is now vetoed on the device, like a non-finite gradient norm: clamp_mark() at the start of the step,
+# clamp_veto() after backward -> a 0 / 1 device scalar that the optimiser's guard reads (optim.ClippedSGD.step) and,
+# under data parallelism, that travels with the LAST gradient bucket so that every rank skips the same step
+# (parallel.GradientAllReducer).  The clamped tensor's amax was recorded before the clamp: the next update_scales()
+# follows it, and the step after a skipped one runs with room.  "0": A/B switch (round-5 behaviour: count only).
+SKIP_CLAMPED_STEPS = os.environ.get("SLN_SKIP_CLAMPED_STEPS", "1") != "0"
+_CLAMP_MARK = {}
+
+
+def saturation_total(idx):
+    """0-d int64 DEVICE tensor: blocks of book `idx` that clamped since start-up (no host sync)."""
+    b = _books[idx]
+    return b.saturated[:max(b.n, 1)].sum(dtype=torch.int64) + b.retired_saturated
+
+
+def clamp_mark():
+    """Start of a train step: remember every book's clamp total (device-side)."""
+    _CLAMP_MARK.clear()
+    if SKIP_CLAMPED_STEPS:
+        for i in _books:
+            _CLAMP_MARK[i] = saturation_total(i)
+
+
+def clamp_veto(device=None):
+    """-> float32 [1] device tensor, 1.0 if a block clamped since clamp_mark() (on `device`'s book, default: any
+    single book), else 0.0; None when nothing was marked (guard off, no HIP convolution ran, CPU)."""
+    if not SKIP_CLAMPED_STEPS or not _CLAMP_MARK:
+        return None
+    out = None
+    for i, mark in _CLAMP_MARK.items():
+        if device is not None and device.index is not None and i != device.index:
+            continue
+        v = (saturation_total(i) != mark).to(torch.float32).reshape(1)
+        out = v if out is None else torch.maximum(out, v.to(out.device))
+    return out
+
+
 def saturation_snapshot():
     """Device-side copy of every book's per-slot clamp counters (no host sync): take one per step, diff them with
     saturation_report() afterwards to learn which tensor role clamped in which step."""

@@ -325,6 +325,27 @@ extern "C" int64_t sln_rle_to_string(const uint32_t *counts, int64_t m, char *ou
     return p;
 }
 
+// The same for the N masks of a batch in ONE call (round 6: the evaluation hand-off runs on a worker thread next to
+// the next batch's forward; a ctypes call releases the interpreter lock for its whole duration, a Python loop of N
+// small calls does not): row n of `counts` (row pitch `row_stride` words) holds num_runs[n] counts; the strings are
+// written back to back into `out` and offsets[n] .. offsets[n + 1] delimits string n (offsets has N + 1 entries).
+// Returns the total length, or -SLN_ERR_INVALID_ARG (cap too small: 6 characters per count always suffice).
+extern "C" int64_t sln_rle_to_strings(const uint32_t *counts, int64_t row_stride, const int32_t *num_runs, int N,
+                                      char *out, int64_t cap, int64_t *offsets) {
+    if (N < 0 || row_stride < 0 || (N > 0 && (!counts || !num_runs || !out || !offsets))) return -SLN_ERR_INVALID_ARG;
+    int64_t p = 0;
+    for (int n = 0; n < N; ++n) {
+        offsets[n] = p;
+        const int64_t m = num_runs[n];
+        if (m < 0 || m > row_stride) return -SLN_ERR_INVALID_ARG;
+        const int64_t w = sln_rle_to_string(counts + (int64_t)n * row_stride, m, out + p, cap - p);
+        if (w < 0) return w;
+        p += w;
+    }
+    if (N > 0) offsets[N] = p;
+    return p;
+}
+
 // Host side inverse (maskApi.c:218-231): counts from the compressed string.  Returns the number of
 // counts, or -SLN_ERR_INVALID_ARG when `cap` is too small (one count per character always suffices).
 extern "C" int64_t sln_rle_from_string(const char *s, int64_t len, uint32_t *counts, int64_t cap) {

@@ -530,7 +530,13 @@ class MaskRCNN(nn.Module):
         """One optimisation step on a batch: predict -> six losses -> backward ->
         (data-parallel gradient all-reduce) -> global-norm clip 5.0 -> SGD
         (model.py:415-444).  `batch` = dict(images, image_metas, rpn_match, rpn_bbox,
-        gt_class_ids, gt_boxes, gt_layer).  Returns the loss tensor (no host sync)."""
+        gt_class_ids, gt_boxes, gt_layer).  Returns the loss tensor (no host sync).
+        A step in which an fp16 operand block had to clamp is NOT applied (conv_hip.clamp_mark / clamp_veto, round 6):
+        the optimiser skips it on the device and counts it; under data parallelism every rank skips the same step."""
+        hip = None
+        if batch["images"].is_cuda and nn_ops.BACKEND != "torch":
+            from . import conv_hip as hip
+            hip.clamp_mark()
         out = self.predict([batch["images"], batch.get("image_metas"), batch["gt_class_ids"],
                             batch["gt_boxes"], batch["gt_layer"]], mode="training",
                            priorities=priorities)
@@ -542,17 +548,22 @@ class MaskRCNN(nn.Module):
             loss.backward()
         if grad_sync is not None:
             grad_sync([p for p in self.parameters() if p.requires_grad])
-        self.optimizer_step(optimizer)
+        reducer = getattr(grad_sync, "__self__", grad_sync)       # (a bound finish / the reducer object itself)
+        if getattr(reducer, "world", 1) > 1 and getattr(reducer, "veto", None) is not None:
+            veto = reducer.veto                                    # summed over the ranks with the last bucket
+        else:
+            veto = hip.clamp_veto(batch["images"].device) if hip is not None else None
+        self.optimizer_step(optimizer, veto)
         return loss.detach(), parts
 
-    def optimizer_step(self, optimizer):
+    def optimizer_step(self, optimizer, veto=None):
         """Global-norm clip (5.0) over every gradient, then momentum SGD with weight decay on the
         non-'bn' parameters (model.py:441-444, 352-358).  Runs after the all-reduce: a parameter
         without a local gradient may have received one from a peer, and every rank must clip over
         the same set."""
         from .optim import ClippedSGD
         if isinstance(optimizer, ClippedSGD):
-            self.last_grad_norm = optimizer.step(self.config.GRADIENT_CLIP_NORM)
+            self.last_grad_norm = optimizer.step(self.config.GRADIENT_CLIP_NORM, veto=veto)
             return
         params = [p for p in self.parameters() if p.requires_grad and p.grad is not None]
         self.last_grad_norm = torch.nn.utils.clip_grad_norm_(params, self.config.GRADIENT_CLIP_NORM)
@@ -616,6 +627,7 @@ class MaskRCNN(nn.Module):
             from . import conv_hip
         sat0 = conv_hip.saturation_count() if conv_hip is not None else 0      # (before the loop: not in it)
         skip0 = optimizer.skipped_steps() if hasattr(optimizer, "skipped_steps") else 0
+        skipc0 = optimizer.skipped_clamped_steps() if hasattr(optimizer, "skipped_clamped_steps") else 0
         step = 0
         for batch in datagenerator:
             loss, _ = self.train_step(batch, optimizer, grad_sync)
@@ -626,16 +638,25 @@ class MaskRCNN(nn.Module):
             if step == steps:
                 break
         mean = float(loss_sum / finite_steps.clamp(min=1))   # the one host sync of the epoch
+        clamped_skips = (optimizer.skipped_clamped_steps() - skipc0) if hasattr(optimizer, "skipped_clamped_steps") else 0
+        blocks = (conv_hip.saturation_count() - sat0) if conv_hip is not None else 0
+        guarded = conv_hip is not None and conv_hip.SKIP_CLAMPED_STEPS and hasattr(optimizer, "skipped_clamped_steps")
         health = {"steps": step, "non_finite_losses": step - int(finite_steps),
-                  "conv_saturated_blocks": (conv_hip.saturation_count() - sat0) if conv_hip is not None else 0,
-                  "skipped_optimizer_steps": (optimizer.skipped_steps() - skip0)
-                  if hasattr(optimizer, "skipped_steps") else 0}
+                  "conv_saturated_blocks": blocks,
+                  # every clamped block of a guarded step was vetoed with its step: nothing of it reached the weights
+                  "clamped_and_skipped_steps": clamped_skips,
+                  "clamped_and_applied_blocks": 0 if guarded else blocks,
+                  "skipped_optimizer_steps": ((optimizer.skipped_steps() - skip0)
+                                              if hasattr(optimizer, "skipped_steps") else 0) - clamped_skips}
         if conv_hip is not None:
             conv_hip.check_ranks()
         self.epoch_health = health
         if health["skipped_optimizer_steps"]:
             log("ERROR: {} of {} optimiser steps were skipped for a non-finite gradient norm".format(
                 health["skipped_optimizer_steps"], step))
+        if health["clamped_and_skipped_steps"]:
+            log("{} of {} optimiser steps were not applied: an fp16 operand block clamped in them ({} blocks); their "
+                "scales follow from the next step on".format(health["clamped_and_skipped_steps"], step, blocks))
         if health["non_finite_losses"] or health["conv_saturated_blocks"] or health["skipped_optimizer_steps"]:
             log("epoch health: {}".format(health))
         return mean
@@ -706,6 +727,17 @@ class MaskRCNN(nn.Module):
                     results.append({"rois": rois, "class_ids": class_ids, "scores": scores, "masks": masks,
                                     "image_index": i0 + b})
         return results
+
+    def detect_submit(self, images, tail, keys=None, priorities=None):
+        """detect() without the hand-off on this thread: mold, ONE batched predict(mode='inference'), then the outputs
+        go to `tail` (tail.InferenceTail: unmold + RLE of the whole batch on a side stream, a worker thread) and the
+        call returns -- the next batch's forward can be enqueued at once.  tail.results() -> {key: {rois, class_ids,
+        scores, rles}} (model.py:464-514 + amodal_train.py:370-400, batched)."""
+        molded, metas, windows = self.mold_inputs(images)
+        x = torch.from_numpy(molded.transpose(0, 3, 1, 2)).float().to(self.anchors.device)
+        with torch.no_grad():
+            detections, mrcnn_mask = self.predict([x, metas], mode="inference", priorities=priorities)
+        tail.submit(detections, mrcnn_mask, self.last_num_detections, [im.shape for im in images], windows, keys)
 
     def unmold_detections_device(self, detections, mrcnn_mask, image_shape, window, keep_device=False):
         """unmold_detections (model.py:747-806) without leaving the GPU: detections [M,6] and

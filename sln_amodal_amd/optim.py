@@ -26,7 +26,8 @@ class ClippedSGD(object):
             g.setdefault("momentum", momentum)
             self.param_groups.append(g)
         self.state = {}                      # param -> momentum buffer
-        self.skipped = None                  # device int32: steps skipped for a non-finite gradient norm
+        self.skipped = None                  # device int32: steps skipped (non-finite gradient norm OR a clamp veto)
+        self.skipped_clamped = None          # device int32: of those, the steps vetoed for clamped operand blocks
         self._plan_key, self._plan = None, None
         self._ring, self._turn = [], 0       # pinned staging buffers of the pointer tables
         self.capturing = False               # inside a HIP-graph capture: no event waits (the tables are static)
@@ -59,6 +60,10 @@ class ClippedSGD(object):
     def skipped_steps(self):
         """Steps whose update was skipped on the device because the gradient norm was inf / NaN (host sync)."""
         return (int(self.skipped.item()) if self.skipped is not None else 0) + getattr(self, "_skipped_loaded", 0)
+
+    def skipped_clamped_steps(self):
+        """Of skipped_steps(): the steps vetoed because an fp16 operand block had to clamp in them (host sync)."""
+        return int(self.skipped_clamped.item()) if self.skipped_clamped is not None else 0
 
     def state_dict(self):
         """Momentum buffers by position in the flattened parameter groups + the groups' hyper-parameters
@@ -124,7 +129,11 @@ class ClippedSGD(object):
         return self._plan
 
     @torch.no_grad()
-    def step(self, max_norm):
+    def step(self, max_norm, veto=None):
+        """veto: float32 [1] device tensor or None; > 0 = do not apply this step (conv_hip.clamp_veto(), or the
+        all-reduced one of parallel.GradientAllReducer): the update is skipped on the device through the same guard
+        as a non-finite gradient norm and counted in `skipped` and `skipped_clamped`; `last_norm` stays the real
+        norm.  No host sync either way."""
         act = self._active()
         if not act:
             return None
@@ -175,11 +184,20 @@ class ClippedSGD(object):
         nch = ct.numel() if sum(p.numel() for p in ps) else 0
         _lib.check(L.sln_grad_sqnorm_f32(vp(tab[1]), vp(numel), vp(ct), vp(co), nch, CHUNK, vp(partial), vp(sq),
                                          st), "sln_grad_sqnorm_f32")
+        sq_guard = sq
+        if veto is not None:
+            # the guard's input: +inf instead of the squared norm when the step is vetoed (two 5-us elementwise ops)
+            if self.skipped_clamped is None:
+                self.skipped_clamped = torch.zeros(1, dtype=torch.int32, device=dev)
+            hit = veto.reshape(1) > 0
+            sq_guard = torch.where(hit, torch.full_like(sq, float("inf")), sq)
+            # (a step that is non-finite anyway is counted as that, not as clamped)
+            self.skipped_clamped += (hit & torch.isfinite(sq)).to(torch.int32)
         _lib.check(L.sln_sgd_clip_step_f32(vp(tab[0]), vp(tab[1]), vp(tab[2]), vp(numel), vp(wd), vp(ct), vp(co),
-                                           nch, CHUNK, vp(sq), float(max_norm), lr, momentum, vp(self.skipped), st),
-                   "sln_sgd_clip_step_f32")
+                                           nch, CHUNK, vp(sq_guard), float(max_norm), lr, momentum, vp(self.skipped),
+                                           st), "sln_sgd_clip_step_f32")
         # caches keyed by the weights' version counters (split weight parts) must see the update
         torch._C._autograd._unsafe_set_version_counter(ps, [p._version + 1 for p in ps])
-        self._keep = (tab, gs)                # alive until the next step: the launches above are asynchronous
+        self._keep = (tab, gs, sq_guard)      # alive until the next step: the launches above are asynchronous
         self.last_norm = sq.sqrt().to(torch.float32)[0]
         return self.last_norm

@@ -140,6 +140,13 @@ class GradientAllReducer(object):
                 self._slot[id(p)] = (bi, off)
                 off += (p.numel() + 3) // 4 * 4      # 16-B aligned slots (vector loads in the optimiser)
         self._size = [sum((p.numel() + 3) // 4 * 4 for p in b) for b in self.buckets]
+        # the step's clamp veto travels with the LAST bucket (round 6): one extra 16-B slot behind its gradients holds
+        # 1.0 on a rank whose operand blocks clamped in this step (conv_hip.clamp_veto()); after the SUM every rank
+        # reads the same "> 0" and skips -- or applies -- the same update: replicas stay identical, no extra collective
+        self._veto_off = self._size[-1] if self._size else 0
+        if self._size:
+            self._size[-1] += 4
+        self.veto = None        # after finish(): float32 [1] view, > 0 if ANY rank vetoed the step
         self._work = [None] * len(self.buckets)
         self._next = 0          # collectives are issued strictly in bucket order on every rank
         self._hooks = []
@@ -239,8 +246,24 @@ class GradientAllReducer(object):
                 torch._foreach_zero_(missing)
             if dst:
                 torch._foreach_copy_(dst, src)       # one multi-tensor launch (layout conversion included)
+        if bi == len(self.buckets) - 1:
+            # every gradient of the pass has been produced by now (its last hook fired, or finish() is flushing what
+            # never arrived): whatever clamped in this step's forward or backward is in the counters
+            v = self._local_veto(flat)
+            with torch.no_grad():
+                if v is None:
+                    flat[self._veto_off:self._veto_off + 4].zero_()
+                else:
+                    flat[self._veto_off:self._veto_off + 4].copy_(v.expand(4))
         self.trace.append(bi)
         self._work[bi] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+
+    def _local_veto(self, flat):
+        """This rank's veto of the step: conv_hip.clamp_veto() on the GPU, nothing on the host (tests override it)."""
+        if not flat.is_cuda:
+            return None
+        from . import conv_hip
+        return conv_hip.clamp_veto(flat.device)
 
     def finish(self):
         if self.world == 1:
@@ -274,6 +297,7 @@ class GradientAllReducer(object):
         self._pending = [len(b) for b in self.buckets]
         self._next = 0
         self.last_trace, self.trace = self.trace, []
+        self.veto = self._flat[-1][self._veto_off:self._veto_off + 1]
 
     def diagnostics(self, last=None):
         """Exposed all-reduce wait of the last `last` finish() calls (host sync: call it after the timed region):

@@ -190,6 +190,69 @@ def test_train_step_runs_updates_and_stays_finite():
     assert set(parts) == {"layer", "rpn_bbox", "mrcnn_bbox", "mrcnn_class", "amodal", "rpn_class"}
 
 
+def test_a_train_step_with_a_clamped_operand_block_is_skipped_not_applied():
+    """a step whose operands clamped to +-65504 computed with under-estimated values; it must not reach
+    the weights.  Provoked like a loss spike does it: one layer's weights are multiplied by 2^12 between two steps, so
+    its output outgrows the 2^5 of head room its delayed scale has.  The step is vetoed on the device (no host sync in
+    train_step), counted, weights and momentum stay bit-identical; the scale follows, and the next step applies.
+    With the guard off (SLN_SKIP_CLAMPED_STEPS=0 semantics) the same step IS applied -- the round-5 behaviour."""
+    from sln_amodal_amd import conv_hip, synthetic
+    m, cfg = _small_model()
+    batch = synthetic.make_batch(cfg, 2, 256, 256, seed=1234, anchors_f64=m.anchors_f64)
+    synthetic.calibrate_batchnorm(m, batch["images"])
+    synthetic.calibrate_glm(m, batch["images"])
+    synthetic.warm_start_rpn(m, [batch], iters=10)
+    opt = m.make_optimizer(1e-4)
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    pr = {"pos": torch.rand(2, 1000, device="cuda", generator=gen), "neg": torch.rand(2, 1000, device="cuda", generator=gen)}
+    for _ in range(3):
+        m.train_step(batch, opt, priorities=pr)
+    assert opt.skipped_steps() == 0
+    names = [n for n, p in m.named_parameters() if p.requires_grad]
+    P = dict(m.named_parameters())
+    sat0 = conv_hip.saturation_count()
+    with torch.no_grad():
+        m.fpn.P3_conv2[1].weight.mul_(4096.0)       # the spike: this layer's output (and what follows) is x 4096
+    snap = {n: P[n].detach().clone() for n in names}
+    bufs = {n: opt.state[P[n]].clone() for n in names if P[n] in opt.state}
+    loss, _ = m.train_step(batch, opt, priorities=pr)
+    assert conv_hip.saturation_count() > sat0                           # blocks clamped in that step ...
+    assert opt.skipped_clamped_steps() == 1 and opt.skipped_steps() == 1    # ... so it was vetoed, as a clamp
+    assert all(torch.equal(P[n], snap[n]) for n in names)               # nothing reached the weights
+    assert all(torch.equal(opt.state[P[n]], b) for n, b in bufs.items())
+    # the scales follow (a tensor computed FROM clamped operands under-reports its own maximum once more, so the
+    # layers downstream may need a second vetoed step): within three steps a step runs clamp-free and is applied,
+    # and no step that clamped was
+    applied_at = None
+    for k in range(3):
+        sat1, skip1 = conv_hip.saturation_count(), opt.skipped_steps()
+        before = {n: P[n].detach().clone() for n in names}
+        m.train_step(batch, opt, priorities=pr)
+        clamped = conv_hip.saturation_count() > sat1
+        changed = sum(not torch.equal(P[n], before[n]) for n in names)
+        assert (opt.skipped_steps() == skip1 + 1) == clamped
+        assert (changed == 0) == clamped
+        if not clamped:
+            applied_at = k
+            assert changed > len(names) // 2
+            break
+    assert applied_at is not None
+    assert opt.skipped_steps() == opt.skipped_clamped_steps()
+    sat1, skips = conv_hip.saturation_count(), opt.skipped_clamped_steps()
+    # guard off: the clamped step is applied (what round 5 did)
+    with torch.no_grad():
+        m.fpn.P3_conv2[1].weight.mul_(4096.0)
+    snap = {n: P[n].detach().clone() for n in names}
+    old = conv_hip.SKIP_CLAMPED_STEPS
+    conv_hip.SKIP_CLAMPED_STEPS = False
+    try:
+        m.train_step(batch, opt, priorities=pr)
+    finally:
+        conv_hip.SKIP_CLAMPED_STEPS = old
+    assert conv_hip.saturation_count() > sat1 and opt.skipped_clamped_steps() == skips
+    assert sum(not torch.equal(P[n], snap[n]) for n in names) > len(names) // 2
+
+
 def test_loss_parity_hip_conv_vs_aten_conv_same_proposals():
     """Six losses with the HIP split-bf16 conv stack vs aten fp32 convs, same weights,
     batch, proposals and sampling priorities: within 1e-4 (north-star tolerance)."""

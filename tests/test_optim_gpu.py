@@ -155,3 +155,45 @@ def test_param_group_hyperparameters_are_read_at_step_time_and_state_round_trips
     opt.param_groups[0]["lr"] = 0.3
     with pytest.raises(ValueError):
         opt.step(5.0)
+
+
+def test_a_vetoed_step_is_not_applied_and_is_counted():
+    """ClippedSGD.step(max_norm, veto=...): a veto > 0 (an fp16 operand block clamped somewhere in the step,
+    conv_hip.clamp_veto()) leaves weights AND momentum buffers untouched through the device-side guard, counts the step
+    in skipped_steps() and skipped_clamped_steps(), keeps the real gradient norm in last_norm; a veto of 0 is the
+    ordinary step, bit for bit."""
+    from sln_amodal_amd.optim import ClippedSGD
+    ps, gs = _make(5, 0.05)
+    a = [torch.nn.Parameter(p.cuda()) for p in ps]
+    b = [torch.nn.Parameter(p.cuda()) for p in ps]
+    oa = ClippedSGD([{"params": a, "weight_decay": 1e-4}], lr=0.01, momentum=0.9)
+    ob = ClippedSGD([{"params": b, "weight_decay": 1e-4}], lr=0.01, momentum=0.9)
+    zero, one = torch.zeros(1, device="cuda"), torch.ones(1, device="cuda")
+    for r, rnd in enumerate(gs):
+        for p, q, g in zip(a, b, rnd):
+            p.grad, q.grad = g.cuda(), g.cuda()
+        na = oa.step(5.0)                    # no veto argument
+        nb = ob.step(5.0, veto=zero)         # an explicit "nothing clamped"
+        assert float(na) == float(nb)
+        assert all(torch.equal(p, q) for p, q in zip(a, b))
+    before = [p.detach().clone() for p in b]
+    bufs = [ob.state[p].clone() for p in b]
+    v0 = [p._version for p in b]
+    for p, g in zip(b, gs[0]):
+        p.grad = g.cuda()
+    norm = ob.step(5.0, veto=one)
+    assert all(torch.equal(p, q) for p, q in zip(b, before))
+    assert all(torch.equal(ob.state[p], q) for p, q in zip(b, bufs))
+    assert float(norm) > 0 and np.isfinite(float(norm))
+    assert ob.skipped_steps() == 1 and ob.skipped_clamped_steps() == 1 and oa.skipped_steps() == 0
+    # a non-finite step that is ALSO vetoed counts as non-finite only
+    b[0].grad[0] = float("nan")
+    ob.step(5.0, veto=one)
+    assert ob.skipped_steps() == 2 and ob.skipped_clamped_steps() == 1
+    assert all(torch.equal(p, q) for p, q in zip(b, before))
+    # ... and the next clean step applies
+    for p, g in zip(b, gs[1]):
+        p.grad = g.cuda()
+    ob.step(5.0, veto=zero)
+    assert not any(torch.equal(p, q) for p, q in zip(b, before) if p.numel() > 1)
+    assert ob.skipped_steps() == 2

@@ -189,3 +189,54 @@ def test_a_rank_that_raises_mid_backward_takes_its_peer_down_and_the_job_can_res
         p.join(120)
     assert [p.exitcode for p in again] == [0, 0]
     assert sorted(q2.get(timeout=5) for _ in range(2)) == [0, 1]
+
+
+def _veto_worker(rank, world, port, out):
+    """The step's clamp veto travels with the last gradient bucket: rank 1 vetoes step 1 only; after finish() BOTH
+    ranks read veto > 0 in that step and 0 in the others, the gradients are the plain means either way."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank), SLN_CPU_AFFINITY="0")
+    from sln_amodal_amd import parallel
+    parallel.init_distributed(backend="gloo", timeout_s=60)
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(7, 13), torch.nn.ReLU(), torch.nn.Linear(13, 3))
+    params = list(model[0].parameters()) + list(model[2].parameters())
+    red = parallel.GradientAllReducer(params, bucket_bytes=64).attach()
+    assert len(red.buckets) >= 2 and red.veto is None
+    sizes = list(red._size)
+    assert sizes[-1] == sum((p.numel() + 3) // 4 * 4 for p in red.buckets[-1]) + 4     # one 16-B slot behind the last bucket
+    step = [0]
+    red._local_veto = lambda flat: torch.ones(1) if (rank == 1 and step[0] == 1) else None
+    g = torch.Generator().manual_seed(rank)
+    seen = []
+    for k in range(3):
+        step[0] = k
+        for p in params:
+            p.grad = None
+        model(torch.randn(4, 7, generator=g)).square().mean().backward()
+        local = torch.cat([p.grad.reshape(-1) for p in params]).clone()
+        red.finish()
+        seen.append(float(red.veto))
+        gathered = [torch.zeros_like(local) for _ in range(world)]
+        dist.all_gather(gathered, local)
+        assert torch.allclose(torch.cat([p.grad.reshape(-1) for p in params]), sum(gathered) / world, atol=1e-7)
+    assert seen[0] == 0.0 and seen[1] > 0.0 and seen[2] == 0.0, seen
+    dist.destroy_process_group()
+    out.put(rank)
+
+
+def test_clamp_veto_travels_with_the_last_bucket_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_veto_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+    for p in procs:
+        if p.is_alive():
+            p.terminate()
+            p.join(10)
+    assert [p.exitcode for p in procs] == [0, 0]
+    assert sorted(q.get(timeout=5) for _ in range(2)) == [0, 1]

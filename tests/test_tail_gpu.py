@@ -169,3 +169,91 @@ def test_unmold_then_rle_equals_reference_pipeline(orc):
     for i, r in enumerate(rles):
         want = orc.rle_to_string(orc.rle_encode(orc.unmold_mask(g["masks"][i], g["boxes"][i], (H, W))))
         assert r == {"size": [H, W], "counts": want}
+
+
+def _random_batch(B, S, seed, shapes):
+    """Detections like predict(mode='inference') returns them ([B,S,6]: normalised-to-window boxes in pixels, class,
+    score; zero rows behind each image's count), mask logits [B,S,2,28,28], windows."""
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    dim = 256
+    counts = torch.tensor([S, 0, 7, 1, S // 2, 3][:B], dtype=torch.int32, device="cuda")
+    tl = torch.rand(B, S, 2, device="cuda", generator=g) * (dim - 40)
+    wh = torch.rand(B, S, 2, device="cuda", generator=g) * 120 + 3
+    det = torch.cat([tl, (tl + wh).clamp(max=dim), torch.ones(B, S, 1, device="cuda"),
+                     torch.rand(B, S, 1, device="cuda", generator=g)], 2)
+    det[0, 3, 2:4] = det[0, 3, 0:2]            # a zero-area box inside the count: dropped (model.py:786-793)
+    det[2, 5, 4] = 0                           # a class-0 row inside the count: the image ends there (model.py:762-764)
+    det = det * (torch.arange(S, device="cuda").view(1, S, 1) < counts.view(B, 1, 1))
+    msk = torch.randn(B, S, 2, 28, 28, device="cuda", generator=g)
+    windows = [(0, 0, dim, dim)] * B
+    return det.contiguous(), msk, counts, windows, [shapes[b % len(shapes)] for b in range(B)]
+
+
+@pytest.mark.parametrize("shapes", [[(200, 320, 3)], [(200, 320, 3), (97, 131, 3)]])
+def test_batched_tail_equals_the_per_image_hand_off(shapes):
+    """tail.unmold_batch (one unmold + one run-length launch per image size for ALL detections of a batch, one C call
+    for the strings) against the per-image path it replaces on the evaluation loop (MaskRCNN.unmold_detections_device +
+    mask_rle.encode, themselves bit-identical to model.py:747-806 / utils.py:447-465 / maskApi.c:33-49, 204-216 --
+    test_unmold_then_rle_equals_reference_pipeline): the same boxes, class ids, scores, masks and RLE strings."""
+    from sln_amodal_amd import mask_rle, tail
+    from sln_amodal_amd.model import MaskRCNN
+    B, S = 6, 20
+    det, msk, counts, windows, shp = _random_batch(B, S, 3, shapes)
+    got = tail.unmold_batch(det, msk, counts, shp, windows, rle=True, keep_masks=True)
+    seen = 0
+    for b in range(B):
+        n = int(counts[b])
+        want = MaskRCNN.unmold_detections_device(None, det[b, :n], msk[b, :n], shp[b], windows[b], keep_device=True) if n else None
+        if want is None or want["rois"].shape[0] == 0:
+            assert b not in got
+            continue
+        seen += 1
+        r = got[b]
+        assert np.array_equal(r["rois"], want["rois"]) and np.array_equal(r["class_ids"], want["class_ids"])
+        assert np.array_equal(r["scores"], want["scores"])
+        assert torch.equal(r["masks_device"], want["masks_device"])
+        assert r["rles"] == mask_rle.encode(want["masks_device"])
+    assert seen >= 4
+    assert got[2]["rois"].shape[0] == 5 and got[0]["rois"].shape[0] == S - 1       # the two filters above
+
+
+def test_inference_tail_worker_delivers_every_batch_in_order():
+    """tail.InferenceTail: submit() returns at once (an event record); a worker thread runs the batched hand-off on
+    its own stream while the submitting thread goes on; results() returns every image of every batch under its key,
+    equal to the synchronous call."""
+    from sln_amodal_amd import tail
+    B, S = 4, 12
+    batches = [_random_batch(B, S, 10 + k, [(160, 192, 3)]) for k in range(5)]
+    want = {}
+    for k, (det, msk, counts, windows, shp) in enumerate(batches):
+        for b, r in tail.unmold_batch(det, msk, counts, shp, windows).items():
+            want[k * B + b] = r
+    t = tail.InferenceTail("cuda", depth=2)
+    try:
+        for k, (det, msk, counts, windows, shp) in enumerate(batches):
+            y = det * 2.0                                  # (work enqueued on the main stream behind the event)
+            t.submit(det, msk, counts, shp, windows)
+            del y
+        got = t.results()
+    finally:
+        t.close()
+    assert sorted(got) == sorted(want)
+    for key in want:
+        assert np.array_equal(got[key]["rois"], want[key]["rois"]) and got[key]["rles"] == want[key]["rles"]
+        assert np.array_equal(got[key]["scores"], want[key]["scores"])
+    assert t.results() == {}
+
+
+def test_rle_to_strings_equals_the_per_mask_codec(orc):
+    """sln_rle_to_strings (ABI 12) == sln_rle_to_string per row == the oracle's rleToString (maskApi.c:204-216)."""
+    from sln_amodal_amd import mask_rle, tail
+    rng = np.random.RandomState(4)
+    rows = [rng.randint(0, 5000, size=n).astype(np.uint32) for n in (1, 2, 3, 40, 0, 977)]
+    width = max(r.size for r in rows)
+    counts = np.zeros((len(rows), width), np.uint32)
+    for i, r in enumerate(rows):
+        counts[i, :r.size] = r
+    num = np.array([r.size for r in rows], np.int32)
+    got = tail.to_strings(counts, num)
+    assert got == [mask_rle.to_string(r) for r in rows]
+    assert got[3] == orc.rle_to_string(rows[3])

@@ -46,7 +46,10 @@ def run_fixed_batch(m, batch, pr, steps, lr, report):
             row = {"step": it, "total": float(loss), "norm": float(m.last_grad_norm)}
             row.update({k: float(v) for k, v in parts.items()})
             rows.append(row)
-    return rows, (opt.skipped_steps() if hasattr(opt, "skipped_steps") else 0)
+    # (skipped for a non-finite gradient norm, vetoed because an operand block clamped: round 6)
+    clamped = opt.skipped_clamped_steps() if hasattr(opt, "skipped_clamped_steps") else 0
+    run_fixed_batch.clamped_skips = clamped
+    return rows, (opt.skipped_steps() if hasattr(opt, "skipped_steps") else 0) - clamped
 
 
 def _fmt(rows):
@@ -116,28 +119,30 @@ def test_train_step_at_the_reference_learning_rate_stays_finite_and_fits_the_mas
     from sln_amodal_amd import conv_hip, nn_ops
     m, cfg, batch, pr = _prepared()
     start = {k: v.detach().clone() for k, v in m.state_dict().items()}
-    draws = []
+    draws, vetoed = [], []
     for d in range(3):
         sat0 = conv_hip.saturation_count()
         m.load_state_dict(start)
         rows, skipped = run_fixed_batch(m, batch, pr, 80, 0.01, (0, 20, 40, 79))
         draws.append((rows, skipped, conv_hip.saturation_count() - sat0))
+        vetoed.append(run_fixed_batch.clamped_skips)
     m.load_state_dict(start)
     nn_ops.BACKEND = "torch"
     try:
         aten, _ = run_fixed_batch(m, batch, pr, 80, 0.01, (0, 20, 40, 79))
     finally:
         nn_ops.BACKEND = "hip"
-    msg = "\n".join("HIP draw %d (skipped=%d saturated=%d)\n%s" % (d, sk, sa, _fmt(rows))
+    msg = "\n".join("HIP draw %d (skipped=%d saturated=%d vetoed steps=%d)\n%s" % (d, sk, sa, vetoed[d], _fmt(rows))
                     for d, (rows, sk, sa) in enumerate(draws)) + "\naten\n%s" % _fmt(aten)
     print(msg)
     gain_a = aten[0]["layer"] - aten[-1]["layer"]
-    for rows, skipped, saturated in draws:
-        # (an operand block that has to clamp -- the tensor outgrew the amax its scale was derived from one step earlier
-        # -- is what the scale book is for, and this regime provokes it: in 40 recorded draws 0 blocks in 37, 1, 1 and
-        # 11 (one freshly initialised head output in one step: a handful of workgroups) in the others, of ~2 M
-        # workgroups that write parts in 80 steps; the descent test above, at lr 0.001, asserts zero)
-        assert skipped == 0 and saturated <= 64, msg
+    for (rows, skipped, saturated), veto in zip(draws, vetoed):
+        # An operand block that has to clamp -- the tensor outgrew the amax its scale was derived from one step earlier
+        # -- is what this regime provokes (in 40 recorded draws of round 5: 0 blocks in 37, 1, 1 and 11 in the others).
+        # Round 6: such a step is NOT APPLIED (vetoed on the device, conv_hip.clamp_veto), so the bound is tight again:
+        # nothing skipped for a non-finite norm, at most 2 of the 80 steps vetoed, and a clamped block only ever in a
+        # vetoed step (saturated > 0 without a veto would be a clamped-and-applied step).
+        assert skipped == 0 and veto <= 2 and (saturated == 0) == (veto == 0), msg
         assert all(np.isfinite(v) for r in rows for v in r.values()), msg
         assert rows[-1]["layer"] < rows[0]["layer"] - 0.03, msg
         assert rows[-1]["layer"] <= aten[-1]["layer"] + 0.08, msg
