@@ -125,6 +125,10 @@ class InferenceTail(object):
 
     def __init__(self, device, depth=2, rle=True, keep_masks=False):
         self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("InferenceTail runs on the GPU only (no CPU path in sln_amodal_amd)")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.stream = torch.cuda.Stream(device=self.device)
         self.rle, self.keep_masks = rle, keep_masks
         self._q = queue.Queue(maxsize=max(1, int(depth)))
@@ -146,15 +150,27 @@ class InferenceTail(object):
             base = getattr(self, "_n", 0)
             keys = list(range(base, base + B))
             self._n = base + B
-        self._q.put((evt, detections, mrcnn_mask, num_detections, list(image_shapes), list(windows), list(keys)))
+        item = (evt, detections, mrcnn_mask, num_detections, list(image_shapes), list(windows), list(keys))
+        while True:                 # (a full queue with a dead worker must raise, not block for ever)
+            try:
+                self._q.put(item, timeout=1.0)
+                return
+            except queue.Full:
+                if self._err is not None or not self._thread.is_alive():
+                    raise RuntimeError("inference tail worker is not running") from self._err
 
     def _run(self):
-        torch.cuda.set_device(self.device)
+        try:
+            torch.cuda.set_device(self.device)
+        except BaseException as e:
+            self._err = e
         while True:
             item = self._q.get()
             try:
                 if item is None:
                     return
+                if self._err is not None:       # a failed worker drains its queue (results() raises)
+                    continue
                 evt, det, msk, num, shapes, windows, keys = item
                 with torch.cuda.stream(self.stream), torch.no_grad():
                     self.stream.wait_event(evt)

@@ -108,10 +108,18 @@ REST_TOL = [2e-3, 0.05, 0.06, 0.1, 0.2]       # (step 4, scene 1: 0.042 ... 0.09
 # per-step ratio hip / aten of the backbone slices ran 1.0, 12, 1.4, 2.7, 3.2 on scene 0 -- aten's own error jumps
 # x 15 one step later -- and 1.0, 1.1, 0.7, 0.9, 0.6 on scene 1): the worst step of the product path may be at most
 # CONTROL_FACTOR x the worst step of aten, per quantity.
-# (twelve runs of one build, `tools/margins_report.py`, profiles/r5_w_margins.txt: the backbone slices of scene 0 are the
-# quantity closest to its limit -- hip 0.28 ... 0.33 against aten 0.080 ... 0.089, a ratio of 3.1 ... 4.1; everything
-# else stays below 0.7 of 5 x aten)
-CONTROL_FACTOR = 6.0
+# Round 6: what the scene-0 ratio IS.  Twenty recorded runs of the backbone quantity: hip 0.28 ... 0.33
+# against aten 0.080 ... 0.089, a ratio of 3.1 ... 4.1, the same to three digits with every steady-state fusion switched
+# off, with the scales frozen, with the gradient roles' head room at 2^0 (profiles/r6_b_precision_fusions_0.txt).  It
+# is ONE 256-element slice -- output channel 0 of fpn.C2.2.conv2.weight, one channel's ReLU pattern under ~90 layers --
+# on ONE scene (scene 1: 0.6 ... 1.1 on every quantity).  The strict 3 x bf16 format on C1-C2 leaves 1.75, on C1-C4
+# (most of the backbone: the strict format's rate, half the headline) 1.0 -- with per-step errors equal to aten's to
+# three digits (profiles/r6_a_precision_subsets_0.txt): aten and the strict format round their operands like the
+# reference does (24 bits), the default format one bit shorter, and that channel's pattern on that scene sits within
+# the difference.  Per layer the default format is the MORE accurate of the two against fp64
+# (tests/test_precision_gpu.py); no cheap subset of strict layers removes the ratio, so the default stays and the
+# factor goes back from round 5's 6 to 5 (worst recorded ratio 4.1).
+CONTROL_FACTOR = 5.0
 
 
 @pytest.mark.parametrize("scene", [0, 1])

@@ -6,6 +6,7 @@ must stay bit-identical."""
 import os
 import socket
 
+import numpy as np
 import pytest
 import torch
 import torch.distributed as dist
@@ -210,4 +211,44 @@ def test_bench_launches_its_own_ranks():
     a0, a1 = (g["cpu_affinity"] for g in gx["per_rank"])
     assert a0["last"] < a1["first"]              # disjoint shares of the host cores
     # another problem than the headline's: no replayed counter file next to this run's numbers
+    assert out["roofline"]["traffic"] is None
+
+
+@pytest.mark.timeout(1500)
+def test_bench_launches_eight_ranks_on_one_gpu_over_gloo():
+    """`python bench.py --gpus 8` (eight-process readiness without eight GPUs): the parent starts EIGHT
+    ranks that share cuda:0 and exchange through gloo, at a small shape.  What an 8-GPU node's first run depends on
+    besides RCCL itself is asserted from rank 0's line: world_size_seen == 8, eight per_rank entries with their own
+    step times and exchange diagnostics, one bucket launch order, eight disjoint core shares (when the host has >= 8
+    cores), the same number of buckets on every rank, the step's clamp veto riding on the last bucket (no extra
+    collective), a finite loss.  No scaling number is read off this run."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    _release_parent_memory()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env["SLN_DIST_BACKEND"] = "gloo"
+    env["SLN_DIST_TIMEOUT_S"] = "600"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "2",
+                        "--warmup", "1", "--settle", "1", "--batch", "1", "--dim", "128", "--arch", "resnet50",
+                        "--no-cpu-baseline", "--no-strict"], env=env, capture_output=True, text=True, timeout=1400)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["config"]["parallelism"] == "dp8" and out["scaling"] == "weak"
+    assert out["value"] > 0 and np.isfinite(out["config"]["final_loss"])
+    gx = out["gradient_exchange"]
+    assert gx["world_size_seen"] == 8 and gx["backend"] == "gloo"
+    assert [g["rank"] for g in gx["per_rank"]] == list(range(8))
+    assert gx["bucket_launch_order"] == list(range(gx["buckets"])) and gx["buckets"] >= 2
+    for g in gx["per_rank"]:
+        assert g["step_ms_min"] > 0 and g["finishes"] >= 2 and g["buckets"] == gx["buckets"]
+        assert "exposed_wait_ms_mean" in g and "host_wait_ms_mean" in g
+    if (os.cpu_count() or 1) >= 8:
+        shares = [g["cpu_affinity"] for g in gx["per_rank"]]
+        assert all(s.get("cores", 0) >= 1 for s in shares)
+        assert all(a["last"] < b["first"] for a, b in zip(shares, shares[1:]))       # eight disjoint ranges
+    assert out["config"]["clamped_and_applied_blocks"] == 0
     assert out["roofline"]["traffic"] is None

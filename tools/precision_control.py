@@ -97,6 +97,19 @@ def rel(a, b):
     return float((a - b).norm() / b.norm().clamp_min(1e-300))
 
 
+def med(a, b):
+    """MEDIAN over the elements of |a - b| / |b| (b != 0): the relative L2 norm above is carried by a tensor's largest
+    elements; this one says what a TYPICAL element keeps -- where a per-tensor scaled format would show its exponent
+    floor on heavy-tailed tensors."""
+    nz = b != 0
+    if not bool(nz.any()):
+        return 0.0
+    q = ((a - b).abs()[nz] / b.abs()[nz]).flatten()
+    if q.numel() > (1 << 22):
+        q = q[:: q.numel() // (1 << 22)]
+    return float(q.median())
+
+
 def table(kinds=("gauss", "net"), shapes=SHAPES, modes=("p2", "p3", "aten")):
     """-> rows {shape, kind, what, K, p2, p3, aten, p2_over_aten}: relative L2 error against fp64."""
     rows = []
@@ -105,7 +118,7 @@ def table(kinds=("gauss", "net"), shapes=SHAPES, modes=("p2", "p3", "aten")):
         for kind in kinds:
             x, w, upstream = make_operands(shape, kind)
             ref = None
-            outs = {}
+            outs, meds = {}, {}
             for mode in ("ref",) + tuple(modes):
                 if mode == "ref":
                     pt = _pads(k, dil)[0]
@@ -116,11 +129,13 @@ def table(kinds=("gauss", "net"), shapes=SHAPES, modes=("p2", "p3", "aten")):
                     ref = res
                 else:
                     outs[mode] = [rel(a, b) for a, b in zip(res, ref)]
+                    meds[mode] = [med(a, b) for a, b in zip(res, ref)]
                 del res
             kk = {"forward": Cin * k * k, "data gradient": Cout * k * k, "weight gradient": N * up.shape[2] * up.shape[3]}
             for i, what in enumerate(("forward", "data gradient", "weight gradient")):
                 row = {"shape": name, "kind": kind, "what": what, "K": kk[what]}
                 row.update({m: outs[m][i] for m in modes})
+                row.update({m + "_med": meds[m][i] for m in modes})
                 if "aten" in outs and "p2" in outs:
                     row["p2_over_aten"] = outs["p2"][i] / max(outs["aten"][i], 1e-300)
                 rows.append(row)
@@ -136,6 +151,15 @@ def fmt(rows):
         lines.append("%-40s %-6s %-16s %8d  %9.2e %9.2e %9.2e  %5.2f" % (
             r["shape"], r["kind"], r["what"], r["K"], r.get("p2", float("nan")), r.get("p3", float("nan")),
             r.get("aten", float("nan")), r.get("p2_over_aten", float("nan"))))
+    if rows and "p2_med" in rows[0]:
+        lines.append("")
+        lines.append("median over the elements of |error| / |value| (what a typical element keeps):")
+        lines.append("%-40s %-6s %-16s  %9s %9s %9s  %s" % ("layer", "input", "pass", "HIP 2xf16", "HIP 3xbf16", "aten f32",
+                                                          "2xf16 / aten"))
+        for r in rows:
+            lines.append("%-40s %-6s %-16s  %9.2e %9.2e %9.2e  %5.2f" % (
+                r["shape"], r["kind"], r["what"], r.get("p2_med", float("nan")), r.get("p3_med", float("nan")),
+                r.get("aten_med", float("nan")), r.get("p2_med", 0.0) / max(r.get("aten_med", 0.0), 1e-300)))
     return "\n".join(lines)
 
 
