@@ -297,23 +297,64 @@ def main_resnext(args, rank, world, dev):
 
     for i in range(max(args.warmup, 2)):        # (>= 2: the first step bootstraps every operand scale exactly)
         step(i)
+    # --graph: the whole train step -- scale update, forward at three scales, four losses, backward, SGD -- captured
+    # ONCE in a HIP graph and replayed (round 6; VERDICT r5 #4c).  The step has no host synchronisation, so it captures
+    # whole; what a replay removes is the HOST side of ~1 750 launches of ~30 us kernels (the eager step is
+    # launch-bound: 56 ms of kernels in a 64-ms step).  Same kernels, same work, same order; the two input batches
+    # alternate through a static input buffer (one device copy per step, inside the timed region).
+    graph = None
+    if args.graph:
+        if world > 1:
+            raise SystemExit("bench.py --config resnext --graph: single-GPU only (the collective is not captured)")
+        x_static = xs[0].clone()
+        eager_step = step
+
+        def body():
+            conv_hip.update_scales()
+            outs_ = net(x_static)
+            loss_ = sum(F.cross_entropy(F.interpolate(o, size=(oh, oh), mode="bilinear", align_corners=False), target)
+                        for o in outs_)
+            opt.zero_grad(set_to_none=True)
+            loss_.backward()
+            opt.step()
+            return loss_
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                 # (capture prerequisites: warm up on a side stream)
+            for _ in range(3):
+                body()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            loss_static = body()
+
+        def step(i):
+            x_static.copy_(xs[i % 2])
+            graph.replay()
+            return loss_static.clone()
     # one step under the live profile: every launch's algorithmic FLOPs (forward + data + weight gradients) next to
     # the 3 x forward estimate below, and the activations that exist as their fp16 part alone
     conv_hip.PROFILE = []
     po0 = conv_hip.PO_STATS[0]
-    step(0)
+    (eager_step if graph is not None else step)(0)
     torch.cuda.synchronize()
     po_per_step = conv_hip.PO_STATS[0] - po0
     prof_all = sum(e[2] for e in conv_hip.PROFILE)
+    prof_eager_step = list(conv_hip.PROFILE)
     conv_hip.PROFILE = None
-    if rank == 0:
-        conv_hip.PROFILE = []
+    if rank == 0 and graph is None:
+        conv_hip.PROFILE = []       # (a replayed graph runs no Python: the per-launch events of the eager step above stand in)
     barrier()
     t0 = time.perf_counter()
     losses = [step(i).detach() for i in range(args.steps)]
     barrier()
     elapsed = time.perf_counter() - t0
     prof, conv_hip.PROFILE = conv_hip.PROFILE, None
+    if graph is not None:
+        # the dominant kernel's roofline from the eager step profiled above (same launches; their durations under
+        # the graph are not observable per launch), priced over ONE step
+        prof = prof_eager_step
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -333,11 +374,13 @@ def main_resnext(args, rank, world, dev):
                "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / max(args.steps, 1), 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16" if P == 1 else "f32",
                "data": "synthetic",
-               "roofline": dominant_kernel_roofline(prof, elapsed, P, replay_traffic=False),
+               "roofline": dominant_kernel_roofline(prof, elapsed / args.steps if graph is not None else elapsed, P,
+                                                    replay_traffic=False),
                "config": {"workload": "BASELINE.json configs[4]: ResNeXt-101 (3,4,23,3; 32 groups) + ASPP(6,12,18,24) under "
                                       "the multi-scale wrapper (scales 1 / 0.5 / 0.75 + maximum), train step, "
                                       "%d x %dx%d images/GPU, %d classes" % (batch, dim, dim, classes),
                           "images_per_gpu": batch, "image_dim": dim, "parallelism": "dp%d" % world,
+                          "hip_graph": graph is not None,
                           "conv_operand_format": fmt, "conv_split_parts": P,
                           "conv_saturated_blocks": conv_hip.saturation_count(),
                           "parts_only_activations_per_step": po_per_step,
@@ -489,6 +532,9 @@ def main():
     ap.add_argument("--workers", type=int, default=None, help="--data files: loader worker processes per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-strict", action="store_true", help="skip the 5 extra steps in the 3 x bf16 format")
+    ap.add_argument("--graph", action="store_true",
+                    help="--config resnext: capture the whole train step in one HIP graph and replay it (the eager step "
+                         "is launch-bound)")
     ap.add_argument("--cold-start", action="store_true",
                     help="the reference's start of a run: after the set-up the weights go through a checkpoint in the "
                          "reference's state-dict layout into a NEW model object (no operand-scale history; reference "
@@ -635,6 +681,7 @@ def main():
     reruns = 0
     while True:
         skipc_before = clamped_skips()
+        sat_before = conv_hip.saturation_count()
         sat_snaps = [conv_hip.saturation_snapshot()]   # device-side copies, one per timed step: no host sync
         if rank == 0:
             conv_hip.PROFILE = []          # HIP-event pairs around every conv launch (launch stream)
@@ -680,7 +727,8 @@ def main():
     for k_ in range(args.steps):
         for role, shape, blocks in conv_hip.saturation_report(sat_snaps[k_], sat_snaps[k_ + 1]):
             sat_events.append({"step": k_, "role": role, "layer_weight_shape": shape, "blocks": blocks})
-    sat_timed = conv_hip.saturation_count() - sat_warmup
+    sat_timed = conv_hip.saturation_count() - sat_before          # (of the timing that is printed)
+    sat_discarded = sat_before - sat_warmup                       # (of timings discarded for a vetoed step)
     prof, conv_hip.PROFILE = conv_hip.PROFILE, None
     max_mem_gb = round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)      # (of the fp16 x 2 steps: before the strict leg)
     # the same step in the strict operand format (3 x bf16, 6 MFMA products per multiply-add: >= fp32 per
@@ -768,8 +816,9 @@ def main():
                        # printed); with the guard on (default) no clamped block reaches the weights
                        "clamped_and_skipped_steps": [skipc_setup, skipc_warmup - skipc_setup, skipc_timed],
                        "clamped_and_applied_blocks": 0 if conv_hip.SKIP_CLAMPED_STEPS and hasattr(opt, "skipped_clamped_steps")
-                       else sat_setup + (sat_warmup - sat_setup) + sat_timed,
-                       "timed_region_reruns": reruns, "cold_start": bool(args.cold_start),
+                       else sat_setup + (sat_warmup - sat_setup) + sat_discarded + sat_timed,
+                       "timed_region_reruns": reruns, "conv_saturated_blocks_in_discarded_timings": sat_discarded,
+                       "cold_start": bool(args.cold_start),
                        "setup_scale_settle_steps": args.settle},
             "step_roofline": {"bound": "mfma", "kernel": "whole train step (all kernels)",
                               "achieved": round(achieved, 3), "peak": round(split_peak(conv_hip.PARTS), 1),

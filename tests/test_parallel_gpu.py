@@ -233,7 +233,9 @@ def test_bench_launches_eight_ranks_on_one_gpu_over_gloo():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "2",
                         "--warmup", "1", "--settle", "1", "--batch", "1", "--dim", "128", "--arch", "resnet50",
                         "--no-cpu-baseline", "--no-strict"], env=env, capture_output=True, text=True, timeout=1400)
-    assert r.returncode == 0, r.stderr[-3000:]
+    # (the FIRST rank to fail is the cause; its peers' "connection closed by peer" follow)
+    first = [l for l in r.stderr.splitlines() if "Error" in l and "Connection closed" not in l][:5]
+    assert r.returncode == 0, "\n".join(first) + "\n...\n" + r.stderr[-1500:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
