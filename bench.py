@@ -302,7 +302,9 @@ def main_resnext(args, rank, world, dev):
     # whole; what a replay removes is the HOST side of ~1 750 launches of ~30 us kernels (the eager step is
     # launch-bound: 56 ms of kernels in a 64-ms step).  Same kernels, same work, same order; the two input batches
     # alternate through a static input buffer (one device copy per step, inside the timed region).
-    graph = None
+    graph, graph_error = None, None
+    if args.graph is None:
+        args.graph = world == 1         # default: captured on one GPU (the collective of N > 1 is not captured)
     if args.graph:
         if world > 1:
             raise SystemExit("bench.py --config resnext --graph: single-GPU only (the collective is not captured)")
@@ -325,14 +327,18 @@ def main_resnext(args, rank, world, dev):
                 body()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            loss_static = body()
-
-        def step(i):
-            x_static.copy_(xs[i % 2])
-            graph.replay()
-            return loss_static.clone()
+        try:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                loss_static = body()
+        except Exception as e:                        # (a build whose capture fails runs the eager step, and says so)
+            graph, graph_error = None, str(e)[:200]
+            torch.cuda.synchronize()
+        if graph is not None:
+            def step(i):
+                x_static.copy_(xs[i % 2])
+                graph.replay()
+                return loss_static.clone()
     # one step under the live profile: every launch's algorithmic FLOPs (forward + data + weight gradients) next to
     # the 3 x forward estimate below, and the activations that exist as their fp16 part alone
     conv_hip.PROFILE = []
@@ -380,7 +386,7 @@ def main_resnext(args, rank, world, dev):
                                       "the multi-scale wrapper (scales 1 / 0.5 / 0.75 + maximum), train step, "
                                       "%d x %dx%d images/GPU, %d classes" % (batch, dim, dim, classes),
                           "images_per_gpu": batch, "image_dim": dim, "parallelism": "dp%d" % world,
-                          "hip_graph": graph is not None,
+                          "hip_graph": graph is not None, "hip_graph_error": graph_error,
                           "conv_operand_format": fmt, "conv_split_parts": P,
                           "conv_saturated_blocks": conv_hip.saturation_count(),
                           "parts_only_activations_per_step": po_per_step,
@@ -532,9 +538,10 @@ def main():
     ap.add_argument("--workers", type=int, default=None, help="--data files: loader worker processes per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-strict", action="store_true", help="skip the 5 extra steps in the 3 x bf16 format")
-    ap.add_argument("--graph", action="store_true",
+    ap.add_argument("--graph", dest="graph", action="store_true", default=None,
                     help="--config resnext: capture the whole train step in one HIP graph and replay it (the eager step "
-                         "is launch-bound)")
+                         "is launch-bound: ~1 750 launches of ~30 us); the default on one GPU")
+    ap.add_argument("--no-graph", dest="graph", action="store_false", help="--config resnext: the eager step")
     ap.add_argument("--cold-start", action="store_true",
                     help="the reference's start of a run: after the set-up the weights go through a checkpoint in the "
                          "reference's state-dict layout into a NEW model object (no operand-scale history; reference "

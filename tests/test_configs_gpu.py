@@ -230,6 +230,7 @@ def test_bench_config_resnext_fp16_at_its_default_size_prints_the_contract_line(
         assert k in out, k
     cfg = out["config"]
     assert out["dtype"] == "f16" and cfg["conv_split_parts"] == 1
+    assert cfg["hip_graph"] is True, cfg.get("hip_graph_error")      # the whole step replayed from one HIP graph (round 6)
     assert cfg["images_per_gpu"] == 32 and cfg["image_dim"] == 321 and out["n_gpus"] == 1
     assert cfg["conv_saturated_blocks"] == 0
     assert cfg["parts_only_activations_per_step"] >= 300
