@@ -196,19 +196,32 @@ def launch_ranks(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if have < n:
+            # several ranks share a GPU (the gloo functional check): keep the processes' hardware queues inside what
+            # the device schedules without evicting queues -- with 8 ranks + a parent that holds streams of its own,
+            # 4 queues per process oversubscribe the GPU and a rank dies with HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION
+            # behind a queue restore (profiles/HISTORY_r6.md; a one-GPU-per-rank run never gets here)
+            env.setdefault("GPU_MAX_HW_QUEUES", "2")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     import time
     rc = 0
     while any(p.poll() is None for p in procs):
-        if any(p.poll() not in (None, 0) for p in procs):      # a rank died: its peers would wait in a collective
+        dead = [(r, p.poll()) for r, p in enumerate(procs) if p.poll() not in (None, 0)]
+        if dead:      # a rank died: its peers would wait in a collective
+            # (say WHICH rank went first and how: the peers' "connection closed by peer" tracebacks follow it)
+            print("bench.py: rank %d exited first with code %d%s; stopping the other ranks" % (
+                dead[0][0], dead[0][1], " (signal %d)" % -dead[0][1] if dead[0][1] < 0 else ""), file=sys.stderr, flush=True)
             time.sleep(2.0)
             for p in procs:
                 if p.poll() is None:
                     p.terminate()
             break
         time.sleep(0.2)
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
+    codes = [p.wait() for p in procs]
+    if any(codes):
+        print("bench.py: rank exit codes %s" % codes, file=sys.stderr, flush=True)
+    for c in codes:
+        rc = max(rc, abs(c))
     return rc
 
 

@@ -234,7 +234,11 @@ def test_bench_launches_eight_ranks_on_one_gpu_over_gloo():
                         "--warmup", "1", "--settle", "1", "--batch", "1", "--dim", "128", "--arch", "resnet50",
                         "--no-cpu-baseline", "--no-strict"], env=env, capture_output=True, text=True, timeout=1400)
     # (the FIRST rank to fail is the cause; its peers' "connection closed by peer" follow)
-    first = [l for l in r.stderr.splitlines() if "Error" in l and "Connection closed" not in l][:5]
+    first = [l for l in r.stderr.splitlines() if ("Error" in l or l.startswith("bench.py:") or "Killed" in l or
+                                                    "fault" in l.lower()) and "Connection closed" not in l][:8]
+    if r.returncode != 0:
+        with open(os.path.join(os.environ.get("TMPDIR", "/tmp"), "sln_world8_stderr.txt"), "w") as fh:
+            fh.write(r.stderr)
     assert r.returncode == 0, "\n".join(first) + "\n...\n" + r.stderr[-1500:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
