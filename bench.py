@@ -40,7 +40,7 @@ def split_peak(parts):
 PEAK_HBM_GBS = 8000.0
 # HBM bytes per launch cannot be collected live (PMC needs rocprofv3 around the process): the bench line
 # REPLAYS the committed counter passes of the same command and marks them as such
-PMC_TRAFFIC = os.path.join("profiles", "r5_ai_pmc_traffic.json")
+PMC_TRAFFIC = os.path.join("profiles", "r6_e_pmc_traffic.json")
 
 
 def step_gflop_per_image(stage, dim, arch):

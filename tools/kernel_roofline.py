@@ -5,7 +5,7 @@ import torch
 
 PEAK_HBM_GBS = 8000.0
 # the committed counter pass that `measured_*` replays (tools/collect_pmc.sh; the headline problem only)
-PMC_ROIALIGN = "r5_ai_pmc_roialign.json"
+PMC_ROIALIGN = "r6_e_pmc_roialign.json"
 
 
 def _time(fn, iters=10, warmup=3):
