@@ -1,0 +1,7 @@
+#!/bin/bash
+# flake check: the driver's suite command twice more on one box
+set -u
+out=gpurun_out; mkdir -p $out
+for i in 2 3; do
+  python3 -m pytest tests -m gpu -x -q > $out/r6_i_gpu_suite_run$i.log 2>&1; echo "run $i rc=$?"; tail -2 $out/r6_i_gpu_suite_run$i.log
+done
