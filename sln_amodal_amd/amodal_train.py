@@ -235,14 +235,57 @@ class AmodalDataset(object):
             # event and runs the device half (loader.py)
             self.start_workers()
             N = self.max_objects
-            for item in self._pipe:
-                if item["ready"] is not None:
-                    torch.cuda.current_stream(self.device).wait_event(item["ready"])
-                    for t in (item["u8"], item["labels"], item["src_hw"]):
-                        t.record_stream(torch.cuda.current_stream(self.device))
+            # (round 6) the device half of batch k + 1 -- label zoom, object count, molding, boxes, RPN targets: ~5 ms
+            # of small kernels for 16 images -- is enqueued on a SIDE stream while train step k runs on the training
+            # stream: a one-deep pipeline inside this iterator, no extra thread.  The consumer's stream waits on the
+            # batch's event only.  SLN_LOADER_ASSEMBLE_STREAM=0: on the training stream, as in round 5.
+            cuda = torch.device(self.device).type == "cuda"
+            side = None
+            if cuda and os.environ.get("SLN_LOADER_ASSEMBLE_STREAM", "1") != "0":
+                side = getattr(self, "_assemble_stream", None)
+                if side is None:
+                    side = self._assemble_stream = torch.cuda.Stream(device=self.device)
+
+            def assemble(item):
                 jitter = self._jitter_rng.rand(B, N, 4)
-                yield self._assemble(item["u8"], item["labels"], item["src_hw"], item["src_hw_host"], item["flips"],
-                                     jitter, host_zoomed=item["host_zoomed"])
+                if side is None:
+                    if item["ready"] is not None:
+                        torch.cuda.current_stream(self.device).wait_event(item["ready"])
+                        for t in (item["u8"], item["labels"], item["src_hw"]):
+                            t.record_stream(torch.cuda.current_stream(self.device))
+                    return self._assemble(item["u8"], item["labels"], item["src_hw"], item["src_hw_host"],
+                                          item["flips"], jitter, host_zoomed=item["host_zoomed"]), None
+                with torch.cuda.stream(side):
+                    if item["ready"] is not None:
+                        side.wait_event(item["ready"])
+                    for t in (item["u8"], item["labels"], item["src_hw"]):
+                        t.record_stream(side)
+                    batch = self._assemble(item["u8"], item["labels"], item["src_hw"], item["src_hw_host"],
+                                           item["flips"], jitter, host_zoomed=item["host_zoomed"])
+                    done = torch.cuda.Event()
+                    done.record(side)
+                return batch, done
+
+            def hand_over(batch, done):
+                if done is not None:
+                    main = torch.cuda.current_stream(self.device)
+                    main.wait_event(done)
+                    for v in batch.values():        # allocated on the side stream, read (and freed) on this one
+                        if torch.is_tensor(v):
+                            v.record_stream(main)
+                return batch
+
+            ahead = None
+            for item in self._pipe:
+                nxt = assemble(item)
+                if side is None:
+                    yield hand_over(*nxt)
+                    continue
+                if ahead is not None:
+                    yield hand_over(*ahead)
+                ahead = nxt
+            if ahead is not None:
+                yield hand_over(*ahead)
             return
         sampler = None
         if self.files:
