@@ -658,8 +658,8 @@ def main():
         model.set_trainable(LAYER_REGEX[args.stage], exclusive_off=False)
         for p in model.GLM_modual.parameters():
             p.requires_grad = False
-        conv_hip_ = __import__("sln_amodal_amd.conv_hip", fromlist=["x"])
-        conv_hip_.update_scales()     # (the old model's slots died with it: their table entries are recycled)
+        from sln_amodal_amd import conv_hip as _conv_hip
+        _conv_hip.update_scales()     # (the old model's slots died with it: their table entries are recycled)
 
     if file_data is not None:
         file_data.bind(model, dev)
