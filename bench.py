@@ -920,6 +920,8 @@ def main():
                 "roialign_bwd_measured_hbm_frac": rk["roialign_bwd"]["measured_hbm_frac"],
                 "roialign_bwd_measured_hbm_gbs": rk["roialign_bwd"]["measured_hbm_gbs"],
                 "roialign_bwd_whole_op_frac_of_36B_model": rk["roialign_bwd"]["model_frac_whole_op"],
+                # ... and of the roof the scatter really stands under: memory-side float adds, ~1.3 TB/s of added bytes
+                "roialign_bwd_atomic_add_frac": rk["roialign_bwd"]["atomic_add_frac"],
                 "nms_us_per_image": rk["nms"]["us_per_image"]})
         except Exception as e:  # pragma: no cover
             out["roofline_kernels"] = {"error": str(e)[:200]}
