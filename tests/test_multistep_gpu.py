@@ -112,7 +112,8 @@ REST_TOL = [2e-3, 0.05, 0.06, 0.1, 0.2]       # (step 4, scene 1: 0.042 ... 0.09
 # against aten 0.080 ... 0.089, a ratio of 3.1 ... 4.1, the same to three digits with every steady-state fusion switched
 # off, with the scales frozen, with the gradient roles' head room at 2^0 (profiles/r6_b_precision_fusions_0.txt).  It
 # is ONE 256-element slice -- output channel 0 of fpn.C2.2.conv2.weight, one channel's ReLU pattern under ~90 layers --
-# on ONE scene (scene 1: 0.6 ... 1.1 on every quantity).  The strict 3 x bf16 format on C1-C2 leaves 1.75, on C1-C4
+# on ONE scene (scene 1: 0.4 ... 1.3 on every quantity, and there the STRICT format is the farthest on the losses:
+# profiles/r6_k_precision_subsets_1.txt).  The strict 3 x bf16 format on C1-C2 leaves 1.75, on C1-C4
 # (most of the backbone: the strict format's rate, half the headline) 1.0 -- with per-step errors equal to aten's to
 # three digits (profiles/r6_a_precision_subsets_0.txt): aten and the strict format round their operands like the
 # reference does (24 bits), the default format one bit shorter, and that channel's pattern on that scene sits within
