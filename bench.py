@@ -40,7 +40,7 @@ def split_peak(parts):
 PEAK_HBM_GBS = 8000.0
 # HBM bytes per launch cannot be collected live (PMC needs rocprofv3 around the process): the bench line
 # REPLAYS the committed counter passes of the same command and marks them as such
-PMC_TRAFFIC = os.path.join("profiles", "r6_e_pmc_traffic.json")
+PMC_TRAFFIC = os.path.join("profiles", "r6_f_pmc_traffic.json")
 
 
 def step_gflop_per_image(stage, dim, arch):
@@ -920,8 +920,9 @@ def main():
                 "roialign_bwd_measured_hbm_frac": rk["roialign_bwd"]["measured_hbm_frac"],
                 "roialign_bwd_measured_hbm_gbs": rk["roialign_bwd"]["measured_hbm_gbs"],
                 "roialign_bwd_whole_op_frac_of_36B_model": rk["roialign_bwd"]["model_frac_whole_op"],
-                # ... and of the roof the scatter really stands under: memory-side float adds, ~1.3 TB/s of added bytes
-                "roialign_bwd_atomic_add_frac": rk["roialign_bwd"]["atomic_add_frac"],
+                # ... and what the scatter is really bound by: memory-side float adds (the guide measures ~1.3 TB/s of
+                # added bytes chip-wide; this is the kernel's rate over that figure)
+                "roialign_bwd_atomic_add_rate_vs_guide": rk["roialign_bwd"]["atomic_add_rate_vs_guide"],
                 "nms_us_per_image": rk["nms"]["us_per_image"]})
         except Exception as e:  # pragma: no cover
             out["roofline_kernels"] = {"error": str(e)[:200]}
