@@ -475,6 +475,37 @@ def main_detect(args, rank, world, dev):
             tail.submit(detections, mrcnn_mask, model.last_num_detections, shapes, windows)
         return detections, 0
 
+    # --graph (default on one GPU; --no-graph: eager): the batched inference step has no host synchronisation either
+    # (tests run it under torch's sync-debug mode "error"), so it captures whole -- 185 -> 194 img/s, same-box
+    # (profiles/r6_l_detect*.json); the hand-off gets CLONES of the graph's static outputs (1.3 MB)
+    graph = graph_error = None
+    if args.graph is None:
+        args.graph = world == 1
+    if args.graph:
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side), torch.no_grad():
+                for _ in range(3):
+                    model.predict([x, metas], mode="inference")
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph), torch.no_grad():
+                g_det, g_msk = model.predict([x, metas], mode="inference")
+                g_num = model.last_num_detections
+        except Exception as e:
+            graph, graph_error = None, str(e)[:200]
+            torch.cuda.synchronize()
+        if graph is not None:
+            eager_step = step
+
+            def step():
+                graph.replay()
+                if tail is not None:
+                    tail.submit(g_det.clone(), g_msk.clone(), g_num.clone(), shapes, windows)
+                return g_det, 0
+
     def barrier():
         if world > 1:
             dist.barrier()
@@ -484,7 +515,15 @@ def main_detect(args, rank, world, dev):
         step()
     if tail is not None:
         tail.results()
-    if rank == 0:
+    prof_eager = None
+    if graph is not None:            # (a replay runs no Python: one eager step's launches stand in for the roofline)
+        conv_hip.PROFILE = []
+        eager_step()
+        torch.cuda.synchronize()
+        prof_eager, conv_hip.PROFILE = conv_hip.PROFILE, None
+        if tail is not None:
+            tail.results()
+    if rank == 0 and graph is None:
         conv_hip.PROFILE = []
     barrier()
     t0 = time.perf_counter()
@@ -504,6 +543,8 @@ def main_detect(args, rank, world, dev):
     elapsed = float(t.item())
     if rank == 0:
         counts = model.last_num_detections.cpu().numpy()
+        if prof_eager is not None:
+            prof = prof_eager * args.steps          # (the same launches every step)
         flops = sum(e[2] for e in prof) / max(args.steps, 1)              # algorithmic conv FLOPs per step (forward only)
         value = batch * world * args.steps / elapsed
         achieved = flops * args.steps / elapsed / 1e12
@@ -519,6 +560,7 @@ def main_detect(args, rank, world, dev):
                                       "%d x %dx%d images/GPU" % (arch, batch, dim, dim),
                           "arch": arch, "images_per_gpu": batch, "image_dim": dim, "parallelism": "dp%d" % world,
                           "conv_split_parts": conv_hip.PARTS, "tail": bool(args.tail),
+                          "hip_graph": graph is not None, "hip_graph_error": graph_error,
                           "detections_last_batch": [int(c) for c in counts], "rle_masks_encoded": n_rle,
                           "max_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)},
                "step_roofline": {"bound": "mfma", "kernel": "whole inference step (all kernels)",
@@ -552,9 +594,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-strict", action="store_true", help="skip the 5 extra steps in the 3 x bf16 format")
     ap.add_argument("--graph", dest="graph", action="store_true", default=None,
-                    help="--config resnext: capture the whole train step in one HIP graph and replay it (the eager step "
-                         "is launch-bound: ~1 750 launches of ~30 us); the default on one GPU")
-    ap.add_argument("--no-graph", dest="graph", action="store_false", help="--config resnext: the eager step")
+                    help="--config resnext / detect: capture the whole step in one HIP graph and replay it (the eager "
+                         "resnext step is launch-bound: ~1 750 launches of ~30 us); the default on one GPU")
+    ap.add_argument("--no-graph", dest="graph", action="store_false", help="--config resnext / detect: the eager step")
     ap.add_argument("--cold-start", action="store_true",
                     help="the reference's start of a run: after the set-up the weights go through a checkpoint in the "
                          "reference's state-dict layout into a NEW model object (no operand-scale history; reference "

@@ -535,6 +535,8 @@ def test_bench_config_detect_prints_the_contract_line():
         assert k in out, k
     assert out["n_gpus"] == 1 and out["value"] > 0 and out["config"]["images_per_gpu"] == 2
     assert out["config"]["arch"] == "resnet50" and out["config"]["tail"] is True
+    assert out["config"]["hip_graph"] is True, out["config"].get("hip_graph_error")      # (round 6: replayed from one HIP graph)
+    assert out["config"]["rle_masks_encoded"] > 0
     assert out["roofline"]["traffic"] is None and out["step_roofline"]["algorithmic_tflop_per_step"] > 0
     assert len(out["config"]["detections_last_batch"]) == 2
 
