@@ -240,3 +240,26 @@ def test_clamp_veto_travels_with_the_last_bucket_world2_gloo():
             p.join(10)
     assert [p.exitcode for p in procs] == [0, 0]
     assert sorted(q.get(timeout=5) for _ in range(2)) == [0, 1]
+
+
+def test_self_launcher_names_the_rank_that_died_first():
+    """`bench.py --gpus 2` over gloo on a host WITHOUT a GPU: both ranks fail at start-up (the product has no CPU path);
+    the launcher must list every rank's exit code (and, when one rank dies while its peers still run, name it: "rank R
+    exited first with code C" -- here both are gone within one poll), print no JSON line and exit non-zero -- what a
+    maintainer reads when a rank of a real multi-GPU run dies (round 6: the peers' "connection closed by peer"
+    tracebacks used to be all there was)."""
+    import subprocess
+    import sys
+    if torch.cuda.is_available():
+        pytest.skip("needs a host without a GPU (on a GPU box the two ranks run)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env["SLN_DIST_BACKEND"] = "gloo"
+    env["SLN_DIST_TIMEOUT_S"] = "30"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--settle", "0", "--batch", "1", "--dim", "128", "--arch", "resnet50", "--no-cpu-baseline",
+                        "--no-strict"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert "bench.py: rank exit codes [1, 1]" in r.stderr, r.stderr[-1500:]
+    assert "No HIP GPUs are available" in r.stderr
